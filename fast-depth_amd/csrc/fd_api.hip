@@ -1,0 +1,491 @@
+// fd_api.hip -- host side of libfastdepth_hip.so: plan construction, workspace layout, kernel
+// selection/launch, and the C ABI declared in include/fastdepth_hip.h.
+//
+// The plan is the MI355X-native replacement for walking an nn.Sequential tree per call
+// (reference models.py:706-732): the network is analysed once into a flat list of fused kernels with
+// fixed grids, tile shapes and buffer addresses, so a forward is ~38 back-to-back launches on the
+// caller's stream with no host-side decisions, allocations or synchronisation in between.
+#include "fd_kernels_f32.h"
+#include "../../include/fastdepth_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+struct PwCfg { int wgm, wgn, tm, tn; };
+
+struct Layer {
+    fd_layer_desc d;
+    int in_h = 0, in_w = 0;      // logical input size (after upsampling)
+    int out_h = 0, out_w = 0;
+    size_t out_off = 0, out_bytes = 0;   // activation arena
+    size_t w_off = 0, w_bytes = 0, b_off = 0;   // packed weights / bias
+    bool to_output = false;      // writes the network output buffer directly
+    bool head = false;           // Cout == 1 pointwise: fd_head_pw1_f32
+    // dw tiling
+    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0;
+    // stem
+    int chunk = 0;
+    // pw
+    PwCfg pw{};
+    size_t lds = 0;
+    dim3 grid;
+    std::string info, sym;
+    double alg_bytes = 0, alg_flops = 0;
+};
+
+}  // namespace
+
+struct fd_plan {
+    std::vector<Layer> layers;
+    int B = 0, H = 0, W = 0, dtype = 0;
+    uint32_t flags = 0;
+    size_t ws_bytes = 0, weights_bytes = 0;
+    unsigned char *ws = nullptr;
+    bool packed = false;
+    double alg_bytes = 0, alg_flops = 0;
+};
+
+namespace {
+
+// ---- lifetime-based arena ------------------------------------------------------------------------
+struct FreeList {
+    std::vector<std::pair<size_t, size_t>> blocks;   // (offset, size), sorted by offset
+    size_t top = 0;
+    size_t alloc(size_t bytes)
+    {
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].second >= bytes) {
+                size_t off = blocks[i].first;
+                blocks[i].first += bytes;
+                blocks[i].second -= bytes;
+                if (blocks[i].second == 0) blocks.erase(blocks.begin() + i);
+                return off;
+            }
+        // grow: extend a trailing free block if it touches the top
+        if (!blocks.empty() && blocks.back().first + blocks.back().second == top) {
+            size_t off = blocks.back().first;
+            top = off + bytes;
+            blocks.pop_back();
+            return off;
+        }
+        size_t off = top;
+        top += bytes;
+        return off;
+    }
+    void release(size_t off, size_t bytes)
+    {
+        auto it = std::lower_bound(blocks.begin(), blocks.end(), std::make_pair(off, (size_t)0));
+        it = blocks.insert(it, {off, bytes});
+        if (it + 1 != blocks.end() && it->first + it->second == (it + 1)->first) { it->second += (it + 1)->second; blocks.erase(it + 1); }
+        if (it != blocks.begin() && (it - 1)->first + (it - 1)->second == it->first) { (it - 1)->second += it->second; blocks.erase(it); }
+    }
+};
+
+// ---- kernel selection ----------------------------------------------------------------------------
+// Pointwise tile: the fp32 MFMA GEMM is compute-bound for most layers, so the tile is chosen to (a)
+// not waste MFMA work on a ragged N, (b) give the 256 CUs at least ~2 workgroups each, (c) otherwise be
+// as large as possible (fewer LDS/L2 bytes per flop).
+PwCfg choose_pw(long M, int N)
+{
+    const PwCfg c128x128{2, 2, 2, 2}, c128x64{2, 2, 2, 1}, c64x128{2, 2, 1, 2}, c64x64{2, 2, 1, 1}, c128x32{4, 1, 1, 1};
+    if (N <= 32) return c128x32;
+    auto blocks = [&](const PwCfg &c) { return (long)ceil_div(M, c.wgm * c.tm * 32) * ceil_div(N, c.wgn * c.tn * 32); };
+    auto waste = [&](const PwCfg &c) { int bn = c.wgn * c.tn * 32; return (double)(ceil_div(N, bn) * bn) / N; };
+    const PwCfg cands[] = {c128x128, c128x64, c64x128, c64x64};
+    for (const PwCfg &c : cands)
+        if (blocks(c) >= 512 && waste(c) <= 1.15) return c;
+    // small problem: prefer most workgroups among low-waste candidates
+    PwCfg best = c64x64;
+    return best;
+}
+
+int pw_lds_bytes(const PwCfg &c) { return (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 33 * 4; }
+
+int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return FD_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------------
+template <int ACT>
+int launch_stem(const Layer &L, const float *x, const float *wp, const float *bias, float *y, int B, hipStream_t s)
+{
+    switch (L.chunk) {
+    case 32: hipLaunchKernelGGL((fd_stem3x3s2_f32<ACT, 32>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    case 16: hipLaunchKernelGGL((fd_stem3x3s2_f32<ACT, 16>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    default: hipLaunchKernelGGL((fd_stem3x3s2_f32<ACT, 8>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    }
+    return check_launch("fd_stem3x3s2_f32");
+}
+
+template <int K, int S, int MODE, int ACT>
+int launch_dw_inst(const Layer &L, const float *in, const float *skip, const float *wp, const float *bias, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL((fd_dwconv_f32<K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
+                       L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);
+    return check_launch("fd_dwconv_f32");
+}
+
+template <int ACT>
+int launch_dw(const Layer &L, const float *in, const float *skip, const float *wp, const float *bias, float *out, hipStream_t s)
+{
+    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
+    switch (key) {
+    case 310: return launch_dw_inst<3, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
+    case 320: return launch_dw_inst<3, 2, 0, ACT>(L, in, skip, wp, bias, out, s);
+    case 510: return launch_dw_inst<5, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
+    case 511: return launch_dw_inst<5, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
+    case 512: return launch_dw_inst<5, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
+    case 311: return launch_dw_inst<3, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
+    case 312: return launch_dw_inst<3, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
+    }
+    return fail(FD_ERR_INVALID, "depthwise k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
+}
+
+template <int ACT>
+int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias, float *out, long M, hipStream_t s)
+{
+    const int N = L.d.cout, K = L.d.cin;
+    const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
+#define FD_PW_CASE(a, b, c, d) \
+    case a * 1000 + b * 100 + c * 10 + d: \
+        hipLaunchKernelGGL((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K); break;
+    switch (key) {
+        FD_PW_CASE(2, 2, 2, 2)
+        FD_PW_CASE(2, 2, 2, 1)
+        FD_PW_CASE(2, 2, 1, 2)
+        FD_PW_CASE(2, 2, 1, 1)
+        FD_PW_CASE(4, 1, 1, 1)
+    default: return fail(FD_ERR_INVALID, "no pointwise tile %d", key);
+    }
+#undef FD_PW_CASE
+    return check_launch("fd_pw_gemm_f32");
+}
+
+template <int ACT>
+int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hipStream_t s)
+{
+    const float *wp = reinterpret_cast<const float *>(p->ws + L.w_off);
+    const float *bias = reinterpret_cast<const float *>(p->ws + L.b_off);
+    float *out = L.to_output ? y : reinterpret_cast<float *>(p->ws + L.out_off);
+    const float *in = L.d.src < 0 ? x : reinterpret_cast<const float *>(p->ws + p->layers[L.d.src].out_off);
+    const float *skip = L.d.skip >= 0 ? reinterpret_cast<const float *>(p->ws + p->layers[L.d.skip].out_off) : nullptr;
+    switch (L.d.op) {
+    case FD_OP_STEM: return launch_stem<ACT>(L, in, wp, bias, out, p->B, s);
+    case FD_OP_DW: return launch_dw<ACT>(L, in, skip, wp, bias, out, s);
+    case FD_OP_PW:
+        if (L.head) {
+            const int h = L.d.upsample ? L.in_h / 2 : L.in_h, w = L.d.upsample ? L.in_w / 2 : L.in_w;
+            const long npix = (long)p->B * h * w;
+            hipLaunchKernelGGL((fd_head_pw1_f32<ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, npix, h, w, L.d.cin, L.d.upsample);
+            return check_launch("fd_head_pw1_f32");
+        }
+        return launch_pw<ACT>(L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
+    }
+    return fail(FD_ERR_INVALID, "bad op");
+}
+
+}  // namespace
+
+// ==================================================================================================
+extern "C" {
+
+const char *fd_last_error(void) { return g_err.c_str(); }
+const char *fd_version(void) { return "fastdepth_hip 0.1 (gfx950, fp32 inference)"; }
+
+int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
+                   int32_t dtype, uint32_t flags, fd_plan **out_plan)
+{
+    if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
+    if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
+        return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
+    if (dtype != FD_F32) return fail(FD_ERR_INVALID, "dtype %d not supported by this build (fp32 only)", dtype);
+    fd_plan *p = new fd_plan();
+    p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
+    p->layers.resize(n_layers);
+    const size_t esz = 4;
+    size_t woff = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        Layer &L = p->layers[i];
+        L.d = layers[i];
+        const fd_layer_desc &d = L.d;
+#define FD_BAD(...) do { int rc_ = fail(FD_ERR_INVALID, __VA_ARGS__); delete p; return rc_; } while (0)
+        if (d.src >= i || d.skip >= i) FD_BAD("layer %d: src/skip must reference earlier layers", i);
+        if (d.act < FD_ACT_NONE || d.act > FD_ACT_RELU6) FD_BAD("layer %d: bad activation", i);
+        if (d.cin <= 0 || d.cout <= 0) FD_BAD("layer %d: bad channel counts", i);
+        int src_h, src_w, src_c;
+        if (d.src < 0) { src_h = height; src_w = width; src_c = 3; }
+        else { const Layer &S = p->layers[d.src]; src_h = S.out_h; src_w = S.out_w; src_c = S.d.cout; }
+        if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
+        L.in_h = d.upsample ? 2 * src_h : src_h;
+        L.in_w = d.upsample ? 2 * src_w : src_w;
+        if (d.skip >= 0) {
+            const Layer &S = p->layers[d.skip];
+            if (!d.upsample) FD_BAD("layer %d: skip without upsample is not part of this path", i);
+            if (S.out_h != L.in_h || S.out_w != L.in_w || S.d.cout != d.cin)
+                FD_BAD("layer %d: skip tensor %dx%dx%d does not match input %dx%dx%d", i, S.out_h, S.out_w, S.d.cout, L.in_h, L.in_w, d.cin);
+        }
+        switch (d.op) {
+        case FD_OP_STEM:
+            if (d.src != -1 || d.cin != 3 || d.ksize != 3 || d.stride != 2 || d.upsample || d.skip >= 0 || d.cout % 8)
+                FD_BAD("layer %d: stem must be 3->8k channels, 3x3 stride 2 on the network input", i);
+            L.out_h = L.in_h / 2; L.out_w = L.in_w / 2;
+            L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
+            L.lds = 256 * (L.chunk + 4) * 4;
+            L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
+            L.w_bytes = (size_t)27 * d.cout * esz;
+            break;
+        case FD_OP_DW: {
+            if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4)
+                FD_BAD("layer %d: depthwise needs cin==cout (multiple of 4), k in {3,5}, stride in {1,2}", i);
+            if (d.stride == 2 && (L.in_h % 2 || L.in_w % 2)) FD_BAD("layer %d: stride-2 depthwise on odd input", i);
+            L.mode = d.upsample ? (d.skip >= 0 ? 2 : 1) : 0;
+            L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
+            const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
+            L.cbq = ilog2(cb / 4);
+            const int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = d.stride == 2 ? 8 : 16;
+            L.tw = std::min((L.out_w + 3) / 4 * 4, tmax_w);
+            L.th = std::min(L.out_h, tmax_h);
+            L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
+            const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
+            L.lds = ((size_t)th_in * tw_in * (cb + 4) + (size_t)d.ksize * d.ksize * cb + cb) * 4;
+            L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
+            L.w_bytes = (size_t)d.ksize * d.ksize * d.cin * esz;
+            break;
+        }
+        case FD_OP_PW:
+            if (d.src < 0 || d.ksize != 1 || d.stride != 1 || d.cin % 4) FD_BAD("layer %d: pointwise needs k=1 stride=1 cin%%4==0", i);
+            L.out_h = L.in_h; L.out_w = L.in_w;
+            L.w_bytes = (size_t)d.cin * d.cout * esz;
+            if (d.cout == 1) {
+                if (d.skip >= 0) FD_BAD("layer %d: head with skip is not part of this path", i);
+                L.head = true;
+                const long npix = (long)batch * (L.in_h >> (d.upsample ? 1 : 0)) * (L.in_w >> (d.upsample ? 1 : 0));
+                L.grid = dim3(ceil_div(npix * 8, 256));
+            } else {
+                if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample is only supported for the 1-channel head", i);
+                const long M = (long)batch * L.out_h * L.out_w;
+                L.pw = choose_pw(M, d.cout);
+                L.lds = pw_lds_bytes(L.pw);
+                L.grid = dim3(ceil_div(M, L.pw.wgm * L.pw.tm * 32), ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32));
+            }
+            break;
+        default: FD_BAD("layer %d: unknown op %d", i, d.op);
+        }
+        if (L.lds > 64 * 1024) FD_BAD("layer %d: LDS request %zu exceeds 64 KiB", i, L.lds);
+        L.w_off = woff; woff += align_up(L.w_bytes, 256);
+        L.b_off = woff; woff += align_up((size_t)d.cout * 4, 256);
+        L.out_bytes = align_up((size_t)batch * L.out_h * L.out_w * d.cout * esz, 256);
+    }
+    Layer &last = p->layers.back();
+    if (last.d.cout != 1 || last.out_h != height || last.out_w != width)
+        FD_BAD("the last layer must produce the [B,1,%d,%d] network output (got %dx%dx%d)", height, width, last.out_h, last.out_w, last.d.cout);
+#undef FD_BAD
+    last.to_output = true;
+    p->weights_bytes = woff;
+
+    // activation arena
+    std::vector<int> last_use(n_layers, -1);
+    for (int i = 0; i < n_layers; ++i) {
+        if (p->layers[i].d.src >= 0) last_use[p->layers[i].d.src] = i;
+        if (p->layers[i].d.skip >= 0) last_use[p->layers[i].d.skip] = i;
+    }
+    FreeList fl;
+    for (int i = 0; i < n_layers; ++i) {
+        Layer &L = p->layers[i];
+        if (L.to_output) continue;
+        if (!(flags & FD_PLAN_KEEP_ACTIVATIONS))
+            for (int j = 0; j < i; ++j)
+                if (last_use[j] == i - 1 && !p->layers[j].to_output) fl.release(p->layers[j].out_off - woff, p->layers[j].out_bytes);
+        // (a buffer whose last reader is layer i-1 is free from layer i on; readers of layer i keep theirs)
+        L.out_off = woff + fl.alloc(L.out_bytes);
+    }
+    p->ws_bytes = woff + fl.top;
+
+    // bookkeeping: algorithmic traffic and descriptions (SURVEY.md 8(d) convention)
+    for (int i = 0; i < n_layers; ++i) {
+        Layer &L = p->layers[i];
+        const fd_layer_desc &d = L.d;
+        const double src_elems = (double)batch * (d.upsample ? (L.in_h / 2) * (L.in_w / 2) : L.in_h * L.in_w) * d.cin;
+        const double skip_elems = d.skip >= 0 ? (double)batch * L.in_h * L.in_w * d.cin : 0.0;
+        const double out_elems = (double)batch * L.out_h * L.out_w * d.cout;
+        const double w_elems = (double)L.w_bytes / esz + 2.0 * d.cout;
+        L.alg_bytes = (src_elems + skip_elems + out_elems + w_elems) * esz;
+        p->alg_bytes += L.alg_bytes;
+        const double taps = d.op == FD_OP_STEM ? 27.0 : (d.op == FD_OP_DW ? (double)d.ksize * d.ksize : (double)d.cin);
+        const double mac_px = L.head && d.upsample ? (double)L.out_h * L.out_w : (double)L.out_h * L.out_w;
+        L.alg_flops = 2.0 * batch * mac_px * d.cout * taps;
+        p->alg_flops += L.alg_flops;
+        char buf[256];
+        if (d.op == FD_OP_STEM)
+            snprintf(buf, sizeof buf, "stem3x3s2_f32<chunk %d> grid=%u lds=%zu", L.chunk, L.grid.x, L.lds);
+        else if (d.op == FD_OP_DW)
+            snprintf(buf, sizeof buf, "dwconv_f32<k%d s%d mode%d> tile %dx%dx%d grid=%ux%ux%u lds=%zu", d.ksize, d.stride, L.mode,
+                     L.th, L.tw, 4 << L.cbq, L.grid.x, L.grid.y, L.grid.z, L.lds);
+        else if (L.head)
+            snprintf(buf, sizeof buf, "head_pw1_f32 up=%d grid=%u", d.upsample, L.grid.x);
+        else
+            snprintf(buf, sizeof buf, "pw_gemm_f32<%dx%d> M=%ld N=%d K=%d grid=%ux%u lds=%zu", L.pw.wgm * L.pw.tm * 32,
+                     L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.grid.x, L.grid.y, L.lds);
+        L.info = buf;
+        if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2_f32<%d, %d>", d.act, L.chunk);
+        else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv_f32<%d, %d, %d, %d>", d.ksize, d.stride, L.mode, d.act);
+        else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1_f32<%d>", d.act);
+        else snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
+        L.sym = buf;
+    }
+    *out_plan = p;
+    return FD_OK;
+}
+
+void fd_plan_destroy(fd_plan *plan) { delete plan; }
+
+size_t fd_plan_workspace_bytes(const fd_plan *plan) { return plan ? plan->ws_bytes : 0; }
+
+int fd_plan_bind_workspace(fd_plan *plan, void *device_ptr, size_t bytes)
+{
+    if (!plan || !device_ptr) return fail(FD_ERR_INVALID, "null plan/workspace");
+    if (bytes < plan->ws_bytes) return fail(FD_ERR_INVALID, "workspace too small: %zu < %zu", bytes, plan->ws_bytes);
+    if (reinterpret_cast<uintptr_t>(device_ptr) % 256) return fail(FD_ERR_INVALID, "workspace must be 256-byte aligned");
+    plan->ws = static_cast<unsigned char *>(device_ptr);
+    plan->packed = false;
+    return FD_OK;
+}
+
+int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n_layers, float bn_eps, void *stream)
+{
+    if (!plan || !params) return fail(FD_ERR_INVALID, "null plan/params");
+    if (!plan->ws) return fail(FD_ERR_STATE, "bind a workspace before packing weights");
+    if (n_layers != (int)plan->layers.size()) return fail(FD_ERR_INVALID, "expected %zu layer parameter sets", plan->layers.size());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n_layers; ++i) {
+        const Layer &L = plan->layers[i];
+        const fd_layer_params &q = params[i];
+        if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
+        const int inner = (int)(L.w_bytes / 4 / L.d.cout);
+        const int transpose = (L.d.op == FD_OP_PW) ? 0 : 1;          // stem/dw kernels want tap-major [inner][cout]
+        const long total = std::max<long>((long)L.d.cout * inner, L.d.cout);
+        hipLaunchKernelGGL(fd_pack_fold_f32, dim3(ceil_div(total, 256)), dim3(256), 0, s, q.conv_weight, q.bn_weight, q.bn_bias,
+                           q.bn_mean, q.bn_var, bn_eps, reinterpret_cast<float *>(plan->ws + L.w_off),
+                           reinterpret_cast<float *>(plan->ws + L.b_off), L.d.cout, inner, transpose);
+        int rc = check_launch("fd_pack_fold_f32");
+        if (rc) return rc;
+    }
+    plan->packed = true;
+    return FD_OK;
+}
+
+static int run_layer(fd_plan *plan, const Layer &L, const float *x, float *out, hipStream_t s)
+{
+    switch (L.d.act) {
+    case FD_ACT_RELU: return launch_layer<FD_ACT_RELU_>(plan, L, x, out, s);
+    case FD_ACT_RELU6: return launch_layer<FD_ACT_RELU6_>(plan, L, x, out, s);
+    default: return launch_layer<FD_ACT_NONE_>(plan, L, x, out, s);
+    }
+}
+
+int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)
+{
+    if (!plan || !x_nchw || !y) return fail(FD_ERR_INVALID, "null argument");
+    if (!plan->ws || !plan->packed) return fail(FD_ERR_STATE, "plan needs a bound workspace and packed weights");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (const Layer &L : plan->layers) {
+        int rc = run_layer(plan, L, static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
+        if (rc) return rc;
+    }
+    return FD_OK;
+}
+
+int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, float *ms_per_layer, int32_t n_layers)
+{
+    if (!plan || !x_nchw || !y || !ms_per_layer) return fail(FD_ERR_INVALID, "null argument");
+    if (!plan->ws || !plan->packed) return fail(FD_ERR_STATE, "plan needs a bound workspace and packed weights");
+    if (n_layers != (int)plan->layers.size()) return fail(FD_ERR_INVALID, "expected room for %zu layer timings", plan->layers.size());
+#ifdef FD_EMU
+    for (int i = 0; i < n_layers; ++i) ms_per_layer[i] = 0.0f;
+    return fd_forward(plan, x_nchw, y, stream);
+#else
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<hipEvent_t> ev(n_layers + 1);
+    for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
+    int rc = FD_OK;
+    (void)hipEventRecord(ev[0], s);
+    for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
+        rc = run_layer(plan, plan->layers[i], static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
+        (void)hipEventRecord(ev[i + 1], s);
+    }
+    if (rc == FD_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(FD_ERR_HIP, "hipStreamSynchronize failed");
+    for (int i = 0; i < n_layers && rc == FD_OK; ++i)
+        if (hipEventElapsedTime(&ms_per_layer[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+#endif
+}
+
+int fd_layer_output(const fd_plan *plan, int32_t layer, const void **device_ptr, int32_t *n, int32_t *h, int32_t *w, int32_t *c)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return fail(FD_ERR_INVALID, "bad layer index");
+    if (!(plan->flags & FD_PLAN_KEEP_ACTIVATIONS)) return fail(FD_ERR_STATE, "plan was not created with FD_PLAN_KEEP_ACTIVATIONS");
+    const Layer &L = plan->layers[layer];
+    if (L.to_output) return fail(FD_ERR_STATE, "the last layer writes the caller's output buffer");
+    if (!plan->ws) return fail(FD_ERR_STATE, "no workspace bound");
+    if (device_ptr) *device_ptr = plan->ws + L.out_off;
+    if (n) *n = plan->B;
+    if (h) *h = L.out_h;
+    if (w) *w = L.out_w;
+    if (c) *c = L.d.cout;
+    return FD_OK;
+}
+
+int32_t fd_plan_num_kernels(const fd_plan *plan) { return plan ? (int32_t)plan->layers.size() : 0; }
+
+const char *fd_plan_kernel_info(const fd_plan *plan, int32_t layer)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return "";
+    return plan->layers[layer].info.c_str();
+}
+
+const char *fd_plan_kernel_symbol(const fd_plan *plan, int32_t layer)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return "";
+    return plan->layers[layer].sym.c_str();
+}
+
+double fd_plan_algorithmic_bytes(const fd_plan *plan) { return plan ? plan->alg_bytes : 0.0; }
+double fd_plan_algorithmic_flops(const fd_plan *plan) { return plan ? plan->alg_flops : 0.0; }
+
+int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_bytes, double *algorithmic_flops)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return fail(FD_ERR_INVALID, "bad layer index");
+    if (algorithmic_bytes) *algorithmic_bytes = plan->layers[layer].alg_bytes;
+    if (algorithmic_flops) *algorithmic_flops = plan->layers[layer].alg_flops;
+    return FD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// fd_kernels_f32.h -- fp32 inference kernels of the FastDepth hot path for gfx950 (MI355X).
+//
+// Activation layout is NHWC (channel fastest): a wavefront's 64 lanes read/write 16-byte channel
+// groups of neighbouring pixels, so every global access is a run of >=128 contiguous bytes.
+// BatchNorm (inference form) is folded into the weights by fd_pack_fold_f32, so each kernel is
+// conv + bias + activation with no separate normalisation / activation pass.
+//
+// Kernels (reference statement each one replaces):
+//   fd_pack_fold_f32    BN(eval) algebra: gamma*(x-mean)/sqrt(var+eps)+beta  == conv(w*s) + (beta-mean*s)
+//   fd_stem3x3s2_f32    conv_bn(3,32,2)                      imagenet/mobilenet.py:22-27,41
+//   fd_dwconv_f32       depthwise 3x3 s1/s2 (+BN+ReLU6)      imagenet/mobilenet.py:31-33
+//                       depthwise 5x5 (+BN+ReLU) with the nearest-x2 upsample and the additive skip
+//                       of the PREVIOUS decoder stage folded into the tile read   models.py:61-68,723-729
+//   fd_pw_gemm_f32      pointwise 1x1 (+BN+ReLU/ReLU6) as an fp32 MFMA GEMM       mobilenet.py:35-37; models.py:70-75
+//   fd_head_pw1_f32     decode_conv6 = pointwise(32,1) evaluated at the low resolution and replicated
+//                       2x2 on write (a 1x1 conv + per-channel BN + ReLU commutes with nearest upsampling) models.py:698,723,731
+#pragma once
+#include "fd_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: wp = w * scale[cout]  (optionally transposed to [inner][cout]),  bias = beta - mean*scale
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fd_pack_fold_f32(const float *__restrict__ w, const float *__restrict__ gamma, const float *__restrict__ beta,
+                 const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                 float *__restrict__ wp, float *__restrict__ bias, int cout, int inner, int transpose)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)cout * inner;
+    if (idx < total) {
+        const int co = (int)(idx / inner), i = (int)(idx - (long)co * inner);
+        const float scale = gamma[co] / sqrtf(var[co] + eps);
+        const float v = w[idx] * scale;
+        if (transpose) wp[(long)i * cout + co] = v; else wp[idx] = v;
+    }
+    if (idx < cout) {
+        const float scale = gamma[idx] / sqrtf(var[idx] + eps);
+        bias[idx] = beta[idx] - mean[idx] * scale;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem: dense 3x3 stride-2 conv, 3 -> Cout channels.  x is NCHW-planar (as the dataloader hands it
+// over), y is NHWC.  One work-item = one output pixel; the 27 taps live in registers, the folded
+// weights wp[27][Cout] are wave-uniform (scalar loads).  The per-pixel channel vector is transposed
+// through LDS so that the global store is dense.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int CHUNK>
+__global__ void __launch_bounds__(256)
+fd_stem3x3s2_f32(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+                 float *__restrict__ y, int B, int H, int W, int Cout)
+{
+    FD_DYN_SMEM(smem_raw);
+    float *tile = reinterpret_cast<float *>(smem_raw);       // [256][CHUNK + 4]
+    constexpr int TS = CHUNK + 4;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long npix = (long)B * Ho * Wo;
+    const int tid = threadIdx.x;
+    const long p = (long)blockIdx.x * 256 + tid;
+    const bool valid = p < npix;
+    int n = 0, oy = 0, ox = 0;
+    if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                in[(c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
+            }
+    for (int c0 = 0; c0 < Cout; c0 += CHUNK) {
+        float acc[CHUNK];
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) acc[j] = bias[c0 + j];
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j) acc[j] = fmaf(in[t], wp[t * Cout + c0 + j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < CHUNK; j += 4) {
+            fd_f32x4 v = {fd_act<ACT>(acc[j]), fd_act<ACT>(acc[j + 1]), fd_act<ACT>(acc[j + 2]), fd_act<ACT>(acc[j + 3])};
+            fd_st4(tile + tid * TS + j, v);
+        }
+        __syncthreads();
+        constexpr int Q = CHUNK / 4;                          // float4 per pixel in this chunk
+        for (int f = tid; f < 256 * Q; f += 256) {
+            const int px = f / Q, c4 = f - px * Q;
+            const long gp = (long)blockIdx.x * 256 + px;
+            if (gp < npix) fd_st4(y + gp * Cout + c0 + c4 * 4, fd_ld4(tile + px * TS + c4 * 4));
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise K x K conv, stride S, NHWC, LDS-tiled.
+//   MODE 0: input read as stored.
+//   MODE 1: input is the nearest-x2 upsampling of `in` (stored at half resolution)      models.py:723
+//   MODE 2: MODE 1 plus `skip` (stored at full resolution) added                          models.py:724-729
+// A workgroup owns TH x TW output pixels x CB channels (CB = 4 << cbq).  Phase 1 stages the
+// (TH-1)*S+K by (TW-1)*S+K input patch -- zero padded, upsampled and skip-added on the fly -- into LDS
+// with 16-byte loads; phase 2 gives every work-item strips of 4 output pixels x 4 channels: per filter
+// row it pulls 3*S+K input vectors from LDS once and reuses them across the K taps and 4 outputs.
+// The upsampled / summed tensor is never written to HBM.
+// ------------------------------------------------------------------------------------------------
+template <int K, int S, int MODE, int ACT>
+__global__ void __launch_bounds__(256)
+fd_dwconv_f32(const float *__restrict__ in, const float *__restrict__ skip, const float *__restrict__ wp,
+              const float *__restrict__ bias, float *__restrict__ out, int Hin, int Win, int Ho, int Wo, int C,
+              int cbq, int TH, int TW, int tiles_x)
+{
+    constexpr int P = K / 2;
+    constexpr int NIN = 3 * S + K;                       // input columns feeding 4 adjacent outputs
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
+    float *s_in = smem;                                   // [TH_in*TW_in][PSTR]
+    float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]
+    float *s_b = s_w + K * K * CB;                        // [CB]
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
+    const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
+    const int cg = c0 + c4 * 4;                            // first global channel of this lane
+    const bool c_ok = cg < C;
+
+    for (int i = tid; i < K * K * lanes_c; i += 256) {
+        const int t = i >> cbq, cc = i & (lanes_c - 1);
+        fd_st4(s_w + t * CB + cc * 4, (c0 + cc * 4 < C) ? fd_ld4(wp + (long)t * C + c0 + cc * 4) : fd_zero4());
+    }
+    if (tid < lanes_c) fd_st4(s_b + tid * 4, (c0 + tid * 4 < C) ? fd_ld4(bias + c0 + tid * 4) : fd_zero4());
+
+    const int npx_in = TH_in * TW_in;
+    for (int px = pt; px < npx_in; px += npt) {
+        const int iy = px / TW_in, ix = px - iy * TW_in;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        fd_f32x4 v = fd_zero4();
+        if (c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {
+            if (MODE == 0) {
+                v = fd_ld4(in + (((long)n * Hin + gy) * Win + gx) * C + cg);
+            } else {
+                const int Hs = Hin >> 1, Ws = Win >> 1;
+                v = fd_ld4(in + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                if (MODE == 2) v += fd_ld4(skip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+            }
+        }
+        fd_st4(s_in + px * PSTR + c4 * 4, v);
+    }
+    __syncthreads();
+
+    const int TWS = TW >> 2, nstrips = TH * TWS;
+    const fd_f32x4 b4 = fd_ld4(s_b + c4 * 4);
+    for (int s = pt; s < nstrips; s += npt) {
+        const int oy = s / TWS, ox = (s - oy * TWS) * 4;
+        fd_f32x4 acc[4] = {b4, b4, b4, b4};
+#pragma unroll 1   // one filter row in flight: keeps the kernel at <=128 VGPRs (>=4 waves/SIMD hide the LDS latency)
+        for (int ky = 0; ky < K; ++ky) {
+            const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
+            fd_f32x4 r[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const fd_f32x4 w = fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += r[j * S + kx] * w;
+            }
+        }
+        const int gy = oy0 + oy;
+        if (c_ok && gy < Ho) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = ox0 + ox + j;
+                if (gx < Wo) fd_st4(out + (((long)n * Ho + gy) * Wo + gx) * C + cg, fd_act4<ACT>(acc[j]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise 1x1 conv as GEMM:  out[M][N] = act(A[M][K] * Wt[N][K]^T + bias[N]),  M = B*H*W pixels (NHWC
+// rows), K = Cin, N = Cout, all fp32, on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+// 4 waves as WGM x WGN, each wave owns TM x TN tiles of 32x32 -> block tile (WGM*TM*32) x (WGN*TN*32),
+// BK = 32.  Global -> register prefetch of the next K tile overlaps the MFMAs of the current one; LDS
+// rows are padded to 33 floats so both the 4-byte fragment reads (lane = row) and the transposing
+// writes are bank-conflict free.  Ragged M / N / K (pruned plans: multiples of 8) are zero-filled.
+// ------------------------------------------------------------------------------------------------
+template <int WGM, int WGN, int TM, int TN, int ACT>
+__global__ void __launch_bounds__(256)
+fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
+               float *__restrict__ out, int M, int N, int K)
+{
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32, LS = BK + 1;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;         // 16-byte loads per work-item per K tile
+    FD_DYN_SMEM(smem_raw);
+    float *As = reinterpret_cast<float *>(smem_raw);       // [BM][LS]
+    float *Bs = As + BM * LS;                              // [BN][LS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int lr = tid >> 3, lk = (tid & 7) * 4;          // staging: row within a 32-row slab, k offset
+
+    fd_f32x4 ra[A_IT], rb[B_IT];
+    auto gload = [&](int k0) {
+        const bool k_ok = (k0 + lk) < K;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const long row = m0 + lr + 32 * i;
+            ra[i] = (k_ok && row < M) ? fd_ld4(A + row * K + k0 + lk) : fd_zero4();
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int row = n0 + lr + 32 * i;
+            rb[i] = (k_ok && row < N) ? fd_ld4(Wt + (long)row * K + k0 + lk) : fd_zero4();
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            float *p = As + (lr + 32 * i) * LS + lk;
+            p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            float *p = Bs + (lr + 32 * i) * LS + lk;
+            p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+        }
+    };
+
+    fd_f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const float *a_frag = As + (wm * TM * 32 + (lane & 31)) * LS + (lane >> 5);
+    const float *b_frag = Bs + (wn * TN * 32 + (lane & 31)) * LS + (lane >> 5);
+
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_frag[i * 32 * LS + kk * 2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_frag[j * 32 * LS + kk * 2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of the 32x32 tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) out[row * N + col] = fd_act<ACT>(acc[i][j][r] + bv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head: pointwise Cin -> 1 (+BN+ReLU).  8 lanes share one low-resolution pixel (16-byte channel groups,
+// dense 128-byte reads), a 3-step wave shuffle reduces the dot product, lane 0 writes the value once
+// (up == 0) or as the 2x2 block it becomes after nearest upsampling (up == 1).
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ void __launch_bounds__(256)
+fd_head_pw1_f32(const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
+                float *__restrict__ y, long npix, int h, int w, int Cin, int up)
+{
+    const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int l8 = threadIdx.x & 7;
+    float s = 0.0f;
+    if (g < npix) {
+        for (int c = l8 * 4; c < Cin; c += 32) {
+            const fd_f32x4 v = fd_ld4(in + g * Cin + c), q = fd_ld4(wp + c);
+            s = fmaf(v.x, q.x, s); s = fmaf(v.y, q.y, s); s = fmaf(v.z, q.z, s); s = fmaf(v.w, q.w, s);
+        }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (g < npix && l8 == 0) {
+        const float v = fd_act<ACT>(s + bias[0]);
+        if (!up) { y[g] = v; return; }
+        const int ox = (int)(g % w);
+        const long t = g / w;
+        const int oy = (int)(t % h);
+        const long n = t / h;
+        float *o = y + ((n * 2 * h + 2 * oy) * 2 * (long)w + 2 * ox);
+        const fd_f32x2 vv = {v, v};
+        *reinterpret_cast<fd_f32x2 *>(o) = vv;
+        *reinterpret_cast<fd_f32x2 *>(o + 2 * w) = vv;
+    }
+}

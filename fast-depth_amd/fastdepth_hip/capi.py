@@ -1,0 +1,75 @@
+"""ctypes declarations for include/fastdepth_hip.h.  No torch import here."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libfastdepth_hip.so")
+
+FD_F32, FD_F16, FD_BF16 = 0, 1, 2
+FD_OP_STEM, FD_OP_DW, FD_OP_PW = 0, 1, 2
+FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
+FD_PLAN_KEEP_ACTIVATIONS = 1
+
+
+class LayerDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("op", "cin", "cout", "ksize", "stride", "act", "src", "upsample", "skip", "reserved")]
+
+
+class LayerParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias", "bn_mean", "bn_var")]
+
+
+class FastDepthError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """Loads the shared library and declares every entry point of include/fastdepth_hip.h.
+    Raises (never falls back) if the library is missing: the product has no other execution path."""
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise FastDepthError("HIP extension not built: %s is missing (run `python fast-depth_amd/build.py`)" % path)
+    lib = ctypes.CDLL(path)
+    vp, i32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32
+    lib.fd_plan_create.argtypes = [ctypes.POINTER(LayerDesc), i32, i32, i32, i32, i32, u32, ctypes.POINTER(vp)]
+    lib.fd_plan_create.restype = ctypes.c_int
+    lib.fd_plan_destroy.argtypes = [vp]
+    lib.fd_plan_destroy.restype = None
+    lib.fd_plan_workspace_bytes.argtypes = [vp]
+    lib.fd_plan_workspace_bytes.restype = ctypes.c_size_t
+    lib.fd_plan_bind_workspace.argtypes = [vp, vp, ctypes.c_size_t]
+    lib.fd_plan_bind_workspace.restype = ctypes.c_int
+    lib.fd_plan_pack_weights.argtypes = [vp, ctypes.POINTER(LayerParams), i32, ctypes.c_float, vp]
+    lib.fd_plan_pack_weights.restype = ctypes.c_int
+    lib.fd_forward.argtypes = [vp, vp, vp, vp]
+    lib.fd_forward.restype = ctypes.c_int
+    lib.fd_forward_timed.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ctypes.c_float), i32]
+    lib.fd_forward_timed.restype = ctypes.c_int
+    lib.fd_layer_output.argtypes = [vp, i32, ctypes.POINTER(vp)] + [ctypes.POINTER(i32)] * 4
+    lib.fd_layer_output.restype = ctypes.c_int
+    lib.fd_plan_num_kernels.argtypes = [vp]
+    lib.fd_plan_num_kernels.restype = i32
+    lib.fd_plan_kernel_info.argtypes = [vp, i32]
+    lib.fd_plan_kernel_info.restype = ctypes.c_char_p
+    lib.fd_plan_kernel_symbol.argtypes = [vp, i32]
+    lib.fd_plan_kernel_symbol.restype = ctypes.c_char_p
+    lib.fd_plan_algorithmic_bytes.argtypes = [vp]
+    lib.fd_plan_algorithmic_bytes.restype = ctypes.c_double
+    lib.fd_plan_algorithmic_flops.argtypes = [vp]
+    lib.fd_plan_algorithmic_flops.restype = ctypes.c_double
+    lib.fd_plan_layer_stats.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    lib.fd_plan_layer_stats.restype = ctypes.c_int
+    lib.fd_last_error.restype = ctypes.c_char_p
+    lib.fd_version.restype = ctypes.c_char_p
+    return lib
+
+
+EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_plan_bind_workspace",
+           "fd_plan_pack_weights", "fd_forward", "fd_forward_timed", "fd_layer_output", "fd_plan_num_kernels", "fd_plan_kernel_info", "fd_plan_kernel_symbol",
+           "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats", "fd_last_error", "fd_version")
+
+
+def check(lib, rc, what):
+    if rc != 0:
+        raise FastDepthError("%s failed (%d): %s" % (what, rc, lib.fd_last_error().decode()))

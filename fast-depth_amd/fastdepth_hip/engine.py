@@ -1,0 +1,152 @@
+"""torch-facing engine: owns one fd_plan per (batch, H, W) and the device workspace, enqueues on torch's
+current HIP stream, repacks weights when the parameters' version counters move.
+
+PyTorch is used for what the boundary leaves to the host: device memory (`torch.empty`), the current
+stream, parameter storage.  All arithmetic happens in libfastdepth_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .plan import layers_of
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = capi.load()          # raises if the extension is not built: no fallback
+    return _LIB
+
+
+class _Plan:
+    def __init__(self, engine, batch, height, width, device, keep=False):
+        L = lib()
+        self.layers = engine.layers
+        n = len(self.layers)
+        descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
+        handle = ctypes.c_void_p()
+        capi.check(L, L.fd_plan_create(descs, n, batch, height, width, capi.FD_F32,
+                                       capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0, ctypes.byref(handle)), "fd_plan_create")
+        self.handle = handle
+        self.shape = (batch, height, width)
+        self.workspace = torch.empty(L.fd_plan_workspace_bytes(handle) + 256, dtype=torch.uint8, device=device)
+        base = (self.workspace.data_ptr() + 255) // 256 * 256
+        capi.check(L, L.fd_plan_bind_workspace(handle, base, L.fd_plan_workspace_bytes(handle)), "fd_plan_bind_workspace")
+        self.version = None
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _LIB is not None:
+            _LIB.fd_plan_destroy(self.handle)
+            self.handle = None
+
+    def kernel_info(self):
+        L = lib()
+        return [L.fd_plan_kernel_info(self.handle, i).decode() for i in range(L.fd_plan_num_kernels(self.handle))]
+
+
+class Engine:
+    """One per model instance (created lazily by MobileNetSkipAdd.forward)."""
+
+    def __init__(self, model, keep_activations=False):
+        self.model = model
+        self.layers = layers_of(model)
+        self.keep = keep_activations
+        self.plans = {}
+
+    def invalidate(self):
+        for p in self.plans.values():
+            p.version = None
+
+    def _version(self):
+        v = 0
+        for l in self.layers:
+            for t in (l.conv.weight, l.bn.weight, l.bn.bias, l.bn.running_mean, l.bn.running_var):
+                v = v * 1000003 + t._version + (t.data_ptr() & 0xFFFFFFF)
+        return v
+
+    def plan_for(self, x):
+        b, c, h, w = x.shape
+        key = (b, h, w, x.device.index)
+        p = self.plans.get(key)
+        if p is None:
+            p = self.plans[key] = _Plan(self, b, h, w, x.device, self.keep)
+        return p
+
+    def _pack(self, plan, stream):
+        L = lib()
+        n = len(self.layers)
+        params = (capi.LayerParams * n)()
+        for q, l in zip(params, self.layers):
+            for name, t in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias),
+                            ("bn_mean", l.bn.running_mean), ("bn_var", l.bn.running_var)):
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise capi.FastDepthError("parameter %s.%s must be a contiguous float32 tensor on the GPU" % (l.name, name))
+                setattr(q, name, t.data_ptr())
+        eps = self.layers[0].bn.eps
+        if any(l.bn.eps != eps for l in self.layers):
+            raise capi.FastDepthError("mixed BatchNorm eps values are not supported")
+        capi.check(L, L.fd_plan_pack_weights(plan.handle, params, n, eps, stream), "fd_plan_pack_weights")
+
+    def forward(self, x):
+        if self.model.training:
+            raise capi.FastDepthError("train-mode forward (batch-statistics BatchNorm + backward) is not built yet in "
+                                      "this round; call model.eval() for inference")
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
+            raise capi.FastDepthError("expected a float32 [B,3,H,W] tensor, got %s %s" % (tuple(x.shape), x.dtype))
+        x = x.contiguous()
+        L = lib()
+        plan = self.plan_for(x)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        with torch.cuda.device(x.device):
+            ver = self._version()
+            if plan.version != ver:
+                self._pack(plan, stream)
+                plan.version = ver
+            y = torch.empty((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+            capi.check(L, L.fd_forward(plan.handle, x.data_ptr(), y.data_ptr(), stream), "fd_forward")
+        return y
+
+    def forward_timed(self, x):
+        """Measurement aid: one forward with HIP events around every layer's kernel (synchronises).
+        Returns (y, [ms per layer])."""
+        L = lib()
+        x = x.contiguous()
+        plan = self.plan_for(x)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        n = len(self.layers)
+        ms = (ctypes.c_float * n)()
+        with torch.cuda.device(x.device):
+            ver = self._version()
+            if plan.version != ver:
+                self._pack(plan, stream)
+                plan.version = ver
+            y = torch.empty((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+            capi.check(L, L.fd_forward_timed(plan.handle, x.data_ptr(), y.data_ptr(), stream, ms, n), "fd_forward_timed")
+        return y, list(ms)
+
+    def layer_stats(self, x):
+        """[(layer name, kernel symbol, kernel info, algorithmic bytes, algorithmic flops)] for x's plan."""
+        L = lib()
+        plan = self.plan_for(x)
+        out = []
+        for i, l in enumerate(self.layers):
+            b, f = ctypes.c_double(), ctypes.c_double()
+            capi.check(L, L.fd_plan_layer_stats(plan.handle, i, ctypes.byref(b), ctypes.byref(f)), "fd_plan_layer_stats")
+            out.append((l.name, L.fd_plan_kernel_symbol(plan.handle, i).decode(), L.fd_plan_kernel_info(plan.handle, i).decode(),
+                        b.value, f.value))
+        return out
+
+    def layer_output(self, x, index):
+        """Test hook: NCHW copy of fused layer `index`'s output from the last forward on x's plan."""
+        L = lib()
+        plan = self.plan_for(x)
+        ptr = ctypes.c_void_p()
+        dims = [ctypes.c_int32() for _ in range(4)]
+        capi.check(L, L.fd_layer_output(plan.handle, index, ctypes.byref(ptr), *[ctypes.byref(d) for d in dims]), "fd_layer_output")
+        n, h, w, c = [d.value for d in dims]
+        off = ptr.value - plan.workspace.data_ptr()
+        flat = plan.workspace[off:off + n * h * w * c * 4].view(torch.float32)
+        return flat.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()

@@ -1,0 +1,132 @@
+/*
+ * fastdepth_hip.h -- C ABI of libfastdepth_hip.so: the MI355X (gfx950) execution engine for the
+ * FastDepth MobileNet-NNConv5(dw)+skip-add hot path.
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  Device pointers are HIP device pointers of
+ * the calling process (torch allocations are fine), `stream` is a hipStream_t passed as void*.
+ * Nothing here synchronises the device; every call returns FD_OK (0) or a negative error and
+ * fd_last_error() describes the failure (thread-local).
+ *
+ * What each entry point replaces in the reference (dwofk/fast-depth):
+ *   fd_plan_create            the static structure of models.MobileNetSkipAdd.__init__        models.py:655-704
+ *                             (+ imagenet/mobilenet.py:40-54), expressed as a list of fused layers
+ *   fd_plan_pack_weights      what `model.eval()` + nn.BatchNorm2d's running statistics imply   mobilenet.py:25,32,36; models.py:66,73
+ *                             (BN folded into the preceding conv once, instead of per call)
+ *   fd_forward                `pred = model(input)` inside torch.no_grad()                      main.py:74-75  ->  models.py:706-732
+ *                             i.e. 38 aten::convolution + 38 batch_norm + 38 activations +
+ *                             5 upsample_nearest2d + 3 add, as ~38 fused HIP kernels
+ *   fd_layer_output           (test hook) the per-module outputs a forward hook would see
+ *   fd_metrics_*              (next row f-2) metrics.Result.evaluate                            metrics.py:31-55
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Layout contract: network input is NCHW float32 exactly as main.py:68 hands it over
+ * ([B,3,H,W], values in [0,1], no mean/std normalisation: dataloaders/dataloader.py:97-99); the
+ * network output [B,1,H,W] is written densely (NCHW == NHWC for one channel).  All intermediate
+ * activations live in the caller-provided workspace in NHWC and never cross this boundary except
+ * through fd_layer_output.
+ */
+#ifndef FASTDEPTH_HIP_H
+#define FASTDEPTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_OK 0
+#define FD_ERR_INVALID (-1)   /* bad argument / unsupported structure */
+#define FD_ERR_STATE (-2)     /* call order (workspace not bound, weights not packed, ...) */
+#define FD_ERR_HIP (-3)       /* a HIP runtime call or kernel launch failed */
+
+/* storage / arithmetic type of activations and packed weights (accumulation is always fp32) */
+enum fd_dtype { FD_F32 = 0, FD_F16 = 1, FD_BF16 = 2 };
+
+/* fused layer kinds: every one is Conv2d(bias=False) + BatchNorm2d + activation */
+enum fd_op {
+    FD_OP_STEM = 0, /* dense 3x3 conv, stride 2, NCHW-planar in -> NHWC out   (mobilenet.py:22-27,41)  */
+    FD_OP_DW = 1,   /* depthwise k x k conv (k = 3 or 5), stride 1 or 2        (mobilenet.py:31-33; models.py:61-68) */
+    FD_OP_PW = 2    /* pointwise 1x1 conv = GEMM over channels                 (mobilenet.py:35-37; models.py:70-75) */
+};
+enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
+
+/* plan flags */
+#define FD_PLAN_KEEP_ACTIVATIONS 1u /* one private buffer per layer output (needed for fd_layer_output); default: lifetime-based reuse */
+
+typedef struct fd_layer_desc {
+    int32_t op;       /* enum fd_op */
+    int32_t cin;
+    int32_t cout;     /* == cin for FD_OP_DW */
+    int32_t ksize;    /* 3 (stem, encoder dw), 5 (decoder dw), 1 (pw) */
+    int32_t stride;   /* 1 or 2 */
+    int32_t act;      /* enum fd_act */
+    int32_t src;      /* index of the layer whose output feeds this one; -1 = network input */
+    int32_t upsample; /* 1: the input is the nearest-neighbour x2 upsampling of src's output (models.py:723) */
+    int32_t skip;     /* >= 0: add that layer's output to the (upsampled) input before the conv (models.py:724-729); -1: none */
+    int32_t reserved;
+} fd_layer_desc;
+
+/* device pointers to the live parameters of one layer (fp32, torch layouts) */
+typedef struct fd_layer_params {
+    const float *conv_weight;  /* [cout][cin/groups][k][k] */
+    const float *bn_weight;    /* gamma [cout] */
+    const float *bn_bias;      /* beta  [cout] */
+    const float *bn_mean;      /* running_mean [cout] */
+    const float *bn_var;       /* running_var  [cout] */
+} fd_layer_params;
+
+typedef struct fd_plan fd_plan;
+
+/* Builds the execution plan (kernel selection, tiling, workspace layout) for a fixed
+ * (batch, height, width, dtype).  height and width must be multiples of 32 (the reference fails at
+ * its skip additions otherwise).  The last layer must produce the network output. */
+int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height,
+                   int32_t width, int32_t dtype, uint32_t flags, fd_plan **out_plan);
+void fd_plan_destroy(fd_plan *plan);
+
+/* Bytes of device memory the plan needs (packed weights + activation arena); the caller allocates
+ * it (e.g. a torch uint8 tensor) and binds it.  The pointer must be 256-byte aligned. */
+size_t fd_plan_workspace_bytes(const fd_plan *plan);
+int fd_plan_bind_workspace(fd_plan *plan, void *device_ptr, size_t bytes);
+
+/* Folds BatchNorm (inference form, running statistics) into each conv and repacks the weights into
+ * the kernels' layouts, on `stream`.  Must be repeated whenever the parameters change. */
+int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n_layers, float bn_eps,
+                         void *stream);
+
+/* Inference forward: x [B,3,H,W] float32 NCHW -> y [B,cout_last,H,W] float32, enqueued on `stream`. */
+int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream);
+
+/* Same as fd_forward, but brackets every layer's kernel with HIP events on `stream`, synchronises the stream
+ * and returns each layer's device time in milliseconds (ms_per_layer[n_layers]).  Measurement aid for
+ * bench.py's roofline report; not for production calls. */
+int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, float *ms_per_layer, int32_t n_layers);
+
+/* Test hook: where layer `layer`'s output lives (NHWC, plan dtype).  Valid after fd_forward on a
+ * plan created with FD_PLAN_KEEP_ACTIVATIONS. */
+int fd_layer_output(const fd_plan *plan, int32_t layer, const void **device_ptr, int32_t *n, int32_t *h,
+                    int32_t *w, int32_t *c);
+
+/* Number of kernels one fd_forward enqueues, and a human-readable description of layer i's kernel
+ * choice ("pw_gemm_f32<128x64> grid=... lds=...").  The string is owned by the plan. */
+int32_t fd_plan_num_kernels(const fd_plan *plan);
+const char *fd_plan_kernel_info(const fd_plan *plan, int32_t layer);
+/* Demangled name of the __global__ function layer i launches, spelled as rocprofv3 prints it
+ * (e.g. "fd_pw_gemm_f32<2, 2, 1, 1, 2>"), so bench.py's per-kernel timings can be matched to a kernel trace. */
+const char *fd_plan_kernel_symbol(const fd_plan *plan, int32_t layer);
+
+/* Algorithmic HBM bytes of one forward (SURVEY.md 8(d) convention: every fused unit reads its stored
+ * inputs once and writes its output once; weights + folded BN once per batch). */
+double fd_plan_algorithmic_bytes(const fd_plan *plan);
+double fd_plan_algorithmic_flops(const fd_plan *plan);
+/* The same two figures for one layer's kernel launch. */
+int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_bytes, double *algorithmic_flops);
+
+const char *fd_last_error(void);
+const char *fd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTDEPTH_HIP_H */

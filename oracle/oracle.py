@@ -61,7 +61,7 @@ def to_numpy_state(state_dict):
         if k.endswith("num_batches_tracked"):
             continue
         a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
-        out[k] = np.ascontiguousarray(a, dtype=np.float32)
+        out[k] = np.array(a, dtype=np.float32, copy=True, order="C")   # private copy: train mode updates running stats in place
     return out
 
 
