@@ -45,10 +45,12 @@ struct Layer {
     bool head = false;           // Cout == 1 pointwise: fd_head_pw1_f32
     // dw tiling
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0;
+    bool dw_rows = false;        // register-window 3x3 kernel (fd_dw3_rows_f32) instead of the LDS-tiled one
     // stem
     int chunk = 0;
     // pw
     PwCfg pw{};
+    int m_tiles = 0, n_tiles = 0;
     size_t lds = 0;
     dim3 grid;
     std::string info, sym;
@@ -113,15 +115,14 @@ PwCfg choose_pw(long M, int N)
     if (N <= 32) return c128x32;
     auto blocks = [&](const PwCfg &c) { return (long)ceil_div(M, c.wgm * c.tm * 32) * ceil_div(N, c.wgn * c.tn * 32); };
     auto waste = [&](const PwCfg &c) { int bn = c.wgn * c.tn * 32; return (double)(ceil_div(N, bn) * bn) / N; };
-    const PwCfg cands[] = {c128x128, c128x64, c64x128, c64x64};
-    for (const PwCfg &c : cands)
-        if (blocks(c) >= 512 && waste(c) <= 1.15) return c;
-    // small problem: prefer most workgroups among low-waste candidates
-    PwCfg best = c64x64;
-    return best;
+    // Measured on MI355X (scratch/gemm, round 1): with the fp32 MFMA at 64 cycles per instruction the 64x64 tile
+    // (one 32x32 accumulator per wave, 4+ workgroups per CU) beats the larger tiles on every shape of this
+    // network -- latency hiding across workgroups matters more than operand reuse.
+    (void)blocks; (void)waste; (void)c128x128; (void)c128x64; (void)c64x128;
+    return c64x64;
 }
 
-int pw_lds_bytes(const PwCfg &c) { return (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 33 * 4; }
+int pw_lds_bytes(const PwCfg &c) { return 2 * (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 36 * 4; }   // double-buffered, 144-byte rows
 
 int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 
@@ -155,6 +156,13 @@ int launch_dw_inst(const Layer &L, const float *in, const float *skip, const flo
 template <int ACT>
 int launch_dw(const Layer &L, const float *in, const float *skip, const float *wp, const float *bias, float *out, hipStream_t s)
 {
+    if (L.dw_rows) {
+        if (L.d.stride == 1)
+            hipLaunchKernelGGL((fd_dw3_rows_f32<1, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
+        else
+            hipLaunchKernelGGL((fd_dw3_rows_f32<2, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
+        return check_launch("fd_dw3_rows_f32");
+    }
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     switch (key) {
     case 310: return launch_dw_inst<3, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
@@ -175,7 +183,8 @@ int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias
     const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
 #define FD_PW_CASE(a, b, c, d) \
     case a * 1000 + b * 100 + c * 10 + d: \
-        hipLaunchKernelGGL((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K); break;
+        if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_pw_gemm_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        hipLaunchKernelGGL((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, L.m_tiles, L.n_tiles); break;
     switch (key) {
         FD_PW_CASE(2, 2, 2, 2)
         FD_PW_CASE(2, 2, 2, 1)
@@ -267,6 +276,18 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             if (d.stride == 2 && (L.in_h % 2 || L.in_w % 2)) FD_BAD("layer %d: stride-2 depthwise on odd input", i);
             L.mode = d.upsample ? (d.skip >= 0 ? 2 : 1) : 0;
             L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
+            if (d.ksize == 3 && L.mode == 0) {
+                // register-window kernel: pick the row-strip height so that the grid has >= ~4 workgroups per CU when it can
+                L.dw_rows = true;
+                const int gx = ceil_div((long)L.out_w * (d.cin / 4), 256);
+                int th = L.out_h;
+                while (th > 4 && (long)gx * ceil_div(L.out_h, th) * batch < 1024) th = (th + 1) / 2;
+                L.th = th;
+                L.grid = dim3(gx, ceil_div(L.out_h, th), batch);
+                L.lds = 0;
+                L.w_bytes = (size_t)9 * d.cin * esz;
+                break;
+            }
             const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);
             const int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = d.stride == 2 ? 8 : 16;
@@ -293,12 +314,14 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 const long M = (long)batch * L.out_h * L.out_w;
                 L.pw = choose_pw(M, d.cout);
                 L.lds = pw_lds_bytes(L.pw);
-                L.grid = dim3(ceil_div(M, L.pw.wgm * L.pw.tm * 32), ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32));
+                L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
+                L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
+                L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));   // 1-D, XCD-aware mapping inside the kernel
             }
             break;
         default: FD_BAD("layer %d: unknown op %d", i, d.op);
         }
-        if (L.lds > 64 * 1024) FD_BAD("layer %d: LDS request %zu exceeds 64 KiB", i, L.lds);
+        if (L.lds > 160 * 1024) FD_BAD("layer %d: LDS request %zu exceeds 160 KiB", i, L.lds);
         L.w_off = woff; woff += align_up(L.w_bytes, 256);
         L.b_off = woff; woff += align_up((size_t)d.cout * 4, 256);
         L.out_bytes = align_up((size_t)batch * L.out_h * L.out_w * d.cout * esz, 256);
@@ -345,16 +368,19 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         char buf[256];
         if (d.op == FD_OP_STEM)
             snprintf(buf, sizeof buf, "stem3x3s2_f32<chunk %d> grid=%u lds=%zu", L.chunk, L.grid.x, L.lds);
+        else if (d.op == FD_OP_DW && L.dw_rows)
+            snprintf(buf, sizeof buf, "dw3_rows_f32<s%d> rows/item %d grid=%ux%ux%u", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW)
             snprintf(buf, sizeof buf, "dwconv_f32<k%d s%d mode%d> tile %dx%dx%d grid=%ux%ux%u lds=%zu", d.ksize, d.stride, L.mode,
                      L.th, L.tw, 4 << L.cbq, L.grid.x, L.grid.y, L.grid.z, L.lds);
         else if (L.head)
             snprintf(buf, sizeof buf, "head_pw1_f32 up=%d grid=%u", d.upsample, L.grid.x);
         else
-            snprintf(buf, sizeof buf, "pw_gemm_f32<%dx%d> M=%ld N=%d K=%d grid=%ux%u lds=%zu", L.pw.wgm * L.pw.tm * 32,
-                     L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.grid.x, L.grid.y, L.lds);
+            snprintf(buf, sizeof buf, "pw_gemm_f32<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
+                     L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         L.info = buf;
         if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2_f32<%d, %d>", d.act, L.chunk);
+        else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows_f32<%d, %d>", d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv_f32<%d, %d, %d, %d>", d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1_f32<%d>", d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);

@@ -183,29 +183,110 @@ fd_dwconv_f32(const float *__restrict__ in, const float *__restrict__ skip, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depthwise 3x3, stride S, NHWC, register-window variant (no LDS, no barriers) for the encoder layers.
+// In NHWC an image row is one contiguous run of W*C floats, so a work-item is indexed by q = x*(C/4) + c4
+// (one 16-byte channel group of one column) and neighbouring work-items touch neighbouring 16-byte words:
+// every wave access is a dense 1 KiB run whatever C is (also for the pruned, non-power-of-two widths).
+// Each work-item walks down TH output rows keeping the 3 x 3 input window (and the 9 folded taps) in
+// registers: per output row it loads only the 3*S new input vectors; the horizontal neighbours it needs are
+// the same words its neighbours load, so they are L1/L2 hits and HBM sees every input byte once.
+// ------------------------------------------------------------------------------------------------
+template <int S, int ACT>
+__global__ void __launch_bounds__(256)
+fd_dw3_rows_f32(const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
+                float *__restrict__ out, int H, int W, int Ho, int Wo, int C, int TH)
+{
+    const int CG = C >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;            // output column-group index within a row
+    if (q >= Wo * CG) return;
+    const int xo = q / CG, c4 = q - xo * CG;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * TH;
+    const int oy1 = (oy0 + TH < Ho) ? oy0 + TH : Ho;
+    fd_f32x4 w[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = fd_ld4(wp + (long)t * C + c4 * 4);
+    const fd_f32x4 b4 = fd_ld4(bias + c4 * 4);
+    const float *img = in + (long)n * H * W * C + c4 * 4;
+    const int x0 = xo * S - 1;                                  // leftmost input column of the window
+    const bool okl = x0 >= 0, okr = (x0 + 2) < W;               // centre column x0+1 is always valid
+    auto load_row = [&](int iy, fd_f32x4 &l, fd_f32x4 &c, fd_f32x4 &r) {
+        if (iy < 0 || iy >= H) { l = c = r = fd_zero4(); return; }
+        const float *p = img + ((long)iy * W + x0) * C;
+        l = okl ? fd_ld4(p) : fd_zero4();
+        c = fd_ld4(p + C);
+        r = okr ? fd_ld4(p + 2 * C) : fd_zero4();
+    };
+    float *o = out + (((long)n * Ho + oy0) * Wo) * C + (long)q * 4;
+    if (S == 1) {
+        fd_f32x4 r0l, r0c, r0r, r1l, r1c, r1r, r2l, r2c, r2r;
+        load_row(oy0 - 1, r0l, r0c, r0r);
+        load_row(oy0, r1l, r1c, r1r);
+        for (int oy = oy0; oy < oy1; ++oy) {
+            load_row(oy + 1, r2l, r2c, r2r);
+            fd_f32x4 acc = b4;
+            acc += r0l * w[0]; acc += r0c * w[1]; acc += r0r * w[2];
+            acc += r1l * w[3]; acc += r1c * w[4]; acc += r1r * w[5];
+            acc += r2l * w[6]; acc += r2c * w[7]; acc += r2r * w[8];
+            fd_st4(o, fd_act4<ACT>(acc));
+            o += (long)Wo * C;
+            r0l = r1l; r0c = r1c; r0r = r1r; r1l = r2l; r1c = r2c; r1r = r2r;
+        }
+    } else {
+        fd_f32x4 r0l, r0c, r0r, r1l, r1c, r1r, r2l, r2c, r2r;
+        load_row(2 * oy0 - 1, r0l, r0c, r0r);
+        for (int oy = oy0; oy < oy1; ++oy) {
+            load_row(2 * oy, r1l, r1c, r1r);
+            load_row(2 * oy + 1, r2l, r2c, r2r);
+            fd_f32x4 acc = b4;
+            acc += r0l * w[0]; acc += r0c * w[1]; acc += r0r * w[2];
+            acc += r1l * w[3]; acc += r1c * w[4]; acc += r1r * w[5];
+            acc += r2l * w[6]; acc += r2c * w[7]; acc += r2r * w[8];
+            fd_st4(o, fd_act4<ACT>(acc));
+            o += (long)Wo * C;
+            r0l = r2l; r0c = r2c; r0r = r2r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pointwise 1x1 conv as GEMM:  out[M][N] = act(A[M][K] * Wt[N][K]^T + bias[N]),  M = B*H*W pixels (NHWC
 // rows), K = Cin, N = Cout, all fp32, on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
-// 4 waves as WGM x WGN, each wave owns TM x TN tiles of 32x32 -> block tile (WGM*TM*32) x (WGN*TN*32),
-// BK = 32.  Global -> register prefetch of the next K tile overlaps the MFMAs of the current one; LDS
-// rows are padded to 33 floats so both the 4-byte fragment reads (lane = row) and the transposing
-// writes are bank-conflict free.  Ragged M / N / K (pruned plans: multiples of 8) are zero-filled.
+//
+// 4 waves as WGM x WGN, each wave owns TM x TN tiles of 32x32 -> block tile (WGM*TM*32) x (WGN*TN*32), BK = 32.
+//  * LDS holds both operands row-major with 144-byte rows (32 floats + 16 B pad), double buffered: one
+//    barrier per K tile, the global->register prefetch of tile t+1 is in flight during the MFMAs of tile t.
+//  * K-permutation trick: one MFMA step multiplies the k held by lanes 0-31 with the k' held by lanes 32-63,
+//    and any pairing is valid as long as A and B use the same one.  So every lane fetches ONE 16-byte chunk
+//    (4 consecutive k of its row; lanes 0-31 chunk 2g, lanes 32-63 chunk 2g+1) with a single ds_read_b128 and
+//    feeds 4 MFMAs from it -- 4x fewer LDS instructions than per-step 4-byte fragment reads, and the staging
+//    side becomes a single ds_write_b128 per 16-byte global load.  The 9-slot row pitch makes both the
+//    b128 reads (16-lane groups over distinct rows) and the b128 writes (8-lane groups along one row)
+//    bank-conflict free.
+//  * XCD-aware 1-D grid: workgroup b runs on XCD b%8 (observed dispatch order); the N tiles of one M tile get
+//    consecutive slots on ONE XCD so the A panel is fetched into that XCD's L2 once; weights stay L2 resident.
+// Ragged M / N / K (pruned plans: multiples of 8 / 4) are zero-filled.
 // ------------------------------------------------------------------------------------------------
 template <int WGM, int WGN, int TM, int TN, int ACT>
 __global__ void __launch_bounds__(256)
 fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
-               float *__restrict__ out, int M, int N, int K)
+               float *__restrict__ out, int M, int N, int K, int m_tiles, int n_tiles)
 {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32, LS = BK + 1;
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32, RS = BK + 4;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;         // 16-byte loads per work-item per K tile
+    constexpr int BUF = (BM + BN) * RS;                    // floats per LDS buffer
     FD_DYN_SMEM(smem_raw);
-    float *As = reinterpret_cast<float *>(smem_raw);       // [BM][LS]
-    float *Bs = As + BM * LS;                              // [BN][LS]
+    float *smem = reinterpret_cast<float *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int lr = tid >> 3, lk = (tid & 7) * 4;          // staging: row within a 32-row slab, k offset
+    // XCD-aware tile assignment
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % n_tiles, mt = (slot / n_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    const int lr = tid >> 3, lk = (tid & 7) * 4;          // staging: row within a 32-row slab, k offset of the 16-B chunk
 
     fd_f32x4 ra[A_IT], rb[B_IT];
     auto gload = [&](int k0) {
@@ -221,17 +302,11 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
             rb[i] = (k_ok && row < N) ? fd_ld4(Wt + (long)row * K + k0 + lk) : fd_zero4();
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](float *buf) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            float *p = As + (lr + 32 * i) * LS + lk;
-            p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
-        }
+        for (int i = 0; i < A_IT; ++i) fd_st4(buf + (lr + 32 * i) * RS + lk, ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            float *p = Bs + (lr + 32 * i) * LS + lk;
-            p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
-        }
+        for (int i = 0; i < B_IT; ++i) fd_st4(buf + (BM + lr + 32 * i) * RS + lk, rb[i]);
     };
 
     fd_f32x16 acc[TM][TN];
@@ -242,27 +317,33 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const float *a_frag = As + (wm * TM * 32 + (lane & 31)) * LS + (lane >> 5);
-    const float *b_frag = Bs + (wn * TN * 32 + (lane & 31)) * LS + (lane >> 5);
+    // this lane's fragment base: row (lane&31) of the wave's first tile, chunk (lane>>5) of each chunk pair
+    const int a_off = (wm * TM * 32 + (lane & 31)) * RS + (lane >> 5) * 4;
+    const int b_off = (BM + wn * TN * 32 + (lane & 31)) * RS + (lane >> 5) * 4;
 
+    const int T = (K + BK - 1) / BK;
     gload(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        lstore();
-        __syncthreads();
-        if (k0 + BK < K) gload(k0 + BK);
+    lstore(smem);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const float *cur = smem + (t & 1) * BUF;
+        if (t + 1 < T) gload((t + 1) * BK);
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
+        for (int g = 0; g < BK / 8; ++g) {
+            fd_f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = a_frag[i * 32 * LS + kk * 2];
+            for (int i = 0; i < TM; ++i) a[i] = fd_ld4(cur + a_off + i * 32 * RS + g * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = b_frag[j * 32 * LS + kk * 2];
+            for (int j = 0; j < TN; ++j) b[j] = fd_ld4(cur + b_off + j * 32 * RS + g * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
         }
+        if (t + 1 < T) lstore(smem + ((t + 1) & 1) * BUF);
         __syncthreads();
     }
 

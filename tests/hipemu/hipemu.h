@@ -236,6 +236,6 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
-template <typename F> inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 
 #endif /* HIPEMU_H */
