@@ -11,13 +11,33 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#ifndef FD_EMU
+#include <hip/hip_ext.h>
+#endif
+
 namespace {
 
 thread_local std::string g_err;
+
+// fd_forward_timed sets these so that the next launch records the kernel's own begin/end timestamps
+// (hipExtLaunchKernelGGL start/stop events == what rocprofv3's kernel trace reports), without the
+// launch-gap and event-record overhead that bracketing with hipEventRecord would add.
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+#ifdef FD_EMU
+#define FD_LAUNCH(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)
+#else
+#define FD_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                        \
+        if (g_ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+    } while (0)
+#endif
 
 int fail(int code, const char *fmt, ...)
 {
@@ -41,6 +61,7 @@ struct Layer {
     int out_h = 0, out_w = 0;
     size_t out_off = 0, out_bytes = 0;   // activation arena
     size_t w_off = 0, w_bytes = 0, b_off = 0;   // packed weights / bias
+    size_t w_elems = 0;          // unpadded weight element count (algorithmic bytes)
     bool to_output = false;      // writes the network output buffer directly
     bool head = false;           // Cout == 1 pointwise: fd_head_pw1_f32
     // dw tiling
@@ -122,7 +143,7 @@ PwCfg choose_pw(long M, int N)
     return c64x64;
 }
 
-int pw_lds_bytes(const PwCfg &c) { return 2 * (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 36 * 4; }   // double-buffered, 144-byte rows
+int pw_lds_bytes(const PwCfg &c) { return 3 * (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 32 * 4; }   // 3-stage ring of 128-byte rows
 
 int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 
@@ -138,9 +159,9 @@ template <int ACT>
 int launch_stem(const Layer &L, const float *x, const float *wp, const float *bias, float *y, int B, hipStream_t s)
 {
     switch (L.chunk) {
-    case 32: hipLaunchKernelGGL((fd_stem3x3s2_f32<ACT, 32>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
-    case 16: hipLaunchKernelGGL((fd_stem3x3s2_f32<ACT, 16>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
-    default: hipLaunchKernelGGL((fd_stem3x3s2_f32<ACT, 8>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    case 32: FD_LAUNCH((fd_stem3x3s2_f32<ACT, 32>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    case 16: FD_LAUNCH((fd_stem3x3s2_f32<ACT, 16>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    default: FD_LAUNCH((fd_stem3x3s2_f32<ACT, 8>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
     }
     return check_launch("fd_stem3x3s2_f32");
 }
@@ -148,7 +169,7 @@ int launch_stem(const Layer &L, const float *x, const float *wp, const float *bi
 template <int K, int S, int MODE, int ACT>
 int launch_dw_inst(const Layer &L, const float *in, const float *skip, const float *wp, const float *bias, float *out, hipStream_t s)
 {
-    hipLaunchKernelGGL((fd_dwconv_f32<K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
+    FD_LAUNCH((fd_dwconv_f32<K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
                        L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);
     return check_launch("fd_dwconv_f32");
 }
@@ -158,9 +179,9 @@ int launch_dw(const Layer &L, const float *in, const float *skip, const float *w
 {
     if (L.dw_rows) {
         if (L.d.stride == 1)
-            hipLaunchKernelGGL((fd_dw3_rows_f32<1, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
+            FD_LAUNCH((fd_dw3_rows_f32<1, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
         else
-            hipLaunchKernelGGL((fd_dw3_rows_f32<2, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
+            FD_LAUNCH((fd_dw3_rows_f32<2, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
         return check_launch("fd_dw3_rows_f32");
     }
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
@@ -184,7 +205,7 @@ int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias
 #define FD_PW_CASE(a, b, c, d) \
     case a * 1000 + b * 100 + c * 10 + d: \
         if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_pw_gemm_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        hipLaunchKernelGGL((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, L.m_tiles, L.n_tiles); break;
+        FD_LAUNCH((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, (K + 31) / 32 * 32, L.m_tiles, L.n_tiles); break;
     switch (key) {
         FD_PW_CASE(2, 2, 2, 2)
         FD_PW_CASE(2, 2, 2, 1)
@@ -212,7 +233,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
         if (L.head) {
             const int h = L.d.upsample ? L.in_h / 2 : L.in_h, w = L.d.upsample ? L.in_w / 2 : L.in_w;
             const long npix = (long)p->B * h * w;
-            hipLaunchKernelGGL((fd_head_pw1_f32<ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, npix, h, w, L.d.cin, L.d.upsample);
+            FD_LAUNCH((fd_head_pw1_f32<ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, npix, h, w, L.d.cin, L.d.upsample);
             return check_launch("fd_head_pw1_f32");
         }
         return launch_pw<ACT>(L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
@@ -268,7 +289,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
             L.lds = 256 * (L.chunk + 4) * 4;
             L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
-            L.w_bytes = (size_t)27 * d.cout * esz;
+            L.w_bytes = (size_t)27 * d.cout * esz; L.w_elems = (size_t)27 * d.cout;
             break;
         case FD_OP_DW: {
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4)
@@ -285,25 +306,27 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.th = th;
                 L.grid = dim3(gx, ceil_div(L.out_h, th), batch);
                 L.lds = 0;
-                L.w_bytes = (size_t)9 * d.cin * esz;
+                L.w_bytes = (size_t)9 * d.cin * esz; L.w_elems = (size_t)9 * d.cin;
                 break;
             }
             const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);
-            const int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = d.stride == 2 ? 8 : 16;
+            int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = 8;   // 8x16 outputs x 32 channels: ~37 KB LDS -> 4 workgroups per CU (measured best, round 1)
+            if (const char *e = getenv("FD_TUNE_DW_TILE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b >= 4 && b % 4 == 0) { tmax_h = a; tmax_w = b; } }   // tuning aid
             L.tw = std::min((L.out_w + 3) / 4 * 4, tmax_w);
             L.th = std::min(L.out_h, tmax_h);
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
             L.lds = ((size_t)th_in * tw_in * (cb + 4) + (size_t)d.ksize * d.ksize * cb + cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
-            L.w_bytes = (size_t)d.ksize * d.ksize * d.cin * esz;
+            L.w_bytes = (size_t)d.ksize * d.ksize * d.cin * esz; L.w_elems = (size_t)d.ksize * d.ksize * d.cin;
             break;
         }
         case FD_OP_PW:
             if (d.src < 0 || d.ksize != 1 || d.stride != 1 || d.cin % 4) FD_BAD("layer %d: pointwise needs k=1 stride=1 cin%%4==0", i);
             L.out_h = L.in_h; L.out_w = L.in_w;
             L.w_bytes = (size_t)d.cin * d.cout * esz;
+            L.w_elems = (size_t)d.cin * d.cout;
             if (d.cout == 1) {
                 if (d.skip >= 0) FD_BAD("layer %d: head with skip is not part of this path", i);
                 L.head = true;
@@ -312,6 +335,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             } else {
                 if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample is only supported for the 1-channel head", i);
                 const long M = (long)batch * L.out_h * L.out_w;
+                L.w_bytes = (size_t)d.cout * ((d.cin + 31) / 32 * 32) * esz;      // rows zero-padded to a multiple of BK = 32
                 L.pw = choose_pw(M, d.cout);
                 L.lds = pw_lds_bytes(L.pw);
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
@@ -358,7 +382,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         const double src_elems = (double)batch * (d.upsample ? (L.in_h / 2) * (L.in_w / 2) : L.in_h * L.in_w) * d.cin;
         const double skip_elems = d.skip >= 0 ? (double)batch * L.in_h * L.in_w * d.cin : 0.0;
         const double out_elems = (double)batch * L.out_h * L.out_w * d.cout;
-        const double w_elems = (double)L.w_bytes / esz + 2.0 * d.cout;
+        const double w_elems = (double)L.w_elems + 2.0 * d.cout;
         L.alg_bytes = (src_elems + skip_elems + out_elems + w_elems) * esz;
         p->alg_bytes += L.alg_bytes;
         const double taps = d.op == FD_OP_STEM ? 27.0 : (d.op == FD_OP_DW ? (double)d.ksize * d.ksize : (double)d.cin);
@@ -414,12 +438,13 @@ int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n
         const Layer &L = plan->layers[i];
         const fd_layer_params &q = params[i];
         if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
-        const int inner = (int)(L.w_bytes / 4 / L.d.cout);
+        const int inner = (int)(L.w_elems / L.d.cout);
         const int transpose = (L.d.op == FD_OP_PW) ? 0 : 1;          // stem/dw kernels want tap-major [inner][cout]
-        const long total = std::max<long>((long)L.d.cout * inner, L.d.cout);
+        const int pitch = transpose ? inner : (int)(L.w_bytes / 4 / L.d.cout);   // pointwise rows are padded to 32 floats
+        const long total = std::max<long>((long)L.d.cout * std::max(inner, pitch), L.d.cout);
         hipLaunchKernelGGL(fd_pack_fold_f32, dim3(ceil_div(total, 256)), dim3(256), 0, s, q.conv_weight, q.bn_weight, q.bn_bias,
                            q.bn_mean, q.bn_var, bn_eps, reinterpret_cast<float *>(plan->ws + L.w_off),
-                           reinterpret_cast<float *>(plan->ws + L.b_off), L.d.cout, inner, transpose);
+                           reinterpret_cast<float *>(plan->ws + L.b_off), L.d.cout, inner, transpose, pitch);
         int rc = check_launch("fd_pack_fold_f32");
         if (rc) return rc;
     }
@@ -458,17 +483,17 @@ int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, f
     return fd_forward(plan, x_nchw, y, stream);
 #else
     hipStream_t s = static_cast<hipStream_t>(stream);
-    std::vector<hipEvent_t> ev(n_layers + 1);
+    std::vector<hipEvent_t> ev(2 * n_layers);
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
     int rc = FD_OK;
-    (void)hipEventRecord(ev[0], s);
     for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
+        g_ev_start = ev[2 * i]; g_ev_stop = ev[2 * i + 1];
         rc = run_layer(plan, plan->layers[i], static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
-        (void)hipEventRecord(ev[i + 1], s);
     }
+    g_ev_start = g_ev_stop = nullptr;
     if (rc == FD_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(FD_ERR_HIP, "hipStreamSynchronize failed");
     for (int i = 0; i < n_layers && rc == FD_OK; ++i)
-        if (hipEventElapsedTime(&ms_per_layer[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
+        if (hipEventElapsedTime(&ms_per_layer[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 #endif

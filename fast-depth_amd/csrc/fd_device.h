@@ -11,6 +11,28 @@
 #define FD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
+// ---- direct global -> LDS copy (LDS-DMA), counted waits, raw workgroup barrier -------------------------
+// fd_glds16: every lane copies 16 bytes from ITS global address to  lds_wave_base + lane*16  (the LDS side is
+// wave-uniform base + lane*16 by hardware; a swizzled LDS image is obtained by permuting the per-lane SOURCE).
+#ifdef FD_EMU
+inline void fd_glds16(const float *g, float *lds_wave_base) { memcpy((char *)lds_wave_base + hipemu::lane_id() * 16, g, 16); }
+template <int N> inline void fd_wait_vmcnt() {}
+#define FD_SCHED_FENCE() ((void)0)
+inline void fd_block_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void fd_glds16(const float *g, float *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+// wait until at most N of this wave's vector-memory operations (LDS-DMA loads included) are still outstanding
+template <int N> __device__ __forceinline__ void fd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// keeps the compiler's scheduler from moving instructions across this point (source order = issue order)
+#define FD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// raw s_barrier: unlike __syncthreads() it does not drain vmcnt, so LDS-DMA loads stay in flight across it
+__device__ __forceinline__ void fd_block_barrier() { __builtin_amdgcn_s_barrier(); }
+#endif
+
 typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 typedef float fd_f32x2 __attribute__((ext_vector_type(2)));
 typedef float fd_f32x16 __attribute__((ext_vector_type(16)));

@@ -23,14 +23,16 @@
 __global__ void __launch_bounds__(256)
 fd_pack_fold_f32(const float *__restrict__ w, const float *__restrict__ gamma, const float *__restrict__ beta,
                  const float *__restrict__ mean, const float *__restrict__ var, float eps,
-                 float *__restrict__ wp, float *__restrict__ bias, int cout, int inner, int transpose)
+                 float *__restrict__ wp, float *__restrict__ bias, int cout, int inner, int transpose, int row_pitch)
 {
+    // transpose == 0: wp[co][row_pitch] (rows zero-padded beyond `inner`);  transpose == 1: wp[inner][cout]
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)cout * inner;
+    const long total = transpose ? (long)cout * inner : (long)cout * row_pitch;
     if (idx < total) {
-        const int co = (int)(idx / inner), i = (int)(idx - (long)co * inner);
+        const int per = transpose ? inner : row_pitch;
+        const int co = (int)(idx / per), i = (int)(idx - (long)co * per);
         const float scale = gamma[co] / sqrtf(var[co] + eps);
-        const float v = w[idx] * scale;
+        const float v = i < inner ? w[(long)co * inner + i] * scale : 0.0f;
         if (transpose) wp[(long)i * cout + co] = v; else wp[idx] = v;
     }
     if (idx < cout) {
@@ -135,21 +137,34 @@ fd_dwconv_f32(const float *__restrict__ in, const float *__restrict__ skip, cons
     }
     if (tid < lanes_c) fd_st4(s_b + tid * 4, (c0 + tid * 4 < C) ? fd_ld4(bias + c0 + tid * 4) : fd_zero4());
 
+    // Staging with memory-level parallelism: U patch pixels per work-item are requested back to back (2*U
+    // independent 16-byte loads in flight in MODE 2) before any of them is consumed; a load -> add -> ds_write
+    // chain per pixel would serialise ~12 HBM round trips per workgroup.
     const int npx_in = TH_in * TW_in;
-    for (int px = pt; px < npx_in; px += npt) {
-        const int iy = px / TW_in, ix = px - iy * TW_in;
-        const int gy = iy0 + iy, gx = ix0 + ix;
-        fd_f32x4 v = fd_zero4();
-        if (c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {
-            if (MODE == 0) {
-                v = fd_ld4(in + (((long)n * Hin + gy) * Win + gx) * C + cg);
-            } else {
-                const int Hs = Hin >> 1, Ws = Win >> 1;
-                v = fd_ld4(in + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
-                if (MODE == 2) v += fd_ld4(skip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+    constexpr int U = 8;
+    for (int base = pt; base < npx_in; base += npt * U) {
+        fd_f32x4 v[U], sk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            const int iy = px / TW_in, ix = px - iy * TW_in;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            v[u] = fd_zero4(); sk[u] = fd_zero4();
+            if (px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {
+                if (MODE == 0) {
+                    v[u] = fd_ld4(in + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                } else {
+                    const int Hs = Hin >> 1, Ws = Win >> 1;
+                    v[u] = fd_ld4(in + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                    if (MODE == 2) sk[u] = fd_ld4(skip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                }
             }
         }
-        fd_st4(s_in + px * PSTR + c4 * 4, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            if (px < npx_in) fd_st4(s_in + px * PSTR + c4 * 4, MODE == 2 ? v[u] + sk[u] : v[u]);
+        }
     }
     __syncthreads();
 
@@ -250,116 +265,150 @@ fd_dw3_rows_f32(const float *__restrict__ in, const float *__restrict__ wp, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pointwise 1x1 conv as GEMM:  out[M][N] = act(A[M][K] * Wt[N][K]^T + bias[N]),  M = B*H*W pixels (NHWC
+// Pointwise 1x1 conv as GEMM:  out[M][N] = act(A[M][K] * Wt[N][K32]^T + bias[N]),  M = B*H*W pixels (NHWC
 // rows), K = Cin, N = Cout, all fp32, on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+// Wt rows are zero-padded to K32 = ceil32(K) by fd_pack_fold_f32, so a ragged last K tile multiplies by exact 0.
 //
 // 4 waves as WGM x WGN, each wave owns TM x TN tiles of 32x32 -> block tile (WGM*TM*32) x (WGN*TN*32), BK = 32.
-//  * LDS holds both operands row-major with 144-byte rows (32 floats + 16 B pad), double buffered: one
-//    barrier per K tile, the global->register prefetch of tile t+1 is in flight during the MFMAs of tile t.
+//  * Operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a
+//    3-stage ring, issued TWO K tiles ahead; counted s_waitcnt vmcnt + a raw s_barrier keep those loads in
+//    flight across the one barrier per K tile.  (With the fp32 MFMA at 64 cycles the kernel is latency, not
+//    bandwidth, sensitive: a one-tile-ahead register prefetch left ~20% of the time exposed.)
+//  * LDS rows are 128 bytes (8 chunks of 16 B) with an XOR swizzle chunk' = chunk ^ ((row>>1)&7).  LDS-DMA writes
+//    lane-linearly, so the swizzle is applied to the per-lane SOURCE address (the 8 lanes of a row still read
+//    one 128-byte line) and again on the fragment reads, which makes the 16-lane ds_read_b128 groups hit 16
+//    distinct 16-byte slots.
 //  * K-permutation trick: one MFMA step multiplies the k held by lanes 0-31 with the k' held by lanes 32-63,
-//    and any pairing is valid as long as A and B use the same one.  So every lane fetches ONE 16-byte chunk
-//    (4 consecutive k of its row; lanes 0-31 chunk 2g, lanes 32-63 chunk 2g+1) with a single ds_read_b128 and
-//    feeds 4 MFMAs from it -- 4x fewer LDS instructions than per-step 4-byte fragment reads, and the staging
-//    side becomes a single ds_write_b128 per 16-byte global load.  The 9-slot row pitch makes both the
-//    b128 reads (16-lane groups over distinct rows) and the b128 writes (8-lane groups along one row)
-//    bank-conflict free.
+//    and any pairing is valid as long as A and B use the same one.  Every lane fetches ONE 16-byte chunk (4
+//    consecutive k of its row; lanes 0-31 chunk 2g, lanes 32-63 chunk 2g+1) per ds_read_b128 and feeds 4 MFMAs.
 //  * XCD-aware 1-D grid: workgroup b runs on XCD b%8 (observed dispatch order); the N tiles of one M tile get
 //    consecutive slots on ONE XCD so the A panel is fetched into that XCD's L2 once; weights stay L2 resident.
-// Ragged M / N / K (pruned plans: multiples of 8 / 4) are zero-filled.
+// Ragged M / N: source rows are clamped (finite garbage in rows that are never stored).
 // ------------------------------------------------------------------------------------------------
 template <int WGM, int WGN, int TM, int TN, int ACT>
 __global__ void __launch_bounds__(256)
 fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
-               float *__restrict__ out, int M, int N, int K, int m_tiles, int n_tiles)
+               float *__restrict__ out, int M, int N, int K, int K32, int m_tiles, int n_tiles)
 {
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32, RS = BK + 4;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;         // 16-byte loads per work-item per K tile
-    constexpr int BUF = (BM + BN) * RS;                    // floats per LDS buffer
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32;
+    constexpr int ROWS = BM + BN;                          // LDS rows per stage (A rows then W rows), 32 floats each
+    constexpr int STAGE = ROWS * BK;                       // floats per stage
+    constexpr int RG = ROWS / 8 / 4;                       // LDS-DMA instructions (8 rows = 1 KiB each) per wave per K tile
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    // XCD-aware tile assignment
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nt = slot % n_tiles, mt = (slot / n_tiles) * 8 + xcd;
     if (mt >= m_tiles) return;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
-    const int lr = tid >> 3, lk = (tid & 7) * 4;          // staging: row within a 32-row slab, k offset of the 16-B chunk
 
-    fd_f32x4 ra[A_IT], rb[B_IT];
-    auto gload = [&](int k0) {
-        const bool k_ok = (k0 + lk) < K;
+    // ---- LDS-DMA source pointers: this lane's row / swizzled chunk for each of the wave's row groups ----
+    const float *src[RG];
+    int src_chunk[RG];
+    bool src_is_a[RG];
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const long row = m0 + lr + 32 * i;
-            ra[i] = (k_ok && row < M) ? fd_ld4(A + row * K + k0 + lk) : fd_zero4();
-        }
+    for (int i = 0; i < RG; ++i) {
+        const int r = (wave + 4 * i) * 8 + (lane >> 3);     // row within the stage
+        const int c = (lane & 7) ^ ((r >> 1) & 7);          // global chunk that lands in LDS slot (r, lane&7)
+        src_chunk[i] = c * 4;
+        src_is_a[i] = r < BM;
+        if (r < BM) { long row = m0 + r; if (row > M - 1) row = M - 1; src[i] = A + row * K; }
+        else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K32; }
+    }
+    auto issue = [&](int t) {
+        float *dst = smem + (t % 3) * STAGE + wave * 8 * BK;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int row = n0 + lr + 32 * i;
-            rb[i] = (k_ok && row < N) ? fd_ld4(Wt + (long)row * K + k0 + lk) : fd_zero4();
+        for (int i = 0; i < RG; ++i) {
+            int k = t * BK + src_chunk[i];
+            if (src_is_a[i] && k >= K) k = 0;                // ragged K: any finite data; the padded weights are 0 there
+            fd_glds16(src[i] + k, dst + i * 4 * 8 * BK);
         }
     };
-    auto lstore = [&](float *buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) fd_st4(buf + (lr + 32 * i) * RS + lk, ra[i]);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) fd_st4(buf + (BM + lr + 32 * i) * RS + lk, rb[i]);
-    };
 
+    // accumulators start at the folded-BN bias of their column (a D register holds 16 rows of ONE column), so the
+    // epilogue is just activation + store and no load is pending when the stores are issued
     fd_f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const float bv = col < N ? bias[col] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
 
-    // this lane's fragment base: row (lane&31) of the wave's first tile, chunk (lane>>5) of each chunk pair
-    const int a_off = (wm * TM * 32 + (lane & 31)) * RS + (lane >> 5) * 4;
-    const int b_off = (BM + wn * TN * 32 + (lane & 31)) * RS + (lane >> 5) * 4;
+    // ---- fragment read offsets (floats) within a stage: row*32 + ((2g + h) ^ swz(row))*4 ----
+    const int h = lane >> 5;
+    int a_off[TM][4], b_off[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a_off[i][g] = row * BK + (((2 * g + h) ^ ((row >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = BM + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b_off[j][g] = row * BK + (((2 * g + h) ^ ((row >> 1) & 7)) << 2);
+    }
 
-    const int T = (K + BK - 1) / BK;
-    gload(0);
-    lstore(smem);
-    __syncthreads();
+    const int T = K32 / BK;
+    issue(0);
+    if (T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
-        const float *cur = smem + (t & 1) * BUF;
-        if (t + 1 < T) gload((t + 1) * BK);
+        if (t + 1 < T) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();   // leave only tile t+1's loads in flight
+        fd_block_barrier();                                  // tile t landed for every wave; stage (t+2)%3 is free again
+        const float *cur = smem + (t % 3) * STAGE;
+        // software pipeline inside the K tile: the fragments of chunk pair g+1 are requested before the MFMAs of
+        // pair g are issued, and the LDS-DMA for tile t+2 is issued under the first fragment reads' latency
+        fd_f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            fd_f32x4 a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a[0][i] = fd_ld4(cur + a_off[i][0]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = fd_ld4(cur + a_off + i * 32 * RS + g * 8);
+        for (int j = 0; j < TN; ++j) b[0][j] = fd_ld4(cur + b_off[j][0]);
+        if (t + 2 < T) issue(t + 2);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = fd_ld4(cur + b_off + j * 32 * RS + g * 8);
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(g + 1) & 1][i] = fd_ld4(cur + a_off[i][g + 1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(g + 1) & 1][j] = fd_ld4(cur + b_off[j][g + 1]);
+            }
+            FD_SCHED_FENCE();
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][q], b[g & 1][j][q], acc[i][j], 0, 0, 0);
+            FD_SCHED_FENCE();
         }
-        if (t + 1 < T) lstore(smem + ((t + 1) & 1) * BUF);
-        __syncthreads();
     }
 
     // epilogue: D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31 of the 32x32 tile
+    const bool full = m0 + BM <= M;                          // workgroup-uniform: only the last M tile can be ragged
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (col >= N) continue;
-        const float bv = bias[col];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const long rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+            float *o = out + rbase * N + col;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < M) out[row * N + col] = fd_act<ACT>(acc[i][j][r] + bv);
+                for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * N] = fd_act<ACT>(acc[i][j][r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (rbase + (r & 3) + 8 * (r >> 2) < M) o[((r & 3) + 8 * (r >> 2)) * N] = fd_act<ACT>(acc[i][j][r]);
             }
         }
     }

@@ -98,8 +98,9 @@ int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n
 /* Inference forward: x [B,3,H,W] float32 NCHW -> y [B,cout_last,H,W] float32, enqueued on `stream`. */
 int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream);
 
-/* Same as fd_forward, but brackets every layer's kernel with HIP events on `stream`, synchronises the stream
- * and returns each layer's device time in milliseconds (ms_per_layer[n_layers]).  Measurement aid for
+/* Same as fd_forward, but launches every layer's kernel with begin/end HIP events (hipExtLaunchKernelGGL) on
+ * `stream`, synchronises the stream and returns each kernel's device duration in milliseconds
+ * (ms_per_layer[n_layers]) -- the same quantity rocprofv3's kernel trace reports.  Measurement aid for
  * bench.py's roofline report; not for production calls. */
 int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, float *ms_per_layer, int32_t n_layers);
 

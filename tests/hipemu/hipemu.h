@@ -39,6 +39,7 @@ struct dim3 {
 
 typedef int hipError_t;
 typedef void *hipStream_t;
+typedef void *hipEvent_t;
 #define hipSuccess 0
 #define __global__
 #define __device__
