@@ -540,3 +540,5 @@ int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_
 }
 
 }  // extern "C"
+
+#include "fd_train_impl.h"

@@ -1,0 +1,729 @@
+// fd_kernels_bwd_f32.h -- fp32 backward kernels of the FastDepth train step (gfx950).
+//
+// The train step is not in the reference tree; these kernels implement the autograd of the
+// reference's forward (models.py:706-732 in .train()) by hand:
+//   unit i:  z_i = conv_i(in_i),  y_i = z_i*s_i + t_i  (batch-stat BN),  a_i = act_i(y_i)
+//   saved by the forward: z_i and the table st_i = (s, t, mean, invstd).
+//   G_i  := dLoss/dy_i  (gradient AFTER the activation mask), produced by the backward-data kernel of the consumer,
+//           which also emits the per-channel partial sums  sum(G_i), sum(G_i * xhat_i)   (xhat = (z-mean)*invstd).
+//   fd_bn_bwd_finalize_f32: dbeta = sum(G), dgamma = sum(G*xhat)  -> parameter grads, and the coefficient table
+//           dz_i = A*((G_i - C1) - (z_i - mean)*C2)   with  A = s,  C1 = dbeta/n,  C2 = invstd*dgamma/n
+//           (the BatchNorm backward  dz = s*(G - dbeta/n - xhat*dgamma/n)  as a per-channel map of (G, z)).
+//   The conv-backward kernels form dz_i ON LOAD from (G_i, z_i) and re-create their forward input
+//   a_{i-1} = act(z_{i-1}*s+t) (+ nearest-x2 / skip composition) on load as well: no normalised, activated,
+//   upsampled or BN-backward tensor is ever written to HBM.
+//   Activation masks are strict (ReLU: y > 0; ReLU6: 0 < y < 6), as torch's threshold/hardtanh backward.
+// All reductions are two-stage with a fixed summation order (deterministic).
+#pragma once
+#include "fd_kernels_train_f32.h"
+
+// coefficient table [4][C] of the BatchNorm backward, written in the cancellation-free form
+//   dz = A * ((G - C1) - (z - MU) * C2),   A = gamma*invstd,  C1 = dbeta/n,  MU = batch mean,  C2 = invstd * dgamma / n
+#define FD_CF_A 0
+#define FD_CF_C1 1
+#define FD_CF_MU 2
+#define FD_CF_C2 3
+__device__ __forceinline__ float fd_dz(float g, float z, float cA, float c1, float mu, float c2) { return cA * ((g - c1) - (z - mu) * c2); }
+__device__ __forceinline__ fd_f32x4 fd_dz4(fd_f32x4 g, fd_f32x4 z, fd_f32x4 cA, fd_f32x4 c1, fd_f32x4 mu, fd_f32x4 c2) { return cA * ((g - c1) - (z - mu) * c2); }
+
+template <int ACT>
+__device__ __forceinline__ float fd_actmask(float y)
+{
+    if (ACT == FD_ACT_RELU_) return y > 0.0f ? 1.0f : 0.0f;
+    if (ACT == FD_ACT_RELU6_) return (y > 0.0f && y < 6.0f) ? 1.0f : 0.0f;
+    return 1.0f;
+}
+template <int ACT>
+__device__ __forceinline__ fd_f32x4 fd_actmask4(fd_f32x4 y)
+{
+    fd_f32x4 r = {fd_actmask<ACT>(y.x), fd_actmask<ACT>(y.y), fd_actmask<ACT>(y.z), fd_actmask<ACT>(y.w)};
+    return r;
+}
+
+// ---- generic deterministic partial reduction: out[j] = sum_b part[b*stride + j], j < n -------------------------------
+__global__ void __launch_bounds__(1024)
+fd_reduce_partials_f32(const float *__restrict__ part, int nblk, long stride, int n, float *__restrict__ out)
+{
+    __shared__ double sh[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (j < n)
+        for (int b = wave; b < nblk; b += 16) s += (double)part[(long)b * stride + j];
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < n) {
+        s = 0.0;
+        for (int w = 0; w < 16; ++w) s += sh[w][lane];
+        out[j] = (float)s;
+    }
+}
+
+// out[c*KK + t] = sum_b part[(b*KK + t)*C + c]   (depthwise weight gradient: tap-major partials -> torch's [C][1][k][k])
+__global__ void __launch_bounds__(1024)
+fd_reduce_partials_tapmajor_f32(const float *__restrict__ part, int nblk, int KK, int C, float *__restrict__ out)
+{
+    __shared__ double sh[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;                      // j = t*C + c
+    double s = 0.0;
+    if (j < KK * C)
+        for (int b = wave; b < nblk; b += 16) s += (double)part[(long)b * KK * C + j];
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < KK * C) {
+        s = 0.0;
+        for (int w = 0; w < 16; ++w) s += sh[w][lane];
+        const int t = j / C, c = j - t * C;
+        out[(long)c * KK + t] = (float)s;
+    }
+}
+
+// ---- BatchNorm backward finalize -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int C, double n, const float *__restrict__ st,
+                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef)
+{
+    __shared__ double sh[16][64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = wave; b < nblk; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+    sh[wave][lane][0] = s; sh[wave][lane][1] = q;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        s = 0.0; q = 0.0;
+        for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        const double sc = st[FD_ST_SCALE * C + c], mean = st[FD_ST_MEAN * C + c], invstd = st[FD_ST_INVSTD * C + c];
+        coef[FD_CF_A * C + c] = (float)sc;
+        coef[FD_CF_C1 * C + c] = (float)(s / n);
+        coef[FD_CF_MU * C + c] = (float)mean;
+        coef[FD_CF_C2 * C + c] = (float)(invstd * q / n);
+    }
+}
+
+// ---- mean-L1 loss forward + backward (torch.nn.L1Loss) --------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fd_l1_loss_f32(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ dpred,
+               float *__restrict__ part, long numel, float inv_numel)
+{
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        s += fabsf(d);
+        dpred[i] = d > 0.0f ? inv_numel : (d < 0.0f ? -inv_numel : 0.0f);
+    }
+    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(64)
+fd_l1_loss_final_f32(const float *__restrict__ part, int nblk, float inv_numel, float *__restrict__ loss)
+{
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[b];
+    float f = (float)s;
+    for (int m = 1; m < 64; m <<= 1) f += __shfl_xor(f, m);
+    if (threadIdx.x == 0) loss[0] = f * inv_numel;
+}
+
+// ---- fused multi-tensor SGD ------------------------------------------------------------------------------------------
+struct fd_sgd_rec { float *param; const float *grad; float *buf; long numel; };
+__global__ void __launch_bounds__(256)
+fd_sgd_f32(const fd_sgd_rec *__restrict__ table, int n_tensors, float lr, float momentum, float wd, float grad_scale, int first_step)
+{
+    // blockIdx.y = tensor, blockIdx.x strides over its elements
+    const fd_sgd_rec r = table[blockIdx.y];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < r.numel; i += (long)gridDim.x * 256) {
+        const float p = r.param[i];
+        const float d = fmaf(wd, p, grad_scale * r.grad[i]);
+        const float b = first_step ? d : fmaf(momentum, r.buf[i], d);
+        r.buf[i] = b;
+        r.param[i] = p - lr * b;
+    }
+}
+
+// ---- head backward, step 1: G_head (low res) = mask(y) * (sum of the 2x2 block of dLoss/dpred) + BN partials ----------
+template <int ACT>
+__global__ void __launch_bounds__(256)
+fd_head_bwd_reduce_f32(const float *__restrict__ dpred, const float *__restrict__ zlow, const float *__restrict__ st,
+                       float *__restrict__ g, float *__restrict__ part, long npix, int h, int w, int up)
+{
+    __shared__ float red[8];
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    float dy = 0.0f, dyx = 0.0f;
+    if (p < npix) {
+        const float z = zlow[p];
+        const float y = z * st[FD_ST_SCALE] + st[FD_ST_SHIFT];
+        float d;
+        if (up) {
+            const int ox = (int)(p % w);
+            const long t = p / w;
+            const int oy = (int)(t % h);
+            const long n = t / h;
+            const float *q = dpred + ((n * 2 * h + 2 * oy) * 2 * (long)w + 2 * ox);
+            d = (q[0] + q[1]) + (q[2 * w] + q[2 * w + 1]);
+        } else {
+            d = dpred[p];
+        }
+        dy = d * fd_actmask<ACT>(y);
+        g[p] = dy;
+        dyx = dy * (z - st[FD_ST_MEAN]) * st[FD_ST_INVSTD];
+    }
+    for (int m = 1; m < 64; m <<= 1) { dy += __shfl_xor(dy, m); dyx += __shfl_xor(dyx, m); }
+    if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = dy; red[(threadIdx.x >> 6) * 2 + 1] = dyx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[(long)blockIdx.x * 2] = red[0] + red[2] + red[4] + red[6];
+        part[(long)blockIdx.x * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// ---- head backward, step 2: the 1-channel pointwise conv.  per low-res pixel p, channel k:
+//   dz = A*G + Bc*z + D (scalars, C == 1);  a_in = act_in(z_in*s+t);  dW[k] += dz*a_in;  dA = dz*w[k];
+//   G_in = mask_in(y_in)*dA  (+ BN partials of the producer).  8 lanes share a pixel, PPB pixels per work-item group.
+template <int ACT_IN, int PPB>
+__global__ void __launch_bounds__(256)
+fd_head_bwd_f32(const float *__restrict__ g, const float *__restrict__ zlow, const float *__restrict__ coef,
+                const float *__restrict__ zin, const float *__restrict__ st_in, const float *__restrict__ w,
+                float *__restrict__ g_in, float *__restrict__ part_in, float *__restrict__ wpart, long npix, int Cin)
+{
+    // work-item (group = tid>>3 in 0..31, l8): channel groups c = l8*4 + 32*j; block covers 32*PPB pixels
+    FD_DYN_SMEM(smem_raw);
+    float *red = reinterpret_cast<float *>(smem_raw);          // [32][Cin][3]  (sum G, sum G*xhat, dW)
+    const int grp = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const float cA = coef[FD_CF_A], c1 = coef[FD_CF_C1], cM = coef[FD_CF_MU], c2 = coef[FD_CF_C2];
+    for (int c = l8 * 4; c < Cin; c += 32) {
+        const fd_f32x4 s4 = fd_ld4(st_in + FD_ST_SCALE * Cin + c), t4 = fd_ld4(st_in + FD_ST_SHIFT * Cin + c);
+        const fd_f32x4 m4 = fd_ld4(st_in + FD_ST_MEAN * Cin + c), i4 = fd_ld4(st_in + FD_ST_INVSTD * Cin + c);
+        const fd_f32x4 w4 = fd_ld4(w + c);
+        fd_f32x4 sg = fd_zero4(), sgx = fd_zero4(), sw = fd_zero4();
+        for (int j = 0; j < PPB; ++j) {
+            const long p = ((long)blockIdx.x * PPB + j) * 32 + grp;
+            if (p < npix) {
+                const float dz = fd_dz(g[p], zlow[p], cA, c1, cM, c2);
+                const fd_f32x4 z = fd_ld4(zin + p * Cin + c);
+                const fd_f32x4 y = z * s4 + t4;
+                const fd_f32x4 gi = fd_actmask4<ACT_IN>(y) * (w4 * dz);
+                fd_st4(g_in + p * Cin + c, gi);
+                sg += gi; sgx += gi * ((z - m4) * i4);
+                sw += fd_act4<ACT_IN>(y) * dz;
+            }
+        }
+        fd_st4(red + (grp * Cin + c) * 3, sg);           // three float4 interleaved per (grp, c)
+        fd_st4(red + (grp * Cin + c) * 3 + 4, sgx);
+        fd_st4(red + (grp * Cin + c) * 3 + 8, sw);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cin; c += 256) {
+        float a = 0.0f, b = 0.0f, d = 0.0f;
+        const int c4 = c & ~3, k = c & 3;
+        for (int gI = 0; gI < 32; ++gI) {
+            const float *r = red + (gI * Cin + c4) * 3;
+            a += r[k]; b += r[4 + k]; d += r[8 + k];
+        }
+        part_in[(long)blockIdx.x * 2 * Cin + c] = a;
+        part_in[(long)blockIdx.x * 2 * Cin + Cin + c] = b;
+        wpart[(long)blockIdx.x * Cin + c] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise backward-data GEMM:  dA[M][K] = dz[M][N] * W[N][K],  dz = A*G + Bc*z + D per column n (formed on the
+// fragment read), reduction over n.  Epilogue: G_in[m][k] = mask_in(y_in[m][k]) * (dA[m][k] (+ skipgrad[m][k])) and the
+// producer's BN partials.  Tiles: 64 (m) x 64 (k), reduction step 32 (n).  LDS per stage: G tile [64][32], z tile
+// [64][32] (swizzled 128-byte rows, LDS-DMA) and the W tile [32 n][64 k] (256-byte rows, read as 4-byte fragments:
+// consecutive lanes = consecutive k).
+// ------------------------------------------------------------------------------------------------
+template <int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
+                const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part,
+                int M, int N, int K, int m_tiles, int k_tiles)
+{
+    constexpr int BM = 64, BKO = 64, BR = 32;                 // output tile 64 x 64, reduction step 32
+    constexpr int STAGE = 2 * BM * BR + BR * BKO;             // floats: G, Z, W tiles
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int N32 = (N + 31) / 32 * 32;
+    float *tab = smem + 3 * STAGE;                             // [4][N32] coefficient table (zero beyond N)
+    float *red = tab + 4 * N32;                                // [2][2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wk = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int kt = slot % k_tiles, mt = (slot / k_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * BM;
+    const int k0 = kt * BKO;
+    for (int n = tid; n < N32; n += 256) {
+        tab[n] = n < N ? coef[FD_CF_A * N + n] : 0.0f;
+        tab[N32 + n] = n < N ? coef[FD_CF_C1 * N + n] : 0.0f;
+        tab[2 * N32 + n] = n < N ? coef[FD_CF_MU * N + n] : 0.0f;
+        tab[3 * N32 + n] = n < N ? coef[FD_CF_C2 * N + n] : 0.0f;
+    }
+    // LDS-DMA sources.  G/Z tiles: 64 rows x 8 chunks = 8 row-groups each -> waves 0..3 take 2 groups of G and 2 of Z.
+    // W tile: 32 rows (n) x 16 chunks (k): 64 lanes = 4 rows x 16 chunks -> 8 groups, 2 per wave.
+    const float *src_g[2], *src_z[2], *src_w[2];
+    int chunk_gz[2], nrow_w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave + 4 * i) * 8 + (lane >> 3);
+        chunk_gz[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 4;
+        long row = m0 + r; if (row > M - 1) row = M - 1;
+        src_g[i] = G + row * N; src_z[i] = Z + row * N;
+        nrow_w[i] = (wave + 4 * i) * 4 + (lane >> 4);          // n row within the tile
+        int kc = k0 + (lane & 15) * 4; if (kc > K - 4) kc = K - 4;
+        src_w[i] = Wt + kc;
+    }
+    auto issue = [&](int t) {
+        float *dst = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int n = t * BR + chunk_gz[i]; if (n >= N) n = 0;
+            fd_glds16(src_g[i] + n, dst + (wave + 4 * i) * 8 * BR);
+            fd_glds16(src_z[i] + n, dst + BM * BR + (wave + 4 * i) * 8 * BR);
+            int nr = t * BR + nrow_w[i]; if (nr > N - 1) nr = N - 1;
+            fd_glds16(src_w[i] + (long)nr * K, dst + 2 * BM * BR + (wave + 4 * i) * 4 * BKO);
+        }
+    };
+    fd_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int h = lane >> 5;
+    int a_off[4];
+    {
+        const int ra = wm * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) a_off[g] = ra * BR + (((2 * g + h) ^ ((ra >> 1) & 7)) << 2);
+    }
+    const int b_col = wk * 32 + (lane & 31);
+    const int T = N32 / BR;
+    __syncthreads();
+    issue(0);
+    if (T > 1) issue(1);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
+        fd_block_barrier();
+        if (t + 2 < T) issue(t + 2);
+        const float *cur = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nb = (2 * g + h) * 4;                     // this lane's 4 reduction indices within the tile
+            const fd_f32x4 a = fd_dz4(fd_ld4(cur + a_off[g]), fd_ld4(cur + BM * BR + a_off[g]), fd_ld4(tab + t * BR + nb), fd_ld4(tab + N32 + t * BR + nb),
+                                      fd_ld4(tab + 2 * N32 + t * BR + nb), fd_ld4(tab + 3 * N32 + t * BR + nb));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float b = cur[2 * BM * BR + (nb + q) * BKO + b_col];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b, acc, 0, 0, 0);
+            }
+        }
+    }
+    // epilogue
+    const int col = k0 + wk * 32 + (lane & 31);
+    const long rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    float s = 0.0f, q = 0.0f;
+    if (col < K) {
+        const float sc = st_in[FD_ST_SCALE * K + col], sh = st_in[FD_ST_SHIFT * K + col];
+        const float mu = st_in[FD_ST_MEAN * K + col], is = st_in[FD_ST_INVSTD * K + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row < M) {
+                const float z = Zin[row * K + col];
+                float v = acc[r];
+                if (ADD_SG) v += SG[row * K + col];
+                v *= fd_actmask<ACT_IN>(z * sc + sh);
+                Gin[row * K + col] = v;
+                s += v; q = fmaf(v, (z - mu) * is, q);
+            }
+        }
+    }
+    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+    if (lane < 32) { red[(wm * 2 + 0) * 64 + wk * 32 + lane] = s; red[(wm * 2 + 1) * 64 + wk * 32 + lane] = q; }
+    __syncthreads();
+    if (tid < 64 && k0 + tid < K) {
+        part[(long)mt * 2 * K + k0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
+        part[(long)mt * 2 * K + K + k0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise backward-weights GEMM:  dW[N][K] = sum_m dz[m][n] * a_in[m][k],  a_in = act_in(z_in*s+t).
+// Output tile 64 (n) x 64 (k) per workgroup; the reduction over the M pixels is split over `splits` workgroups
+// (blockIdx.y), each writing a private partial tile (summed afterwards by fd_reduce_partials_f32).
+// Both operands have the reduction index m as their ROW index, i.e. the MFMA fragments are 4-byte reads with
+// consecutive lanes on consecutive n (resp. k): conflict-free without any transposition.  The per-lane n / k is
+// fixed, so the BN-backward coefficients and the producer's scale/shift live in registers.
+// LDS per stage: G [32 m][64 n], Z [32 m][64 n], Zin [32 m][64 k]  (256-byte rows, LDS-DMA, 3-stage ring).
+// ------------------------------------------------------------------------------------------------
+template <int ACT_IN>
+__global__ void __launch_bounds__(256)
+fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
+                int M, int N, int K, int k_tiles, int rows_per_split)
+{
+    constexpr int BR = 32, BT = 64, STAGE = 3 * BR * BT;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int nt = blockIdx.x / k_tiles, kt = blockIdx.x - nt * k_tiles;
+    const int n0 = nt * BT, k0 = kt * BT;
+    const long mbeg = (long)blockIdx.y * rows_per_split;
+    long mend = mbeg + rows_per_split; if (mend > M) mend = M;
+    const int T = (int)((mend - mbeg + BR - 1) / BR);
+    // LDS-DMA: each tile is 32 rows x 16 chunks; a wave instruction covers 4 rows -> 8 groups per tile, 2 per wave
+    int colg[2], colk[2], rowi[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rowi[i] = (wave + 4 * i) * 4 + (lane >> 4);
+        int cn = n0 + (lane & 15) * 4; if (cn > N - 4) cn = N - 4;
+        int ck = k0 + (lane & 15) * 4; if (ck > K - 4) ck = K - 4;
+        colg[i] = cn; colk[i] = ck;
+    }
+    auto issue = [&](int t) {
+        float *dst = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long m = mbeg + (long)t * BR + rowi[i]; if (m > M - 1) m = M - 1;
+            fd_glds16(G + m * N + colg[i], dst + (wave + 4 * i) * 4 * BT);
+            fd_glds16(Z + m * N + colg[i], dst + BR * BT + (wave + 4 * i) * 4 * BT);
+            fd_glds16(Zin + m * K + colk[i], dst + 2 * BR * BT + (wave + 4 * i) * 4 * BT);
+        }
+    };
+    // NOTE: column clamping (cn > N-4) duplicates valid columns into the tile tail; those tail columns belong to
+    // n >= N (or k >= K) and are never stored.
+    const int n = n0 + wn * 32 + (lane & 31), k = k0 + wk * 32 + (lane & 31);
+    const bool n_ok = n < N, k_ok = k < K;
+    const float cA = n_ok ? coef[FD_CF_A * N + n] : 0.0f, c1 = n_ok ? coef[FD_CF_C1 * N + n] : 0.0f, cM = n_ok ? coef[FD_CF_MU * N + n] : 0.0f, c2 = n_ok ? coef[FD_CF_C2 * N + n] : 0.0f;
+    const float sc = k_ok ? st_in[FD_ST_SCALE * K + k] : 0.0f, sh = k_ok ? st_in[FD_ST_SHIFT * K + k] : 0.0f;
+    fd_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int hh = lane >> 5;
+    const int acol = wn * 32 + (lane & 31), bcol = wk * 32 + (lane & 31);
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
+        fd_block_barrier();
+        if (t + 2 < T) issue(t + 2);
+        const float *cur = smem + (t % 3) * STAGE;
+        const long mrow = mbeg + (long)t * BR;
+#pragma unroll
+        for (int j = 0; j < BR / 2; ++j) {
+            const int r = 2 * j + hh;                           // reduction row of this half-wave for MFMA step j
+            const bool ok = mrow + r < mend;                    // rows beyond the split contribute nothing
+            const float g = cur[r * BT + acol], z = cur[BR * BT + r * BT + acol], zi = cur[2 * BR * BT + r * BT + bcol];
+            const float a = ok ? fd_dz(g, z, cA, c1, cM, c2) : 0.0f;
+            const float b = fd_act<ACT_IN>(fmaf(zi, sc, sh));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    // partial tile: wpart[split][n][k]
+    float *o = wpart + (long)blockIdx.y * N * K;
+    const int col = k0 + wk * 32 + (lane & 31);
+    const int rb = n0 + wn * 32 + 4 * (lane >> 5);
+    if (col < K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb + (r & 3) + 8 * (r >> 2);
+            if (row < N) o[(long)row * K + col] = acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise backward-data.  din[y][x][c] = sum_{ky,kx} dz[(y+P-ky)/S][(x+P-kx)/S][c] * w[c][ky][kx]  (terms with a
+// non-integral or out-of-range output index vanish).  A workgroup owns TH x TW INPUT positions x CB channels, stages
+// the dz patch it needs (formed from G, z, coef on load) in LDS, then:
+//   MODE 0: G_in = mask_in(y_in) * (din (+ skipgrad))                              (input was a_in)
+//   MODE 1: G_in(low res) = mask_in(y_in) * sum_{2x2} din                          (input was up2(a_in))
+//   MODE 2: as MODE 1, and skipgrad_out = din at full resolution                   (input was up2(a_in) + a_skip)
+// plus the producer's BN partials  part[blk*2*C + {0,C} + c].
+// ------------------------------------------------------------------------------------------------
+template <int K, int S, int MODE, int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_dw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ w, const float *__restrict__ Zin, const float *__restrict__ st_in,
+                const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ SGout, float *__restrict__ part,
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x)
+{
+    constexpr int P = K / 2;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int oyb = (iy0 + P - (K - 1) >= 0) ? (iy0 + P - (K - 1)) / S : -((-(iy0 + P - (K - 1)) + S - 1) / S);
+    const int oxb = (ix0 + P - (K - 1) >= 0) ? (ix0 + P - (K - 1)) / S : -((-(ix0 + P - (K - 1)) + S - 1) / S);
+    const int PH = (iy0 + TH - 1 + P) / S - oyb + 1, PW = (ix0 + TW - 1 + P) / S - oxb + 1;
+    float *s_dz = smem;                                   // [PH*PW][PSTR]
+    float *s_w = smem + PH * PW * PSTR;                   // [K*K][CB]
+    const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
+    const int cg = c0 + c4 * 4;
+    const bool c_ok = cg < C;
+    for (int i = tid; i < K * K * CB; i += 256) {
+        const int t = i / CB, cc = i - t * CB;
+        s_w[t * CB + cc] = (c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
+    }
+    fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
+    if (c_ok) { cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg); }
+    const int npx = PH * PW;
+    constexpr int U = 8;
+    for (int base = pt; base < npx; base += npt * U) {
+        fd_f32x4 g[U], z[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            const int py = px / PW, pxx = px - py * PW;
+            const int oy = oyb + py, ox = oxb + pxx;
+            ok[u] = px < npx && c_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+            g[u] = fd_zero4(); z[u] = fd_zero4();
+            if (ok[u]) {
+                const long o = (((long)n * Ho + oy) * Wo + ox) * C + cg;
+                g[u] = fd_ld4(G + o); z[u] = fd_ld4(Z + o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            if (px < npx) fd_st4(s_dz + px * PSTR + c4 * 4, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : fd_zero4());
+        }
+    }
+    __syncthreads();
+
+    // producer's tables
+    fd_f32x4 sc = fd_zero4(), sh = fd_zero4(), mu = fd_zero4(), is = fd_zero4();
+    if (c_ok) { sc = fd_ld4(st_in + FD_ST_SCALE * C + cg); sh = fd_ld4(st_in + FD_ST_SHIFT * C + cg); mu = fd_ld4(st_in + FD_ST_MEAN * C + cg); is = fd_ld4(st_in + FD_ST_INVSTD * C + cg); }
+    fd_f32x4 ssum = fd_zero4(), ssx = fd_zero4();
+    auto din_at = [&](int iy, int ix) {                    // gradient w.r.t. the conv input at tile-local (iy, ix)
+        fd_f32x4 acc = fd_zero4();
+        const int gy = iy0 + iy, gx = ix0 + ix;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int ny = gy + P - ky;
+            if (S == 2 && (ny & 1)) continue;
+            const int py = (S == 2 ? (ny >> 1) : ny) - oyb;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int nx = gx + P - kx;
+                if (S == 2 && (nx & 1)) continue;
+                const int pxx = (S == 2 ? (nx >> 1) : nx) - oxb;
+                acc += fd_ld4(s_dz + (py * PW + pxx) * PSTR + c4 * 4) * fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+            }
+        }
+        return acc;
+    };
+    if (MODE == 0) {
+        for (int p = pt; p < TH * TW; p += npt) {
+            const int iy = p / TW, ix = p - iy * TW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            if (!c_ok || gy >= Hin || gx >= Win) continue;
+            fd_f32x4 v = din_at(iy, ix);
+            const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
+            if (ADD_SG) v += fd_ld4(SG + o);
+            const fd_f32x4 z = fd_ld4(Zin + o);
+            v = v * fd_actmask4<ACT_IN>(z * sc + sh);
+            fd_st4(Gin + o, v);
+            ssum += v; ssx += v * ((z - mu) * is);
+        }
+    } else {
+        const int TH2 = TH >> 1, TW2 = TW >> 1, Hs = Hin >> 1, Ws = Win >> 1;
+        for (int p = pt; p < TH2 * TW2; p += npt) {
+            const int ly = p / TW2, lx = p - ly * TW2;
+            const int gy = iy0 + 2 * ly, gx = ix0 + 2 * lx;     // top-left full-res position of the 2x2 block
+            if (!c_ok || gy >= Hin || gx >= Win) continue;
+            fd_f32x4 d00 = din_at(2 * ly, 2 * lx), d01 = din_at(2 * ly, 2 * lx + 1), d10 = din_at(2 * ly + 1, 2 * lx), d11 = din_at(2 * ly + 1, 2 * lx + 1);
+            if (MODE == 2) {
+                const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
+                fd_st4(SGout + o, d00); fd_st4(SGout + o + C, d01);
+                fd_st4(SGout + o + (long)Win * C, d10); fd_st4(SGout + o + (long)Win * C + C, d11);
+            }
+            fd_f32x4 v = (d00 + d01) + (d10 + d11);
+            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg;
+            const fd_f32x4 z = fd_ld4(Zin + ol);
+            v = v * fd_actmask4<ACT_IN>(z * sc + sh);
+            fd_st4(Gin + ol, v);
+            ssum += v; ssx += v * ((z - mu) * is);
+        }
+    }
+    __syncthreads();
+    float *red = smem;                                     // [npt][lanes_c][8]
+    fd_st4(red + (pt * lanes_c + c4) * 8, ssum);
+    fd_st4(red + (pt * lanes_c + c4) * 8 + 4, ssx);
+    __syncthreads();
+    if (tid < lanes_c) {
+        fd_f32x4 a = fd_zero4(), b = fd_zero4();
+        for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
+        const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+        if (c0 + tid * 4 < C) {
+            fd_st4(part + blk * 2 * C + c0 + tid * 4, a);
+            fd_st4(part + blk * 2 * C + C + c0 + tid * 4, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise backward-weights: dW[c][ky][kx] = sum over (n, oy, ox) of dz[oy][ox][c] * in[oy*S-P+ky][ox*S-P+kx][c].
+// Same tiling and input staging as the forward kernel (the input a_in / up2 / +skip is re-created on load); each
+// work-item accumulates the K*K tap sums of its 4 channels over its output strips, the workgroup reduces them through
+// LDS and writes wpart[blk][K*K][C].
+// ------------------------------------------------------------------------------------------------
+template <int K, int S, int MODE, int ACT1, int ACT2>
+__global__ void __launch_bounds__(256)
+fd_dw_wgrad_f32(const float *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ zskip,
+                const float *__restrict__ st2, const float *__restrict__ G, const float *__restrict__ Z,
+                const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
+                int cbq, int TH, int TW, int tiles_x)
+{
+    constexpr int P = K / 2;
+    constexpr int NIN = 3 * S + K;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
+    float *s_in = smem;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
+    const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
+    const int cg = c0 + c4 * 4;
+    const bool c_ok = cg < C;
+    fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
+    fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
+    if (c_ok) {
+        s1 = fd_ld4(st1 + FD_ST_SCALE * C + cg); t1 = fd_ld4(st1 + FD_ST_SHIFT * C + cg);
+        if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + cg); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + cg); }
+        cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg);
+    }
+    const int npx_in = TH_in * TW_in;
+    constexpr int U = 8;
+    for (int base = pt; base < npx_in; base += npt * U) {
+        fd_f32x4 v[U], sk[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            const int iy = px / TW_in, ix = px - iy * TW_in;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            v[u] = fd_zero4(); sk[u] = fd_zero4();
+            ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+            if (ok[u]) {
+                if (MODE == 0) {
+                    v[u] = fd_ld4(zin + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                } else {
+                    const int Hs = Hin >> 1, Ws = Win >> 1;
+                    v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                    if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            if (px < npx_in) {
+                fd_f32x4 a = fd_zero4();
+                if (ok[u]) {
+                    a = fd_bn_act4<ACT1>(v[u], s1, t1);
+                    if (MODE == 2) a += fd_bn_act4<ACT2>(sk[u], s2, t2);
+                }
+                fd_st4(s_in + px * PSTR + c4 * 4, a);
+            }
+        }
+    }
+    __syncthreads();
+    fd_f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = fd_zero4();
+    const int TWS = TW >> 2, nstrips = TH * TWS;
+    for (int s = pt; s < nstrips; s += npt) {
+        const int oy = s / TWS, ox = (s - oy * TWS) * 4;
+        const int gy = oy0 + oy;
+        fd_f32x4 dz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gx = ox0 + ox + j;
+            dz[j] = fd_zero4();
+            if (c_ok && gy < Ho && gx < Wo) {
+                const long o = (((long)n * Ho + gy) * Wo + gx) * C + cg;
+                dz[j] = fd_dz4(fd_ld4(G + o), fd_ld4(Z + o), cA, c1, cM, c2);
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
+            fd_f32x4 r[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ky * K + kx] += r[j * S + kx] * dz[j];
+        }
+    }
+    // workgroup reduction over the pixel-threads, one tap at a time (fixed order)
+    __syncthreads();
+    float *red = smem;                                     // [npt][lanes_c][4]
+    const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+#pragma unroll 1
+    for (int t = 0; t < K * K; ++t) {
+        fd_st4(red + (pt * lanes_c + c4) * 4, acc[t]);
+        __syncthreads();
+        if (tid < lanes_c && c0 + tid * 4 < C) {
+            fd_f32x4 a = fd_zero4();
+            for (int i = 0; i < npt; ++i) a += fd_ld4(red + (i * lanes_c + tid) * 4);
+            fd_st4(wpart + (blk * K * K + t) * C + c0 + tid * 4, a);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps; workgroup = 256 pixels.
+// wpart[blk][Cout*27].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fd_stem_wgrad_f32(const float *__restrict__ x, const float *__restrict__ G, const float *__restrict__ Z,
+                  const float *__restrict__ coef, float *__restrict__ wpart, int B, int H, int W, int Cout)
+{
+    FD_DYN_SMEM(smem_raw);
+    float *s_in = reinterpret_cast<float *>(smem_raw);     // [256][28]
+    float *s_dz = s_in + 256 * 28;                          // [256][Cout + 1]
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long npix = (long)B * Ho * Wo;
+    const int tid = threadIdx.x;
+    const long p = (long)blockIdx.x * 256 + tid;
+    const bool valid = p < npix;
+    int n = 0, oy = 0, ox = 0;
+    if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
+    for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                s_in[tid * 28 + (c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
+            }
+    for (int co = 0; co < Cout; ++co) {
+        float dz = 0.0f;
+        if (valid) dz = fd_dz(G[p * Cout + co], Z[p * Cout + co], coef[FD_CF_A * Cout + co], coef[FD_CF_C1 * Cout + co], coef[FD_CF_MU * Cout + co], coef[FD_CF_C2 * Cout + co]);
+        s_dz[tid * (Cout + 1) + co] = dz;
+    }
+    __syncthreads();
+    for (int o = tid; o < Cout * 27; o += 256) {
+        const int co = o / 27, t = o - co * 27;
+        float s = 0.0f;
+        for (int px = 0; px < 256; ++px) s = fmaf(s_dz[px * (Cout + 1) + co], s_in[px * 28 + t], s);
+        wpart[(long)blockIdx.x * Cout * 27 + o] = s;
+    }
+}

@@ -1,0 +1,409 @@
+// fd_kernels_train_f32.h -- fp32 TRAIN-mode forward kernels of the FastDepth hot path (gfx950).
+//
+// Train mode changes BatchNorm to batch statistics (reference: nn.BatchNorm2d instantiated at
+// imagenet/mobilenet.py:25,32,36 and models.py:66,73, module in .train()): the statistics of a unit's conv
+// output are only known after the whole conv has run, so BN cannot be folded into the weights.  The design:
+//   * every unit stores its RAW conv output z (this is also exactly what backward needs: the activation mask
+//     and x_hat are functions of z), and its epilogue accumulates per-channel sum(z), sum(z^2) partials;
+//   * a tiny finalize kernel turns the partials into (scale s = gamma*invstd, shift t = beta - mean*s, mean,
+//     invstd) and updates running_mean / running_var (momentum 0.1, UNBIASED variance);
+//   * the CONSUMER applies  a = act(z*s + t)  while it loads its input ("normalise on read"), so the
+//     normalised / activated tensor is never written to HBM.  Nearest-x2 upsampling and the additive skips stay
+//     fused into the consumer's read exactly as in the inference kernels (models.py:723-729).
+// Reductions are two-stage and deterministic (per-workgroup partials in a fixed layout, summed in fixed order).
+#pragma once
+#include "fd_device.h"
+
+// per-channel table written by fd_bn_finalize_f32:  [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) invstd
+#define FD_ST_SCALE 0
+#define FD_ST_SHIFT 1
+#define FD_ST_MEAN 2
+#define FD_ST_INVSTD 3
+
+template <int ACT>
+__device__ __forceinline__ fd_f32x4 fd_bn_act4(fd_f32x4 z, fd_f32x4 s, fd_f32x4 t)
+{
+    return fd_act4<ACT>(z * s + t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem, train mode: raw weights w[Cout][27] (torch layout), raw output z (NHWC) + stats partials
+// part[(blockIdx.x)*2*Cout + {0: sum, Cout: sumsq} + c].
+// ------------------------------------------------------------------------------------------------
+template <int CHUNK>
+__global__ void __launch_bounds__(256)
+fd_stem_train_f32(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ z,
+                  float *__restrict__ part, int B, int H, int W, int Cout)
+{
+    FD_DYN_SMEM(smem_raw);
+    float *tile = reinterpret_cast<float *>(smem_raw);       // [256][CHUNK + 4]
+    constexpr int TS = CHUNK + 4;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long npix = (long)B * Ho * Wo;
+    const int tid = threadIdx.x;
+    const long p = (long)blockIdx.x * 256 + tid;
+    const bool valid = p < npix;
+    int n = 0, oy = 0, ox = 0;
+    if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                in[(c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
+            }
+    for (int c0 = 0; c0 < Cout; c0 += CHUNK) {
+        float acc[CHUNK];
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) acc[j] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j) acc[j] = fmaf(in[t], w[(c0 + j) * 27 + t], acc[j]);
+#pragma unroll
+        for (int j = 0; j < CHUNK; j += 4) {
+            fd_f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+            if (!valid) v = fd_zero4();
+            fd_st4(tile + tid * TS + j, v);
+        }
+        __syncthreads();
+        constexpr int Q = CHUNK / 4;
+        for (int f = tid; f < 256 * Q; f += 256) {
+            const int px = f / Q, c4 = f - px * Q;
+            const long gp = (long)blockIdx.x * 256 + px;
+            if (gp < npix) fd_st4(z + gp * Cout + c0 + c4 * 4, fd_ld4(tile + px * TS + c4 * 4));
+        }
+        // per-channel partial statistics of this workgroup's 256 pixels (invalid pixels hold zeros): 8 work-items per
+        // channel each sum 32 pixels in a fixed order, then a 3-step shuffle
+        {
+            const int c = tid >> 3, part8 = tid & 7;
+            float s = 0.0f, q = 0.0f;
+            if (c < CHUNK) {
+                for (int i = 0; i < 32; ++i) { const float v = tile[(part8 * 32 + i) * TS + c]; s += v; q = fmaf(v, v, q); }
+            }
+            s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+            s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+            s += __shfl_xor(s, 4); q += __shfl_xor(q, 4);
+            if (c < CHUNK && part8 == 0) {
+                part[(long)blockIdx.x * 2 * Cout + c0 + c] = s;
+                part[(long)blockIdx.x * 2 * Cout + Cout + c0 + c] = q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise K x K, stride S, train mode (LDS-tiled, same geometry as fd_dwconv_f32).
+//   input  = act1(z_in * s1 + t1)                                   (MODE 0)
+//          = up2(act1(z_in * s1 + t1))                              (MODE 1)
+//          = up2(act1(z_in * s1 + t1)) + act2(z_skip * s2 + t2)     (MODE 2)
+// weights are the live parameter w[C][K*K]; output is the raw conv result + stats partials
+// part[blk*2*C + {0,C} + c] with blk = blockIdx.z * gridDim.x + blockIdx.x.
+// ------------------------------------------------------------------------------------------------
+template <int K, int S, int MODE, int ACT1, int ACT2>
+__global__ void __launch_bounds__(256)
+fd_dwconv_train_f32(const float *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ zskip,
+                    const float *__restrict__ st2, const float *__restrict__ w, float *__restrict__ zout,
+                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x)
+{
+    constexpr int P = K / 2;
+    constexpr int NIN = 3 * S + K;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
+    float *s_in = smem;                                   // [TH_in*TW_in][PSTR]; reused for the stats reduction
+    float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
+    const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
+    const int cg = c0 + c4 * 4;
+    const bool c_ok = cg < C;
+
+    for (int i = tid; i < K * K * CB; i += 256) {         // gather the taps of this channel block: w[c][tap] -> s_w[tap][c]
+        const int t = i / CB, cc = i - t * CB;
+        s_w[t * CB + cc] = (c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
+    }
+    fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
+    if (c_ok) {
+        s1 = fd_ld4(st1 + FD_ST_SCALE * C + cg); t1 = fd_ld4(st1 + FD_ST_SHIFT * C + cg);
+        if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + cg); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + cg); }
+    }
+    const int npx_in = TH_in * TW_in;
+    constexpr int U = 8;
+    for (int base = pt; base < npx_in; base += npt * U) {
+        fd_f32x4 v[U], sk[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            const int iy = px / TW_in, ix = px - iy * TW_in;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            v[u] = fd_zero4(); sk[u] = fd_zero4();
+            ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+            if (ok[u]) {
+                if (MODE == 0) {
+                    v[u] = fd_ld4(zin + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                } else {
+                    const int Hs = Hin >> 1, Ws = Win >> 1;
+                    v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                    if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            if (px < npx_in) {
+                fd_f32x4 a = fd_zero4();                   // zero padding applies to the ACTIVATED tensor
+                if (ok[u]) {
+                    a = fd_bn_act4<ACT1>(v[u], s1, t1);
+                    if (MODE == 2) a += fd_bn_act4<ACT2>(sk[u], s2, t2);
+                }
+                fd_st4(s_in + px * PSTR + c4 * 4, a);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int TWS = TW >> 2, nstrips = TH * TWS;
+    fd_f32x4 ssum = fd_zero4(), ssq = fd_zero4();
+    for (int s = pt; s < nstrips; s += npt) {
+        const int oy = s / TWS, ox = (s - oy * TWS) * 4;
+        fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
+            fd_f32x4 r[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const fd_f32x4 wv = fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += r[j * S + kx] * wv;
+            }
+        }
+        const int gy = oy0 + oy;
+        if (c_ok && gy < Ho) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = ox0 + ox + j;
+                if (gx < Wo) {
+                    fd_st4(zout + (((long)n * Ho + gy) * Wo + gx) * C + cg, acc[j]);
+                    ssum += acc[j]; ssq += acc[j] * acc[j];
+                }
+            }
+        }
+    }
+    // workgroup partial statistics: fixed-order sum over the pixel-threads that share a channel group
+    __syncthreads();
+    float *red = s_in;                                     // [npt][lanes_c][8]
+    fd_st4(red + (pt * lanes_c + c4) * 8, ssum);
+    fd_st4(red + (pt * lanes_c + c4) * 8 + 4, ssq);
+    __syncthreads();
+    if (tid < lanes_c) {
+        fd_f32x4 a = fd_zero4(), b = fd_zero4();
+        for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
+        const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+        if (c0 + tid * 4 < C) {
+            fd_st4(part + blk * 2 * C + c0 + tid * 4, a);
+            fd_st4(part + blk * 2 * C + C + c0 + tid * 4, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise GEMM, train mode:  z[M][N] = act1(zin[M][K] * s1[K] + t1[K]) * W[N][K]^T   (W = live parameter)
+// Same LDS-DMA / swizzle / 3-stage-ring structure as fd_pw_gemm_f32; the BatchNorm + activation of the PRODUCER
+// is applied to the A fragments after the ds_read (a table of scale/shift per k sits in LDS).  The table is zero
+// for k >= K, which also neutralises a ragged last K tile (the W source chunk is clamped to finite data).
+// Epilogue: raw z + per-column partial statistics part[mt*2*N + {0,N} + col].
+// ------------------------------------------------------------------------------------------------
+template <int ACT1>
+__global__ void __launch_bounds__(256)
+fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1, const float *__restrict__ Wt,
+                     float *__restrict__ out, float *__restrict__ part, int M, int N, int K, int m_tiles, int n_tiles)
+{
+    constexpr int BM = 64, BN = 64, BK = 32, ROWS = BM + BN, STAGE = ROWS * BK, RG = ROWS / 8 / 4;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);      // 3 stages, then the scale/shift table [2][K32], then [2][2][64] stats
+    const int K32 = (K + 31) / 32 * 32;
+    float *tab = smem + 3 * STAGE;
+    float *red = tab + 2 * K32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % n_tiles, mt = (slot / n_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    for (int k = tid; k < K32; k += 256) {
+        tab[k] = k < K ? st1[FD_ST_SCALE * K + k] : 0.0f;
+        tab[K32 + k] = k < K ? st1[FD_ST_SHIFT * K + k] : 0.0f;
+    }
+    const float *src[RG];
+    int src_chunk[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int r = (wave + 4 * i) * 8 + (lane >> 3);
+        src_chunk[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 4;
+        if (r < BM) { long row = m0 + r; if (row > M - 1) row = M - 1; src[i] = A + row * K; }
+        else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K; }
+    }
+    auto issue = [&](int t) {
+        float *dst = smem + (t % 3) * STAGE + wave * 8 * BK;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int k = t * BK + src_chunk[i];
+            if (k >= K) k = 0;
+            fd_glds16(src[i] + k, dst + i * 4 * 8 * BK);
+        }
+    };
+    fd_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int h = lane >> 5;
+    int a_off[4], b_off[4];
+    {
+        const int ra = wm * 32 + (lane & 31), rb = BM + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            a_off[g] = ra * BK + (((2 * g + h) ^ ((ra >> 1) & 7)) << 2);
+            b_off[g] = rb * BK + (((2 * g + h) ^ ((rb >> 1) & 7)) << 2);
+        }
+    }
+    const int T = K32 / BK;
+    __syncthreads();                                         // scale/shift table visible (before any LDS-DMA is in flight)
+    issue(0);
+    if (T > 1) issue(1);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        fd_block_barrier();
+        if (t + 2 < T) issue(t + 2);
+        const float *cur = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kb = t * BK + (2 * g + h) * 4;
+            const fd_f32x4 a = fd_bn_act4<ACT1>(fd_ld4(cur + a_off[g]), fd_ld4(tab + kb), fd_ld4(tab + K32 + kb));
+            const fd_f32x4 b = fd_ld4(cur + b_off[g]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+        }
+    }
+    // epilogue: raw z and per-column statistics over this tile's valid rows
+    const int col = n0 + wn * 32 + (lane & 31);
+    const long rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    float s = 0.0f, q = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < M && col < N) { out[row * N + col] = acc[r]; s += acc[r]; q = fmaf(acc[r], acc[r], q); }
+    }
+    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);          // the two half-waves hold different rows of the same column
+    __syncthreads();
+    if (lane < 32) { red[(wm * 2 + 0) * 64 + wn * 32 + lane] = s; red[(wm * 2 + 1) * 64 + wn * 32 + lane] = q; }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) {
+        part[(long)mt * 2 * N + n0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
+        part[(long)mt * 2 * N + N + n0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head, train mode: z_low[p] = sum_k act1(zin[p][k]*s1[k]+t1[k]) * w[k]  at the low resolution (the nearest-x2
+// upsampling commutes with the 1x1 conv; BN statistics over the replicated tensor equal the low-res ones, the
+// unbiased correction uses the full-resolution count -- SURVEY.md Appendix F).  part[blk*2 + {0,1}].
+// ------------------------------------------------------------------------------------------------
+template <int ACT1>
+__global__ void __launch_bounds__(256)
+fd_head_train_f32(const float *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w,
+                  float *__restrict__ zlow, float *__restrict__ part, long npix, int Cin)
+{
+    __shared__ float red[8];
+    const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int l8 = threadIdx.x & 7;
+    float s = 0.0f;
+    if (g < npix) {
+        for (int c = l8 * 4; c < Cin; c += 32) {
+            const fd_f32x4 a = fd_bn_act4<ACT1>(fd_ld4(zin + g * Cin + c), fd_ld4(st1 + FD_ST_SCALE * Cin + c), fd_ld4(st1 + FD_ST_SHIFT * Cin + c));
+            const fd_f32x4 q = fd_ld4(w + c);
+            s = fmaf(a.x, q.x, s); s = fmaf(a.y, q.y, s); s = fmaf(a.z, q.z, s); s = fmaf(a.w, q.w, s);
+        }
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    float v = 0.0f;
+    if (g < npix && l8 == 0) { zlow[g] = s; v = s; }
+    float sq = v * v;
+    for (int m = 8; m < 64; m <<= 1) { v += __shfl_xor(v, m); sq += __shfl_xor(sq, m); }   // lanes with l8 != 0 contribute 0
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = v; red[wave * 2 + 1] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[(long)blockIdx.x * 2] = red[0] + red[2] + red[4] + red[6];
+        part[(long)blockIdx.x * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize: partial sums -> per-channel (scale, shift, mean, invstd) + running-statistics update.
+//   mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), running_var uses var_b * n_u/(n_u-1).
+// One workgroup of 1024 (16 waves) per 64 channels: lane = channel, wave w sums partial blocks b = w, w+16, ...
+// in double, fixed order -> deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int C, double n, double n_unbiased, float eps, float momentum,
+                   const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ run_mean,
+                   float *__restrict__ run_var, float *__restrict__ st)
+{
+    __shared__ double sh[16][64][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = wave; b < nblk; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+    sh[wave][lane][0] = s; sh[wave][lane][1] = q;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        s = 0.0; q = 0.0;
+        for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double sc = (double)gamma[c] * invstd;
+        st[FD_ST_SCALE * C + c] = (float)sc;
+        st[FD_ST_SHIFT * C + c] = (float)((double)beta[c] - mean * sc);
+        st[FD_ST_MEAN * C + c] = (float)mean;
+        st[FD_ST_INVSTD * C + c] = (float)invstd;
+        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var * (n_unbiased / (n_unbiased - 1.0)));
+    }
+}
+
+// prediction of the train-mode forward: pred = act(z_low*s + t), written as 2x2 blocks (up == 1) or 1:1
+template <int ACT>
+__global__ void __launch_bounds__(256)
+fd_head_apply_f32(const float *__restrict__ zlow, const float *__restrict__ st, float *__restrict__ y, long npix, int h, int w, int up)
+{
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= npix) return;
+    const float v = fd_act<ACT>(zlow[g] * st[FD_ST_SCALE] + st[FD_ST_SHIFT]);
+    if (!up) { y[g] = v; return; }
+    const int ox = (int)(g % w);
+    const long t = g / w;
+    const int oy = (int)(t % h);
+    const long n = t / h;
+    float *o = y + ((n * 2 * h + 2 * oy) * 2 * (long)w + 2 * ox);
+    const fd_f32x2 vv = {v, v};
+    *reinterpret_cast<fd_f32x2 *>(o) = vv;
+    *reinterpret_cast<fd_f32x2 *>(o + 2 * w) = vv;
+}

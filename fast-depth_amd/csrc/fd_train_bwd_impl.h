@@ -1,0 +1,246 @@
+// fd_train_bwd_impl.h -- host side of fd_train_backward, fd_l1_loss, fd_sgd_step (included by fd_train_impl.h).
+#pragma once
+
+namespace {
+
+struct BwdCtx {
+    fd_train_plan *p;
+    const fd_layer_params *params;
+    const fd_layer_grads *grads;
+    hipStream_t s;
+};
+
+inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size_t)ph * pw * (cb + 4), (size_t)2048) + (size_t)k * k * cb) * 4; }
+
+int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
+{
+    TLayer &L = c.p->layers[i];
+    FD_LAUNCH(fd_bn_bwd_finalize_f32, dim3(ceil_div(L.d.cout, 64)), dim3(1024), 0, c.s, tws(c.p, c.p->part_off), nblk, L.d.cout, L.n_stat,
+              tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off));
+    return check_launch("fd_bn_bwd_finalize_f32");
+}
+
+template <int K, int S, int MODE, int ACT_IN, int ADD_SG>
+int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
+{
+    TLayer &L = c.p->layers[i];
+    TLayer &P = c.p->layers[L.d.src];
+    const int cb = 4 << L.cbq;
+    const int TH = 8, TW = 16;
+    const int tiles_x = ceil_div(L.in_w, TW), tiles_y = ceil_div(L.in_h, TH);
+    const int ph = (TH - 1 + K / 2) / S + (K - 1) / S + 3, pw = (TW - 1 + K / 2) / S + (K - 1) / S + 3;   // upper bound of the dz patch
+    const size_t lds = dw_bwd_lds(ph, pw, cb, K);
+    dim3 grid(tiles_x * tiles_y, ceil_div(L.d.cin, cb), c.p->B);
+    const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
+    FD_LAUNCH((fd_dw_dgrad_f32<K, S, MODE, ACT_IN, ADD_SG>), grid, dim3(256), lds, c.s, tws(c.p, L.g_off), tws(c.p, L.z_off), tws(c.p, L.coef_off),
+              c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? tws(c.p, P.sg_off) : (const float *)nullptr,
+              tws(c.p, P.g_off), Kp ? tws(c.p, Kp->sg_off) : (float *)nullptr, tws(c.p, c.p->part_off),
+              L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x);
+    *nblk_out = tiles_x * tiles_y * c.p->B;
+    return check_launch("fd_dw_dgrad_f32");
+}
+
+template <int ACT_IN, int ADD_SG>
+int dispatch_dw_dgrad(BwdCtx &c, int i, int *nblk)
+{
+    const TLayer &L = c.p->layers[i];
+    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
+    switch (key) {
+    case 310: return launch_dw_dgrad<3, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
+    case 320: return launch_dw_dgrad<3, 2, 0, ACT_IN, ADD_SG>(c, i, nblk);
+    case 510: return launch_dw_dgrad<5, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
+    case 511: return launch_dw_dgrad<5, 1, 1, ACT_IN, ADD_SG>(c, i, nblk);
+    case 512: return launch_dw_dgrad<5, 1, 2, ACT_IN, ADD_SG>(c, i, nblk);
+    }
+    return fail(FD_ERR_INVALID, "train: depthwise backward k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
+}
+
+template <int ACT1, int ACT2>
+int launch_dw_wgrad_acts(BwdCtx &c, int i)
+{
+    TLayer &L = c.p->layers[i];
+    TLayer &P = c.p->layers[L.d.src];
+    const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
+    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
+    float *wpart = tws(c.p, c.p->wpart_off);
+#define FD_DWW(K_, S_, M_)                                                                                                         \
+    case K_ * 100 + S_ * 10 + M_:                                                                                                  \
+        FD_LAUNCH((fd_dw_wgrad_f32<K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, c.s, tws(c.p, P.z_off), tws(c.p, P.st_off),  \
+                  Kp ? tws(c.p, Kp->z_off) : (const float *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
+                  tws(c.p, L.g_off), tws(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
+                  L.cbq, L.th, L.tw, L.tiles_x);                                                                                   \
+        break;
+    switch (key) {
+        FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2)
+    default: return fail(FD_ERR_INVALID, "train: depthwise wgrad has no kernel for this layer");
+    }
+#undef FD_DWW
+    int rc = check_launch("fd_dw_wgrad_f32");
+    if (rc) return rc;
+    const int kk = L.d.ksize * L.d.ksize;
+    FD_LAUNCH(fd_reduce_partials_tapmajor_f32, dim3(ceil_div((long)kk * L.d.cin, 64)), dim3(1024), 0, c.s, wpart, L.nblk, kk, L.d.cin, c.grads[i].conv_weight);
+    return check_launch("fd_reduce_partials_tapmajor_f32");
+}
+
+int launch_dw_wgrad(BwdCtx &c, int i)
+{
+    const TLayer &L = c.p->layers[i];
+    const int a1 = c.p->layers[L.d.src].d.act, a2 = L.d.skip >= 0 ? c.p->layers[L.d.skip].d.act : FD_ACT_RELU6;
+    if (a1 == FD_ACT_RELU6 && a2 == FD_ACT_RELU6) return launch_dw_wgrad_acts<FD_ACT_RELU6_, FD_ACT_RELU6_>(c, i);
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6) return launch_dw_wgrad_acts<FD_ACT_RELU_, FD_ACT_RELU6_>(c, i);
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU) return launch_dw_wgrad_acts<FD_ACT_RELU_, FD_ACT_RELU_>(c, i);
+    return launch_dw_wgrad_acts<FD_ACT_RELU6_, FD_ACT_RELU_>(c, i);
+}
+
+template <int ACT_IN>
+int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
+{
+    TLayer &L = c.p->layers[i];
+    TLayer &P = c.p->layers[L.d.src];
+    const int M = (int)L.M, N = L.d.cout, K = L.d.cin;
+    const float *G = tws(c.p, L.g_off), *Z = tws(c.p, L.z_off), *coef = tws(c.p, L.coef_off);
+    // --- weights: dW[N][K], reduction over M split across workgroups
+    {
+        const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
+        int splits = std::max(1, std::min(ceil_div(2048, (long)n_tiles * k_tiles), ceil_div(M, 256)));
+        int rows = ceil_div(ceil_div(M, splits), 32) * 32;
+        splits = ceil_div(M, rows);
+        const size_t need = (size_t)splits * N * K * 4;
+        if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
+        const size_t lds = (size_t)3 * 3 * 32 * 64 * 4;
+        (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds, c.s, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
+                  tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
+        int rc = check_launch("fd_pw_wgrad_f32");
+        if (rc) return rc;
+        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div((long)N * K, 64)), dim3(1024), 0, c.s, tws(c.p, c.p->wpart_off), splits, (long)N * K, N * K, c.grads[i].conv_weight);
+        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+    }
+    // --- data: G_src[M][K]
+    {
+        const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
+        const int N32 = (N + 31) / 32 * 32;
+        const size_t lds = ((size_t)3 * (2 * 64 * 32 + 32 * 64) + 4 * N32 + 256) * 4;
+        const bool add = P.skip_consumer >= 0;
+        dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * k_tiles));
+        if (add) {
+            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 1>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, m_tiles, k_tiles);
+        } else {
+            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 0>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
+                      (const float *)nullptr, tws(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, m_tiles, k_tiles);
+        }
+        *nblk = m_tiles;
+        return check_launch("fd_pw_dgrad_f32");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fd_train_backward(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
+                      const void *dy, void *stream)
+{
+    return fd_train_backward_range(plan, params, grads, n_layers, dy, n_layers - 1, 0, stream);
+}
+
+int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
+                            const void *dy, int32_t from_layer, int32_t to_layer, void *stream)
+{
+    if (!plan || !params || !grads || !dy) return fail(FD_ERR_INVALID, "null argument");
+    if (!plan->ws || !plan->forward_done) return fail(FD_ERR_STATE, "fd_train_backward needs a preceding fd_train_forward on this plan");
+    if (n_layers != (int)plan->layers.size()) return fail(FD_ERR_INVALID, "expected %zu layers", plan->layers.size());
+    if (from_layer < to_layer || from_layer >= n_layers || to_layer < 0) return fail(FD_ERR_INVALID, "bad layer range %d..%d", from_layer, to_layer);
+    for (int i = 0; i < n_layers; ++i)
+        if (!grads[i].conv_weight || !grads[i].bn_weight || !grads[i].bn_bias) return fail(FD_ERR_INVALID, "layer %d: null gradient pointer", i);
+    BwdCtx c{plan, params, grads, static_cast<hipStream_t>(stream)};
+    hipStream_t s = c.s;
+    float *part = tws(plan, plan->part_off), *wpart = tws(plan, plan->wpart_off);
+    int rc;
+    // ---- head
+    const int hi = n_layers - 1;
+    TLayer &Hd = plan->layers[hi];
+    TLayer &Hp = plan->layers[Hd.d.src];
+    if (from_layer == hi) {
+        const int nb = ceil_div(Hd.M, 256);
+        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        if ((rc = check_launch("fd_head_bwd_reduce_f32"))) return rc;
+        if ((rc = bn_bwd_finalize(c, hi, nb))) return rc;
+        constexpr int PPB = 16;
+        const int nb2 = ceil_div(Hd.M, 32 * PPB);
+        const size_t lds = (size_t)32 * Hd.d.cin * 3 * 4;
+        if ((size_t)nb2 * Hd.d.cin * 4 > plan->wpart_bytes) return fail(FD_ERR_STATE, "wpart too small for the head");
+        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_f32<FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), tws(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, tws(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
+        else FD_LAUNCH((fd_head_bwd_f32<FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), tws(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, tws(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
+        if ((rc = check_launch("fd_head_bwd_f32"))) return rc;
+        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(Hd.d.cin, 64)), dim3(1024), 0, s, wpart, nb2, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight);
+        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+        // the BN partials of the head's producer are now in `part` (nb2 workgroups)
+        if ((rc = bn_bwd_finalize(c, Hd.d.src, nb2))) return rc;
+    }
+    // ---- remaining units in reverse order; invariant: coef_i and the BN grads of unit i are final when unit i is processed
+    for (int i = std::min(hi - 1, (int)from_layer); i >= to_layer; --i) {
+        TLayer &L = plan->layers[i];
+        const fd_layer_desc &d = L.d;
+        int nblk = 0;
+        switch (d.op) {
+        case FD_OP_STEM:
+            FD_LAUNCH(fd_stem_wgrad_f32, L.grid, dim3(256), (size_t)(256 * 28 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), tws(plan, L.g_off), tws(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout);
+            if ((rc = check_launch("fd_stem_wgrad_f32"))) return rc;
+            FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, wpart, L.nblk, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
+            if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+            break;
+        case FD_OP_DW: {
+            if ((rc = launch_dw_wgrad(c, i))) return rc;
+            const TLayer &P = plan->layers[d.src];
+            const bool add = P.skip_consumer >= 0 && L.mode == 0;
+            if (P.d.act == FD_ACT_RELU6) rc = add ? dispatch_dw_dgrad<FD_ACT_RELU6_, 1>(c, i, &nblk) : dispatch_dw_dgrad<FD_ACT_RELU6_, 0>(c, i, &nblk);
+            else rc = add ? dispatch_dw_dgrad<FD_ACT_RELU_, 1>(c, i, &nblk) : dispatch_dw_dgrad<FD_ACT_RELU_, 0>(c, i, &nblk);
+            if (rc) return rc;
+            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+            break;
+        }
+        case FD_OP_PW: {
+            const TLayer &P = plan->layers[d.src];
+            rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd<FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd<FD_ACT_RELU_>(c, i, &nblk);
+            if (rc) return rc;
+            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+            break;
+        }
+        }
+    }
+    return FD_OK;
+}
+
+size_t fd_l1_loss_scratch_bytes(int64_t numel) { (void)numel; return 1024 * sizeof(float); }
+
+int fd_l1_loss(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream)
+{
+    if (!pred || !target || !dpred || !loss_out || !scratch || numel <= 0) return fail(FD_ERR_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::min<int64_t>(1024, (numel + 255) / 256);
+    const float inv = 1.0f / (float)numel;
+    FD_LAUNCH(fd_l1_loss_f32, dim3(nb), dim3(256), 0, s, static_cast<const float *>(pred), static_cast<const float *>(target), static_cast<float *>(dpred),
+              static_cast<float *>(scratch), (long)numel, inv);
+    int rc = check_launch("fd_l1_loss_f32");
+    if (rc) return rc;
+    FD_LAUNCH(fd_l1_loss_final_f32, dim3(1), dim3(64), 0, s, static_cast<const float *>(scratch), nb, inv, loss_out);
+    return check_launch("fd_l1_loss_final_f32");
+}
+
+int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t total_numel, float lr, float momentum, float weight_decay,
+                float grad_scale, int32_t first_step, void *stream)
+{
+    if (!table_device || n_tensors <= 0) return fail(FD_ERR_INVALID, "null/empty tensor table");
+    static_assert(sizeof(fd_sgd_tensor) == sizeof(fd_sgd_rec), "table record layout");
+    (void)total_numel;
+    FD_LAUNCH(fd_sgd_f32, dim3(64, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const fd_sgd_rec *>(table_device), n_tensors,
+              lr, momentum, weight_decay, grad_scale, first_step);
+    return check_launch("fd_sgd_f32");
+}
+
+}  // extern "C"

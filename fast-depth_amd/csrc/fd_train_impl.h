@@ -1,0 +1,309 @@
+// fd_train_impl.h -- train-step plan (train-mode forward, backward, loss, SGD); included at the end of
+// fd_api.hip so that it shares that translation unit's helpers (fail(), FD_LAUNCH, ceil_div, ...).
+//
+// Workspace layout of a train plan:
+//   [z_i]   raw conv output of every unit, NHWC fp32, all kept (they are the saved tensors of backward)
+//   [st_i]  per-unit BatchNorm table [4][C]: scale, shift, mean, invstd (fd_bn_finalize_f32)
+//   [part]  one shared buffer for per-workgroup reduction partials (consumed right after each producer)
+//   backward only: [g_a, g_b] ping-pong dLoss/d(BN output) buffers, [skipgrad_k] decoder->skip gradient buffers,
+//   [coef_i] per-unit BN-backward coefficient tables, [wpart] weight-gradient partials.
+#pragma once
+#include "fd_kernels_train_f32.h"
+#include "fd_kernels_bwd_f32.h"
+
+namespace {
+
+struct TLayer {
+    fd_layer_desc d;
+    int in_h = 0, in_w = 0, out_h = 0, out_w = 0;   // in_* = logical (post-upsample) input size; head: out_* = LOW-res size when upsample
+    bool head = false;
+    int mode = 0;
+    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling
+    int chunk = 0;                                            // stem
+    int m_tiles = 0, n_tiles = 0;                             // pw
+    size_t lds = 0;
+    dim3 grid;
+    int nblk = 0;                    // reduction partials this unit's forward kernel writes
+    size_t z_off = 0, z_elems = 0;   // raw output
+    size_t st_off = 0;               // [4][C] table
+    size_t coef_off = 0;             // backward coefficient table [4][C]
+    double n_stat = 0, n_unbiased = 0;
+    long M = 0;                      // pixels of the stored output (B*out_h*out_w)
+    // backward bookkeeping
+    int consumer = -1;               // unit that reads this output as `src`
+    int skip_consumer = -1;          // decoder unit that reads this output as `skip` (-1: none)
+    size_t g_off = 0;                // dLoss/dy buffer of this unit
+    size_t sg_off = 0;               // decoder->skip gradient buffer (only for skip sources)
+};
+
+}  // namespace
+
+struct fd_train_plan {
+    std::vector<TLayer> layers;
+    int B = 0, H = 0, W = 0;
+    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0;
+    unsigned char *ws = nullptr;
+    bool forward_done = false;
+    float eps = 1e-5f;
+    const void *x_saved = nullptr;   // the network input of the last forward (the stem's weight gradient re-reads it)
+};
+
+namespace {
+
+inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
+
+template <int ACT1, int ACT2>
+int launch_dw_train(const TLayer &L, const float *zin, const float *st1, const float *zskip, const float *st2, const float *w,
+                    float *zout, float *part, hipStream_t s)
+{
+    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
+#define FD_DWT(K_, S_, M_)                                                                                                   \
+    case K_ * 100 + S_ * 10 + M_:                                                                                            \
+        FD_LAUNCH((fd_dwconv_train_f32<K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
+                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);                                  \
+        break;
+    switch (key) {
+        FD_DWT(3, 1, 0) FD_DWT(3, 2, 0) FD_DWT(5, 1, 0) FD_DWT(5, 1, 1) FD_DWT(5, 1, 2)
+    default: return fail(FD_ERR_INVALID, "train: depthwise k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
+    }
+#undef FD_DWT
+    return check_launch("fd_dwconv_train_f32");
+}
+
+// activation of the producer(s) decides the template instance: encoder = ReLU6, decoder = ReLU (both appear as act1; act2 is
+// the skip tensor's activation, always an encoder unit)
+int dispatch_dw_train(const TLayer &L, int act1, int act2, const float *zin, const float *st1, const float *zskip, const float *st2,
+                      const float *w, float *zout, float *part, hipStream_t s)
+{
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    return fail(FD_ERR_INVALID, "train: unsupported producer activations %d/%d", act1, act2);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
+                         int32_t dtype, uint32_t flags, fd_train_plan **out_plan)
+{
+    if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
+    if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
+        return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
+    if (dtype != FD_F32) return fail(FD_ERR_INVALID, "train plan: dtype %d not supported by this build (fp32 only)", dtype);
+    fd_train_plan *p = new fd_train_plan();
+    p->B = batch; p->H = height; p->W = width;
+    p->layers.resize(n_layers);
+    size_t off = 0, max_part = 0, max_wpart = 0, max_g = 0;
+#define FD_BAD(...) do { int rc_ = fail(FD_ERR_INVALID, __VA_ARGS__); delete p; return rc_; } while (0)
+    for (int i = 0; i < n_layers; ++i) {
+        TLayer &L = p->layers[i];
+        L.d = layers[i];
+        const fd_layer_desc &d = L.d;
+        if (d.src >= i || d.skip >= i) FD_BAD("layer %d: src/skip must reference earlier layers", i);
+        if (d.act != FD_ACT_RELU && d.act != FD_ACT_RELU6) FD_BAD("layer %d: train mode needs ReLU or ReLU6", i);
+        int src_h, src_w, src_c;
+        if (d.src < 0) { src_h = height; src_w = width; src_c = 3; }
+        else { const TLayer &S = p->layers[d.src]; src_h = S.out_h; src_w = S.out_w; src_c = S.d.cout; }
+        if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
+        L.in_h = d.upsample ? 2 * src_h : src_h;
+        L.in_w = d.upsample ? 2 * src_w : src_w;
+        if (d.src >= 0) { if (p->layers[d.src].consumer >= 0) FD_BAD("layer %d: producer %d already has a consumer", i, d.src); p->layers[d.src].consumer = i; }
+        if (d.skip >= 0) {
+            const TLayer &S = p->layers[d.skip];
+            if (!d.upsample || S.out_h != L.in_h || S.out_w != L.in_w || S.d.cout != d.cin) FD_BAD("layer %d: bad skip", i);
+            if (p->layers[d.skip].skip_consumer >= 0) FD_BAD("layer %d: skip source %d used twice", i, d.skip);
+            p->layers[d.skip].skip_consumer = i;
+        }
+        switch (d.op) {
+        case FD_OP_STEM:
+            if (d.src != -1 || d.cin != 3 || d.ksize != 3 || d.stride != 2 || d.upsample || d.skip >= 0 || d.cout % 8) FD_BAD("layer %d: bad stem", i);
+            L.out_h = L.in_h / 2; L.out_w = L.in_w / 2;
+            L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
+            L.lds = 256 * (L.chunk + 4) * 4;
+            L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
+            L.nblk = (int)L.grid.x;
+            max_wpart = std::max(max_wpart, (size_t)L.nblk * 27 * d.cout);
+            break;
+        case FD_OP_DW: {
+            if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);
+            L.mode = d.upsample ? (d.skip >= 0 ? 2 : 1) : 0;
+            L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
+            const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
+            L.cbq = ilog2(cb / 4);
+            L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : 16);
+            L.th = std::min(L.out_h, 8);
+            L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
+            const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
+            L.lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
+            L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
+            L.nblk = L.tiles_x * L.tiles_y * batch;
+            max_wpart = std::max(max_wpart, (size_t)L.nblk * d.ksize * d.ksize * d.cin);
+            break;
+        }
+        case FD_OP_PW:
+            if (d.src < 0 || d.ksize != 1 || d.stride != 1 || d.cin % 4) FD_BAD("layer %d: bad pointwise", i);
+            if (d.cout == 1) {
+                if (d.skip >= 0) FD_BAD("layer %d: head with skip", i);
+                L.head = true;
+                L.out_h = d.upsample ? L.in_h / 2 : L.in_h;      // stored at the LOW resolution
+                L.out_w = d.upsample ? L.in_w / 2 : L.in_w;
+                L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w * 8, 256));
+                L.nblk = (int)L.grid.x;
+                max_wpart = std::max(max_wpart, (size_t)L.nblk * d.cin);
+            } else {
+                if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample only as the 1-channel head", i);
+                L.out_h = L.in_h; L.out_w = L.in_w;
+                const long M = (long)batch * L.out_h * L.out_w;
+                L.m_tiles = ceil_div(M, 64); L.n_tiles = ceil_div(d.cout, 64);
+                L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
+                L.lds = (3 * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
+                L.nblk = L.m_tiles;
+                {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
+                    const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
+                    int splits = std::max(1, std::min(ceil_div(2048, (long)nt * kt), ceil_div(M, 256)));
+                    const int rows = ceil_div(ceil_div(M, splits), 32) * 32;
+                    splits = ceil_div(M, rows);
+                    max_wpart = std::max(max_wpart, (size_t)splits * d.cout * d.cin);
+                }
+            }
+            break;
+        default: FD_BAD("layer %d: unknown op", i);
+        }
+        if (L.lds > 64 * 1024) FD_BAD("layer %d: LDS request %zu exceeds 64 KiB", i, L.lds);
+        L.M = (long)batch * L.out_h * L.out_w;
+        L.z_elems = (size_t)L.M * d.cout;
+        L.n_stat = (double)L.M;
+        L.n_unbiased = (L.head && d.upsample) ? 4.0 * (double)L.M : (double)L.M;
+        L.z_off = off; off += align_up(L.z_elems * 4, 256);
+        L.st_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
+        L.coef_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
+        max_part = std::max(max_part, (size_t)L.nblk * 2 * d.cout);
+        max_g = std::max(max_g, L.z_elems);
+    }
+    TLayer &last = p->layers.back();
+    if (!last.head || (last.d.upsample ? 2 * last.out_h : last.out_h) != height) FD_BAD("the last layer must be the 1-channel head producing [B,1,%d,%d]", height, width);
+#undef FD_BAD
+    // backward buffers: the gradient of unit i is consumed by unit i's own backward kernels right after unit i+1's, so two
+    // ping-pong buffers suffice; skip sources get a private buffer for the decoder's contribution
+    size_t g0 = off; off += align_up(max_g * 4, 256);
+    size_t g1 = off; off += align_up(max_g * 4, 256);
+    for (int i = 0; i < n_layers; ++i) {
+        TLayer &L = p->layers[i];
+        L.g_off = (i & 1) ? g1 : g0;
+        if (flags & FD_PLAN_KEEP_ACTIVATIONS) { L.g_off = off; off += align_up(L.z_elems * 4, 256); }   // private gradient buffers (layer-wise tests)
+        if (L.skip_consumer >= 0) { L.sg_off = off; off += align_up(L.z_elems * 4, 256); }
+    }
+    // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
+    p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
+    p->wpart_off = off; p->wpart_bytes = align_up(std::max(max_wpart, (size_t)1) * 4, 256); off += p->wpart_bytes;
+    p->ws_bytes = off;
+    *out_plan = p;
+    return FD_OK;
+}
+
+void fd_train_plan_destroy(fd_train_plan *plan) { delete plan; }
+size_t fd_train_plan_workspace_bytes(const fd_train_plan *plan) { return plan ? plan->ws_bytes : 0; }
+
+int fd_train_plan_bind_workspace(fd_train_plan *plan, void *device_ptr, size_t bytes)
+{
+    if (!plan || !device_ptr) return fail(FD_ERR_INVALID, "null plan/workspace");
+    if (bytes < plan->ws_bytes) return fail(FD_ERR_INVALID, "workspace too small: %zu < %zu", bytes, plan->ws_bytes);
+    if (reinterpret_cast<uintptr_t>(device_ptr) % 256) return fail(FD_ERR_INVALID, "workspace must be 256-byte aligned");
+    plan->ws = static_cast<unsigned char *>(device_ptr);
+    plan->forward_done = false;
+    return FD_OK;
+}
+
+int fd_train_forward(fd_train_plan *plan, const fd_layer_params *params, int32_t n_layers, float bn_eps, float bn_momentum,
+                     const void *x_nchw, void *y, void *stream)
+{
+    if (!plan || !params || !x_nchw || !y) return fail(FD_ERR_INVALID, "null argument");
+    if (!plan->ws) return fail(FD_ERR_STATE, "bind a workspace first");
+    if (n_layers != (int)plan->layers.size()) return fail(FD_ERR_INVALID, "expected %zu layer parameter sets", plan->layers.size());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float *x = static_cast<const float *>(x_nchw);
+    float *part = tws(plan, plan->part_off);
+    plan->eps = bn_eps;
+    plan->x_saved = x_nchw;
+    for (int i = 0; i < n_layers; ++i) {
+        const TLayer &L = plan->layers[i];
+        const fd_layer_desc &d = L.d;
+        const fd_layer_params &q = params[i];
+        if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
+        float *z = tws(plan, L.z_off);
+        const TLayer *P = d.src >= 0 ? &plan->layers[d.src] : nullptr;
+        const float *zin = P ? tws(plan, P->z_off) : nullptr;
+        const float *st1 = P ? tws(plan, P->st_off) : nullptr;
+        int rc = FD_OK;
+        switch (d.op) {
+        case FD_OP_STEM:
+            switch (L.chunk) {
+            case 32: FD_LAUNCH((fd_stem_train_f32<32>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
+            case 16: FD_LAUNCH((fd_stem_train_f32<16>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
+            default: FD_LAUNCH((fd_stem_train_f32<8>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
+            }
+            rc = check_launch("fd_stem_train_f32");
+            break;
+        case FD_OP_DW: {
+            const TLayer *K = d.skip >= 0 ? &plan->layers[d.skip] : nullptr;
+            rc = dispatch_dw_train(L, P->d.act, K ? K->d.act : FD_ACT_RELU6, zin, st1, K ? tws(plan, K->z_off) : nullptr,
+                                   K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s);
+            break;
+        }
+        case FD_OP_PW:
+            if (L.head) {
+                const long npix = L.M;
+                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, z, part, npix, d.cin);
+                else FD_LAUNCH((fd_head_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, z, part, npix, d.cin);
+                rc = check_launch("fd_head_train_f32");
+            } else {
+                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                rc = check_launch("fd_pw_gemm_train_f32");
+            }
+            break;
+        }
+        if (rc) return rc;
+        FD_LAUNCH(fd_bn_finalize_f32, dim3(ceil_div(d.cout, 64)), dim3(1024), 0, s, part, L.nblk, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
+                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off));
+        if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
+    }
+    const TLayer &Hd = plan->layers.back();
+    if (Hd.d.act == FD_ACT_RELU6)
+        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU6_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+    else
+        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+    int rc = check_launch("fd_head_apply_f32");
+    if (rc) return rc;
+    plan->forward_done = true;
+    return FD_OK;
+}
+
+int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n, int32_t *h,
+                          int32_t *w, int32_t *c)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size() || which < 0 || which > 2) return fail(FD_ERR_INVALID, "bad layer index / selector");
+    if (!plan->ws) return fail(FD_ERR_STATE, "no workspace bound");
+    const TLayer &L = plan->layers[layer];
+    if (which == 2) {   // the BatchNorm table [4][C]: scale, shift, mean, invstd
+        if (device_ptr) *device_ptr = plan->ws + L.st_off;
+        if (n) *n = 1;
+        if (h) *h = 4;
+        if (w) *w = 1;
+        if (c) *c = L.d.cout;
+        return FD_OK;
+    }
+    if (device_ptr) *device_ptr = plan->ws + (which == 0 ? L.z_off : L.g_off);
+    if (n) *n = plan->B;
+    if (h) *h = L.out_h;
+    if (w) *w = L.out_w;
+    if (c) *c = L.d.cout;
+    return FD_OK;
+}
+
+}  // extern "C"
+
+#include "fd_train_bwd_impl.h"

@@ -20,6 +20,14 @@ class LayerParams(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias", "bn_mean", "bn_var")]
 
 
+class LayerGrads(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias")]
+
+
+class SgdTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("momentum_buf", ctypes.c_void_p), ("numel", ctypes.c_int64)]
+
+
 class FastDepthError(RuntimeError):
     pass
 
@@ -60,6 +68,30 @@ def load(path=None):
     lib.fd_plan_algorithmic_flops.restype = ctypes.c_double
     lib.fd_plan_layer_stats.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.fd_plan_layer_stats.restype = ctypes.c_int
+    if hasattr(lib, "fd_train_plan_create"):
+        lib.fd_train_plan_create.argtypes = [ctypes.POINTER(LayerDesc), i32, i32, i32, i32, i32, u32, ctypes.POINTER(vp)]
+        lib.fd_train_plan_create.restype = ctypes.c_int
+        lib.fd_train_plan_destroy.argtypes = [vp]
+        lib.fd_train_plan_destroy.restype = None
+        lib.fd_train_plan_workspace_bytes.argtypes = [vp]
+        lib.fd_train_plan_workspace_bytes.restype = ctypes.c_size_t
+        lib.fd_train_plan_bind_workspace.argtypes = [vp, vp, ctypes.c_size_t]
+        lib.fd_train_plan_bind_workspace.restype = ctypes.c_int
+        lib.fd_train_forward.argtypes = [vp, ctypes.POINTER(LayerParams), i32, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+        lib.fd_train_forward.restype = ctypes.c_int
+        lib.fd_train_layer_tensor.argtypes = [vp, i32, i32, ctypes.POINTER(vp)] + [ctypes.POINTER(i32)] * 4
+        lib.fd_train_layer_tensor.restype = ctypes.c_int
+    if hasattr(lib, "fd_train_backward"):
+        lib.fd_train_backward.argtypes = [vp, ctypes.POINTER(LayerParams), ctypes.POINTER(LayerGrads), i32, vp, vp]
+        lib.fd_train_backward.restype = ctypes.c_int
+        lib.fd_train_backward_range.argtypes = [vp, ctypes.POINTER(LayerParams), ctypes.POINTER(LayerGrads), i32, vp, i32, i32, vp]
+        lib.fd_train_backward_range.restype = ctypes.c_int
+        lib.fd_l1_loss_scratch_bytes.argtypes = [ctypes.c_int64]
+        lib.fd_l1_loss_scratch_bytes.restype = ctypes.c_size_t
+        lib.fd_l1_loss.argtypes = [vp, vp, vp, vp, ctypes.c_int64, vp, vp]
+        lib.fd_l1_loss.restype = ctypes.c_int
+        lib.fd_sgd_step.argtypes = [vp, i32, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i32, vp]
+        lib.fd_sgd_step.restype = ctypes.c_int
     lib.fd_last_error.restype = ctypes.c_char_p
     lib.fd_version.restype = ctypes.c_char_p
     return lib
@@ -67,7 +99,10 @@ def load(path=None):
 
 EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_plan_bind_workspace",
            "fd_plan_pack_weights", "fd_forward", "fd_forward_timed", "fd_layer_output", "fd_plan_num_kernels", "fd_plan_kernel_info", "fd_plan_kernel_symbol",
-           "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats", "fd_last_error", "fd_version")
+           "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats",
+           "fd_train_plan_create", "fd_train_plan_destroy", "fd_train_plan_workspace_bytes", "fd_train_plan_bind_workspace",
+           "fd_train_forward", "fd_train_backward", "fd_train_backward_range", "fd_train_layer_tensor", "fd_l1_loss_scratch_bytes",
+           "fd_l1_loss", "fd_sgd_step", "fd_last_error", "fd_version")
 
 
 def check(lib, rc, what):

@@ -92,8 +92,14 @@ class Engine:
 
     def forward(self, x):
         if self.model.training:
-            raise capi.FastDepthError("train-mode forward (batch-statistics BatchNorm + backward) is not built yet in "
-                                      "this round; call model.eval() for inference")
+            # train mode: batch-statistics BatchNorm + hand-written backward behind a torch.autograd.Function
+            from .train import TrainCore, autograd_forward
+            core = self.__dict__.get("_train_core")
+            if core is None:
+                core = self._train_core = TrainCore(self.model)
+            if torch.is_grad_enabled():
+                return autograd_forward(core, x)
+            return core.forward(x)
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
             raise capi.FastDepthError("expected a float32 [B,3,H,W] tensor, got %s %s" % (tuple(x.shape), x.dtype))
         x = x.contiguous()

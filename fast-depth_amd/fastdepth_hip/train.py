@@ -1,0 +1,237 @@
+"""Train step on the HIP engine: train-mode forward (batch-statistics BatchNorm), hand-written backward, fused mean-L1
+loss, fused multi-tensor SGD and data-parallel gradient all-reduce (RCCL via torch.distributed, one process per GPU).
+
+The train step is NOT in the reference tree (README.md:65 names the upstream it was cut from); SURVEY.md section 3(4)
+defines it as: module in .train() -> torch.nn.L1Loss()(pred, target) -> backward -> mean of per-replica gradients ->
+torch.optim.SGD(lr, momentum, weight_decay).  BatchNorm statistics stay per replica (nn.DataParallel / DDP default
+semantics, the only multi-GPU idiom the reference ever used: imagenet/mobilenet.py:68).
+
+Two ways in:
+  * drop-in: `model.train(); loss = nn.L1Loss()(model(x), target); loss.backward(); optimizer.step()` -- the module's
+    forward routes through `TrainFunction`, a torch.autograd.Function whose forward/backward are the C-ABI calls;
+  * fused: `TrainEngine(model, lr, ...).step(x, target)` -- forward, fd_l1_loss, bucketed backward overlapped with the
+    all-reduce of finished buckets on a side stream, fd_sgd_step; no torch kernels on the path.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .engine import lib
+from .plan import layers_of
+
+
+class _TrainPlan:
+    def __init__(self, layers, batch, height, width, device):
+        L = lib()
+        n = len(layers)
+        descs = (capi.LayerDesc * n)(*[l.desc for l in layers])
+        handle = ctypes.c_void_p()
+        capi.check(L, L.fd_train_plan_create(descs, n, batch, height, width, capi.FD_F32, 0, ctypes.byref(handle)), "fd_train_plan_create")
+        self.handle = handle
+        nbytes = L.fd_train_plan_workspace_bytes(handle)
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        base = (self.workspace.data_ptr() + 255) // 256 * 256
+        capi.check(L, L.fd_train_plan_bind_workspace(handle, base, nbytes), "fd_train_plan_bind_workspace")
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                lib().fd_train_plan_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+def _check_param(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise capi.FastDepthError("%s must be a contiguous float32 tensor on the GPU" % what)
+
+
+class TrainCore:
+    """Shared plumbing: parameter tables, flat gradient buffer (reverse layer order, so that finished buckets are
+    contiguous slices), train plans per input shape."""
+
+    def __init__(self, model):
+        self.model = model
+        self.layers = layers_of(model)
+        self.n = len(self.layers)
+        dev = self.layers[0].conv.weight.device
+        self.device = dev
+        # flat gradient buffer: layer n-1 first ... layer 0 last (the order in which backward completes them)
+        self.param_list = []                      # (layer index, kind, parameter) in flat order
+        for i in reversed(range(self.n)):
+            l = self.layers[i]
+            for kind, p in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias)):
+                _check_param(p, "%s.%s" % (l.name, kind))
+                self.param_list.append((i, kind, p))
+        self.total = sum(p.numel() for _, _, p in self.param_list)
+        self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad_views, self.layer_span = {}, {}
+        off = 0
+        for i, kind, p in self.param_list:
+            self.grad_views[(i, kind)] = self.flat_grad[off:off + p.numel()].view_as(p)
+            lo, hi = self.layer_span.get(i, (off, off))
+            self.layer_span[i] = (min(lo, off), off + p.numel())
+            off += p.numel()
+        self.c_grads = (capi.LayerGrads * self.n)()
+        for i in range(self.n):
+            for kind in ("conv_weight", "bn_weight", "bn_bias"):
+                setattr(self.c_grads[i], kind, self.grad_views[(i, kind)].data_ptr())
+        self.plans = {}
+        self.eps = self.layers[0].bn.eps
+        self.bn_momentum = self.layers[0].bn.momentum
+        if any(l.bn.eps != self.eps or l.bn.momentum != self.bn_momentum for l in self.layers):
+            raise capi.FastDepthError("mixed BatchNorm eps/momentum values are not supported")
+        self._nbt = [l.bn.num_batches_tracked for l in self.layers if l.bn.num_batches_tracked is not None]
+
+    def c_params(self):
+        params = (capi.LayerParams * self.n)()
+        for q, l in zip(params, self.layers):
+            for name, t in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias),
+                            ("bn_mean", l.bn.running_mean), ("bn_var", l.bn.running_var)):
+                _check_param(t, "%s.%s" % (l.name, name))
+                setattr(q, name, t.data_ptr())
+        return params
+
+    def plan_for(self, x):
+        b, c, h, w = x.shape
+        key = (b, h, w, x.device.index)
+        p = self.plans.get(key)
+        if p is None:
+            p = self.plans[key] = _TrainPlan(self.layers, b, h, w, x.device)
+        return p
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
+            raise capi.FastDepthError("expected a float32 [B,3,H,W] GPU tensor, got %s %s on %s" % (tuple(x.shape), x.dtype, x.device))
+        L = lib()
+        x = x.contiguous()
+        plan = self.plan_for(x)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        y = torch.empty((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        self._params = self.c_params()
+        self._x = x                                # the stem's weight gradient re-reads the input in backward
+        with torch.cuda.device(x.device):
+            capi.check(L, L.fd_train_forward(plan.handle, self._params, self.n, self.eps, self.bn_momentum, x.data_ptr(), y.data_ptr(), stream), "fd_train_forward")
+            if self._nbt:
+                torch._foreach_add_(self._nbt, 1)
+        self._plan = plan
+        return y
+
+    def backward_range(self, dy, from_layer, to_layer):
+        L = lib()
+        stream = torch.cuda.current_stream(dy.device).cuda_stream
+        with torch.cuda.device(dy.device):
+            capi.check(L, L.fd_train_backward_range(self._plan.handle, self._params, self.c_grads, self.n, dy.data_ptr(), from_layer, to_layer, stream),
+                       "fd_train_backward_range")
+
+    def backward(self, dy):
+        self.backward_range(dy.contiguous(), self.n - 1, 0)
+
+
+class TrainFunction(torch.autograd.Function):
+    """pred = TrainFunction.apply(core, x, *parameters): autograd entry point of the drop-in module in .train() mode."""
+
+    @staticmethod
+    def forward(ctx, core, x, *params):
+        if x.requires_grad:
+            raise capi.FastDepthError("gradients with respect to the input image are not part of this path")
+        ctx.core = core
+        return core.forward(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        core = ctx.core
+        core.backward(dy.contiguous())
+        grads = []
+        for l in core.layers:
+            i = core.layers.index(l)
+            grads += [core.grad_views[(i, "conv_weight")].clone(), core.grad_views[(i, "bn_weight")].clone(), core.grad_views[(i, "bn_bias")].clone()]
+        return (None, None, *grads)
+
+
+def autograd_forward(core, x):
+    params = []
+    for l in core.layers:
+        params += [l.conv.weight, l.bn.weight, l.bn.bias]
+    return TrainFunction.apply(core, x, *params)
+
+
+def make_buckets(layer_bytes, n_buckets):
+    """Splits layers n-1..0 (backward order) into <= n_buckets contiguous ranges of roughly equal bytes.
+    Returns [(from_layer, to_layer)] with from >= to."""
+    n = len(layer_bytes)
+    total = float(sum(layer_bytes))
+    buckets, start, acc = [], n - 1, 0.0
+    for i in range(n - 1, -1, -1):
+        acc += layer_bytes[i]
+        remaining = n_buckets - len(buckets) - 1
+        if (acc >= total / n_buckets and remaining > 0 and i > 0) or i == 0:
+            buckets.append((start, i))
+            start, acc = i - 1, 0.0
+    return buckets
+
+
+class TrainEngine(TrainCore):
+    """Fused train step with SGD(momentum, weight decay) and optional data parallelism.
+
+    process_group: a torch.distributed process group (backend "nccl" == RCCL on ROCm) or None.  With a group of size n the
+    step is: local forward/backward on this rank's sub-batch; the flat gradient buffer is all-reduced (sum) bucket by bucket
+    on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
+
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4):
+        super().__init__(model)
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.group = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.dist = dist
+            self.world = dist.get_world_size(process_group)
+        self.flat_mom = torch.zeros_like(self.flat_grad)
+        self.steps = 0
+        # SGD table on the device: (param ptr, grad ptr, momentum ptr, numel) per tensor
+        rec, off = [], 0
+        for i, kind, p in self.param_list:
+            rec += [p.data_ptr(), self.flat_grad.data_ptr() + 4 * off, self.flat_mom.data_ptr() + 4 * off, p.numel()]
+            off += p.numel()
+        self.sgd_table = torch.tensor(rec, dtype=torch.int64).to(self.device)
+        self.layer_bytes = [4 * (self.layer_span[i][1] - self.layer_span[i][0]) for i in range(self.n)]
+        self.buckets = make_buckets(self.layer_bytes, n_buckets if self.world > 1 else 1)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._dpred = None
+        self._scratch = torch.empty(lib().fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
+
+    def bucket_slice(self, from_layer, to_layer):
+        return self.flat_grad[self.layer_span[from_layer][0]:self.layer_span[to_layer][1]]
+
+    def step(self, x, target):
+        """One train step on this rank's (x, target); returns the local mean-L1 loss as a 1-element GPU tensor."""
+        L = lib()
+        pred = self.forward(x)
+        target = target.contiguous()
+        if self._dpred is None or self._dpred.shape != pred.shape:
+            self._dpred = torch.empty_like(pred)
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            capi.check(L, L.fd_l1_loss(pred.data_ptr(), target.data_ptr(), self._dpred.data_ptr(), self.loss.data_ptr(), pred.numel(),
+                                       self._scratch.data_ptr(), cur.cuda_stream), "fd_l1_loss")
+            works = []
+            for from_layer, to_layer in self.buckets:
+                self.backward_range(self._dpred, from_layer, to_layer)
+                if self.world > 1:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    self.comm_stream.wait_event(ev)
+                    with torch.cuda.stream(self.comm_stream):
+                        works.append(self.dist.all_reduce(self.bucket_slice(from_layer, to_layer), group=self.group, async_op=True))
+            if self.world > 1:
+                for w in works:
+                    w.wait()                       # makes the current stream wait for the collective (no host sync)
+                cur.wait_stream(self.comm_stream)
+            capi.check(L, L.fd_sgd_step(self.sgd_table.data_ptr(), len(self.param_list), self.total, self.lr, self.momentum, self.weight_decay,
+                                        1.0 / self.world, int(self.steps == 0), cur.cuda_stream), "fd_sgd_step")
+        self.steps += 1
+        return self.loss

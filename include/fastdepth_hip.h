@@ -124,6 +124,59 @@ double fd_plan_algorithmic_flops(const fd_plan *plan);
 /* The same two figures for one layer's kernel launch. */
 int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_bytes, double *algorithmic_flops);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Train step (NOT in the reference tree -- README.md:65 names the upstream it was stripped from; defined in
+ * SURVEY.md section 3(4) as: module in .train() -> L1 loss -> backward -> SGD(momentum, weight decay), data-parallel
+ * gradient mean).  BatchNorm uses batch statistics (biased variance to normalise, unbiased into running_var,
+ * momentum applied in place to the caller's running_mean / running_var tensors).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct fd_train_plan fd_train_plan;
+
+/* device pointers to the gradient tensors of one layer (fp32, same layouts as the parameters) */
+typedef struct fd_layer_grads {
+    float *conv_weight;
+    float *bn_weight;
+    float *bn_bias;
+} fd_layer_grads;
+
+int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
+                         int32_t dtype, uint32_t flags, fd_train_plan **out_plan);
+void fd_train_plan_destroy(fd_train_plan *plan);
+size_t fd_train_plan_workspace_bytes(const fd_train_plan *plan);
+int fd_train_plan_bind_workspace(fd_train_plan *plan, void *device_ptr, size_t bytes);
+
+/* Train-mode forward: reads the LIVE parameters (no folding), saves every unit's raw conv output and batch
+ * statistics in the workspace for fd_train_backward, updates running_mean/var in place, writes y [B,1,H,W]. */
+int fd_train_forward(fd_train_plan *plan, const fd_layer_params *params, int32_t n_layers, float bn_eps,
+                     float bn_momentum, const void *x_nchw, void *y, void *stream);
+
+/* Backward of the last fd_train_forward: dy = dLoss/dy [B,1,H,W] fp32; writes (overwrites) every parameter gradient.
+ * The network input x passed to fd_train_forward must still be valid (the stem's weight gradient re-reads it). */
+int fd_train_backward(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
+                      const void *dy, void *stream);
+
+/* Same, restricted to the units from_layer >= i >= to_layer (from_layer must continue where the previous call stopped;
+ * the first call starts at n_layers-1).  Lets the host interleave gradient all-reduce buckets with the backward pass. */
+int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
+                            const void *dy, int32_t from_layer, int32_t to_layer, void *stream);
+
+/* Test hook: raw conv output z (which == 0) or dLoss/d(BN output) (which == 1) of a layer, NHWC fp32; which == 2: the
+ * layer's BatchNorm table as n=1, h=4 (scale, shift, mean, invstd), w=1, c=C. */
+int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n,
+                          int32_t *h, int32_t *w, int32_t *c);
+
+/* Mean-L1 loss, forward + backward in one pass (torch.nn.L1Loss()): loss_out[0] = mean|pred - target| (device
+ * float), dpred = sign(pred - target) / numel.  `scratch` needs fd_l1_loss_scratch_bytes(numel) bytes. */
+size_t fd_l1_loss_scratch_bytes(int64_t numel);
+int fd_l1_loss(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream);
+
+/* Fused multi-tensor SGD (torch.optim.SGD semantics: d = grad_scale*g + wd*p; buf = mom*buf + d (buf = d on the first
+ * step); p -= lr*buf) over n tensors in ONE launch.  `table` is a device array of n fd_sgd_tensor records; grad_scale
+ * is 1/world_size after a summing all-reduce (data-parallel mean), 1 otherwise. */
+typedef struct fd_sgd_tensor { float *param; const float *grad; float *momentum_buf; int64_t numel; } fd_sgd_tensor;
+int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t total_numel, float lr, float momentum,
+                float weight_decay, float grad_scale, int32_t first_step, void *stream);
+
 const char *fd_last_error(void);
 const char *fd_version(void);
 

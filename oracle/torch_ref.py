@@ -30,28 +30,38 @@ def params_from_state(state_dict, dtype=torch.float32, requires_grad=False):
     return p
 
 
-def _unit(p, x, cp, bp, kind, stride, act, train):
+def _unit(p, x, cp, bp, kind, stride, act, train, bn_taps=None, mask=None):
     w = p[cp + ".weight"]
     k = w.shape[2]
     x = F.conv2d(x, w, None, stride, k // 2, 1, w.shape[0] if kind == "dw" else 1)
     x = F.batch_norm(x, p[bp + ".running_mean"], p[bp + ".running_var"], p[bp + ".weight"], p[bp + ".bias"],
                      train, BN_MOMENTUM, BN_EPS)
+    if bn_taps is not None:          # BN outputs y_i (pre-activation); their .grad is dLoss/dy_i after backward
+        if x.requires_grad:
+            x.retain_grad()
+        bn_taps.append(x)
+    if mask is not None:
+        # activation with an externally supplied pass-through mask (tests: makes the backward comparison independent of
+        # which side of 0 / 6 a pre-activation of magnitude ~1e-7 was rounded to)
+        lo, hi = mask
+        off = torch.where(hi, torch.zeros_like(x), torch.full_like(x, 6.0)) if act == ACT_RELU6 else torch.zeros_like(x)
+        return torch.where(lo & hi, x, off)
     return F.hardtanh(x, 0.0, 6.0) if act == ACT_RELU6 else F.relu(x)
 
 
-def forward(p, x, train=False, taps=None):
+def forward(p, x, train=False, taps=None, bn_taps=None, masks=None):
     """p: dict from params_from_state (running stats are updated in place when train=True)."""
     names = unit_names()
     skips = {}
     for i in range(27):                                   # models.py:710-719
-        x = _unit(p, x, *names[i], train)
+        x = _unit(p, x, *names[i], train, bn_taps, None if masks is None else masks[i])
         if taps is not None:
             taps.append(x)
         if i in (2, 6, 10):
             skips[i] = x
     for j in range(1, 6):                                 # models.py:720-729
         for i in (25 + 2 * j, 26 + 2 * j):
-            x = _unit(p, x, *names[i], train)
+            x = _unit(p, x, *names[i], train, bn_taps, None if masks is None else masks[i])
             if taps is not None:
                 taps.append(x)
         x = F.interpolate(x, scale_factor=2, mode="nearest")
@@ -61,18 +71,18 @@ def forward(p, x, train=False, taps=None):
             x = x + skips[6]
         elif j == 2:
             x = x + skips[10]
-    x = _unit(p, x, *names[37], train)                    # models.py:731
+    x = _unit(p, x, *names[37], train, bn_taps, None if masks is None else masks[37])   # models.py:731
     if taps is not None:
         taps.append(x)
     return x
 
 
-def l1_train_grads(p, x, target):
+def l1_train_grads(p, x, target, bn_taps=None):
     """One train-mode forward + mean-L1 loss + backward.  Returns (loss, {key: grad})."""
     for v in p.values():
         if v.requires_grad and v.grad is not None:
             v.grad = None
-    pred = forward(p, x, train=True)
+    pred = forward(p, x, train=True, bn_taps=bn_taps)
     loss = (pred - target).abs().mean()                   # torch.nn.L1Loss()
     loss.backward()
     return loss.detach(), {k: v.grad.detach().clone() for k, v in p.items() if v.requires_grad}

@@ -110,3 +110,134 @@ def compare_with_oracle(kind, model, x, device):
     info = plan.info()
     plan.close()
     return rel_err(y, y_ref), errs, info
+
+
+class CTrainPlan:
+    """fd_train_plan + workspace; parameters are private fp32 copies on the plan's device (running stats get updated in place)."""
+
+    def __init__(self, kind, model, x, keep=False):
+        self.lib = L = get_lib(kind)
+        self.dev = x.device
+        self.layers = layers_of(model)
+        n = self.n = len(self.layers)
+        descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
+        self.h = ctypes.c_void_p()
+        b, _, hh, ww = x.shape
+        capi.check(L, L.fd_train_plan_create(descs, n, b, hh, ww, capi.FD_F32, capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0, ctypes.byref(self.h)), "fd_train_plan_create")
+        nbytes = L.fd_train_plan_workspace_bytes(self.h)
+        self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.dev)
+        base = (self.ws.data_ptr() + 255) // 256 * 256
+        capi.check(L, L.fd_train_plan_bind_workspace(self.h, base, nbytes), "fd_train_plan_bind_workspace")
+        self.stream = torch.cuda.current_stream().cuda_stream if x.is_cuda else None
+        self.params = (capi.LayerParams * n)()
+        self.tensors = []          # per layer: dict name -> tensor
+        for q, l in zip(self.params, self.layers):
+            d = {}
+            for name, t in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias),
+                            ("bn_mean", l.bn.running_mean), ("bn_var", l.bn.running_var)):
+                d[name] = t.detach().to(self.dev, torch.float32).contiguous().clone()
+                setattr(q, name, d[name].data_ptr())
+            self.tensors.append(d)
+        self.eps, self.momentum = self.layers[0].bn.eps, self.layers[0].bn.momentum
+
+    def forward(self, x):
+        x = x.contiguous()
+        self._x = x                 # fd_train_backward re-reads the network input (stem weight gradient): keep it alive
+        y = torch.full((x.shape[0], 1, x.shape[2], x.shape[3]), float("nan"), dtype=torch.float32, device=self.dev)
+        capi.check(self.lib, self.lib.fd_train_forward(self.h, self.params, self.n, self.eps, self.momentum, x.data_ptr(), y.data_ptr(), self.stream), "fd_train_forward")
+        if x.is_cuda:
+            torch.cuda.synchronize()
+        return y
+
+    def backward(self, dy):
+        self.grads = (capi.LayerGrads * self.n)()
+        self.grad_tensors = []
+        for g, d in zip(self.grads, self.tensors):
+            gd = {k: torch.full_like(d[k], float("nan")) for k in ("conv_weight", "bn_weight", "bn_bias")}
+            for k, t in gd.items():
+                setattr(g, k, t.data_ptr())
+            self.grad_tensors.append(gd)
+        dy = dy.to(self.dev).contiguous()
+        capi.check(self.lib, self.lib.fd_train_backward(self.h, self.params, self.grads, self.n, dy.data_ptr(), self.stream), "fd_train_backward")
+        if dy.is_cuda:
+            torch.cuda.synchronize()
+        return self.grad_tensors
+
+    def tensor(self, i, which=0):
+        ptr = ctypes.c_void_p()
+        d = [ctypes.c_int32() for _ in range(4)]
+        capi.check(self.lib, self.lib.fd_train_layer_tensor(self.h, i, which, ctypes.byref(ptr), *[ctypes.byref(v) for v in d]), "fd_train_layer_tensor")
+        n, h, w, c = [v.value for v in d]
+        off = ptr.value - self.ws.data_ptr()
+        return self.ws[off:off + n * h * w * c * 4].view(torch.float32).view(n, h, w, c).permute(0, 3, 1, 2).contiguous().cpu()
+
+    def close(self):
+        if self.h:
+            self.lib.fd_train_plan_destroy(self.h)
+            self.h = None
+
+
+def train_parity_report(kind, model, x, target, device):
+    """Train-mode forward + backward through the C ABI vs the torch-functional oracle in fp64.
+
+    ReLU/ReLU6 are discontinuous in their derivative: a pre-activation of magnitude ~1e-7 lands on either side of 0
+    (or 6) depending on fp32 rounding order, and through BatchNorm's per-channel sums one flipped element perturbs every
+    gradient upstream.  The check is therefore two-part and rigorous:
+      (1) forward: prediction, running statistics and every unit's pre-activation y_i agree with the fp64 oracle; the
+          pass-through masks may differ only where |y_i| is within 1e-4 (relative to the layer's scale) of the kink;
+      (2) backward: the fp64 oracle is re-run with OUR masks and the SAME dLoss/dpred, which makes the map smooth; all
+          114 gradient tensors must then agree to `tol` (relative L2, with an absolute floor tied to the global norm).
+    """
+    from oracle import oracle, torch_ref
+    model = model.train()
+    names = oracle.unit_names()
+    p64 = torch_ref.params_from_state(model.state_dict(), torch.float64)
+    bn64 = []
+    with torch.no_grad():
+        pred64 = torch_ref.forward(p64, x.double(), train=True, bn_taps=bn64)
+    tp = CTrainPlan(kind, model, x.to(device), keep=True)
+    y = tp.forward(x.to(device)).cpu()
+    rep = {"pred_err": rel_err(y.numpy(), pred64.numpy()), "tensors": {}, "running": 0.0, "y_err": 0.0, "mask_flips": 0, "bad_flips": 0}
+    masks = []
+    for i, (cp, bp, _, _, act) in enumerate(names):
+        z = tp.tensor(i, 0).double()
+        st = tp.tensor(i, 2).double()[0, :, :, 0].t()          # memory is [4][C]; tensor() hands it back as (1, C, 4, 1)
+        yo = z * st[0].view(1, -1, 1, 1) + st[1].view(1, -1, 1, 1)
+        yr = bn64[i]
+        if i == 37 and yr.shape[-1] == 2 * yo.shape[-1]:
+            yr = yr[:, :, ::2, ::2]
+        scale = float(yr.abs().max())
+        rep["y_err"] = max(rep["y_err"], float((yo - yr).abs().max()) / scale)
+        lo, hi = yo > 0, (yo < 6) if act == oracle.ACT_RELU6 else torch.ones_like(yo, dtype=torch.bool)
+        lo_r, hi_r = yr > 0, (yr < 6) if act == oracle.ACT_RELU6 else torch.ones_like(yr, dtype=torch.bool)
+        flips = (lo != lo_r) | (hi != hi_r)
+        rep["mask_flips"] += int(flips.sum())
+        dist = torch.minimum(yr.abs(), (yr - 6).abs()) if act == oracle.ACT_RELU6 else yr.abs()
+        rep["bad_flips"] += int((flips & (dist > 1e-4 * scale)).sum())
+        if i == 37 and bn64[i].shape[-1] == 2 * yo.shape[-1]:
+            lo, hi = lo.repeat_interleave(2, 2).repeat_interleave(2, 3), hi.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        masks.append((lo, hi))
+    # backward with identical masks and identical dLoss/dpred
+    p64g = torch_ref.params_from_state(model.state_dict(), torch.float64, requires_grad=True)
+    predm = torch_ref.forward(p64g, x.double(), train=True, masks=masks)
+    dpred = torch.sign(predm.detach() - target.double()) / predm.numel()
+    predm.backward(dpred)
+    g64 = {k: v.grad.detach() for k, v in p64g.items() if v.requires_grad}
+    grads = tp.backward(dpred.float())
+    for i, (cp, bp, _, _, _) in enumerate(names):
+        for ours, key in ((grads[i]["conv_weight"], cp + ".weight"), (grads[i]["bn_weight"], bp + ".weight"), (grads[i]["bn_bias"], bp + ".bias")):
+            ref = g64[key]
+            rep["tensors"][key] = (float((ours.cpu().double() - ref).norm()), float(ref.norm()))
+        for ours, key in ((tp.tensors[i]["bn_mean"], bp + ".running_mean"), (tp.tensors[i]["bn_var"], bp + ".running_var")):
+            rep["running"] = max(rep["running"], rel_err(ours.cpu().numpy(), p64[key].numpy()))
+    rep["global_norm"] = float(torch.sqrt(sum((v ** 2).sum() for v in g64.values())))
+    tp.close()
+    return rep
+
+
+def assert_train_parity(rep, tol=1e-3):
+    assert rep["pred_err"] < tol and rep["y_err"] < tol and rep["running"] < tol, (rep["pred_err"], rep["y_err"], rep["running"])
+    assert rep["bad_flips"] == 0, "activation masks differ away from the kink: %d of %d flips" % (rep["bad_flips"], rep["mask_flips"])
+    floor = 1e-5 * rep["global_norm"]
+    bad = {k: v for k, v in rep["tensors"].items() if not v[0] <= max(tol * v[1], floor)}
+    assert not bad, "gradient tensors out of tolerance (abs err, norm): %s" % bad

@@ -47,6 +47,7 @@ typedef void *hipEvent_t;
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
+#define __shared__ static   /* one workgroup runs at a time, its fibers share the static */
 
 namespace hipemu {
 

@@ -1,0 +1,98 @@
+"""Train step on a real MI355X: train-mode forward/backward parity (mask-consistent fp64 oracle), the drop-in autograd path,
+the fused TrainEngine step vs the oracle's SGD step, L1 loss / SGD kernels."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import harness
+from oracle import inputs, oracle, torch_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed=3, pruned=False):
+    models = inputs.product_models()
+    torch.manual_seed(seed)
+    m = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None)
+    m.decode_conv6[1].bias.data.fill_(2.8)          # depth-like output range
+    return m
+
+
+def _batch(n, seed=0):
+    x0, d0 = inputs.load_sample()
+    x = inputs.batch_variants(x0, n, seed)
+    g = torch.Generator().manual_seed(seed)
+    tgt = torch.stack([torch.roll(d0[0], (int(torch.randint(-8, 9, (1,), generator=g)), 0), (1, 2)) for _ in range(n)])
+    return x, tgt
+
+
+@pytest.mark.parametrize("pruned", [False, True])
+def test_train_forward_backward_parity_full_size(pruned):
+    m = _model(pruned=pruned)
+    x, tgt = _batch(4)
+    rep = harness.train_parity_report("hip", m, x, tgt, torch.device("cuda"))
+    harness.assert_train_parity(rep, tol=2e-3)
+
+
+def _update_err(after_a, after_b, before, keys):
+    num = den = 0.0
+    for k in keys:
+        da, db = after_a[k].double().cpu() - before[k].double(), after_b[k].double().cpu() - before[k].double()
+        num += float(((da - db) ** 2).sum()); den += float((db ** 2).sum())
+    return (num / den) ** 0.5
+
+
+def test_dropin_autograd_path_fused_engine_and_oracle_sgd():
+    """Optimizer plumbing.  NB the gradient of this randomly initialised train-mode network is chaotic: the ORACLE's own fp64
+    gradient moves by 1.3 % / 20 % / 52 % under relative parameter perturbations of 1e-7 / 1e-5 / 1e-4 (measured, round 1), so
+    multi-step trajectories of two correct implementations diverge; gradient parity proper is the mask-consistent test above.
+    Checked here: step 1 of (a) drop-in autograd + torch.optim.SGD, (b) fused TrainEngine and (c) the oracle agree; the fused
+    momentum / weight-decay arithmetic is exact with respect to its own gradients over two steps."""
+    from fastdepth_hip.train import TrainEngine
+    x, tgt = _batch(4, seed=1)
+    base = _model(seed=5)
+    s0 = {k: v.clone() for k, v in base.state_dict().items()}
+    keys = [k for k, v in base.named_parameters()]
+    ma = copy.deepcopy(base).cuda().train()
+    opt = torch.optim.SGD(ma.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    mb = copy.deepcopy(base).cuda().train()
+    eng = TrainEngine(mb, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    p = torch_ref.params_from_state(base.state_dict(), torch.float32, requires_grad=True)
+    # ---- step 1
+    opt.zero_grad()
+    la = torch.nn.L1Loss()(ma(x.cuda()), tgt.cuda()); la.backward(); opt.step()
+    w0 = mb.conv7[3].weight.detach().clone()
+    lb = float(eng.step(x.cuda(), tgt.cuda()))
+    g0 = eng.grad_views[(14, "conv_weight")].clone()                 # layer 14 = conv7.3
+    lc, grads = torch_ref.l1_train_grads(p, x, tgt)
+    torch_ref.sgd_step(p, grads, {}, 0.01, 0.9, 1e-4)
+    assert float(la) == pytest.approx(lb, rel=1e-6) and lb == pytest.approx(float(lc), rel=1e-4)
+    sa, sb = ma.state_dict(), mb.state_dict()
+    assert _update_err(sa, sb, s0, keys) < 1e-4                      # same gradients, torch SGD vs fused SGD
+    assert _update_err(sb, {k: v.detach() for k, v in p.items()}, s0, keys) < 0.05     # vs the oracle (fp32 rounding noise ~2 %)
+    for k in sa:
+        if "running" in k:
+            assert torch.allclose(sa[k], sb[k], rtol=1e-5, atol=1e-7) and harness.rel_err(sb[k].cpu().numpy(), p[k].numpy()) < 1e-4, k
+    # ---- step 2 (fused): exact momentum / weight decay w.r.t. its own gradients
+    w1 = mb.conv7[3].weight.detach().clone()
+    assert float((w1 - w0 + 0.01 * (g0 + 1e-4 * w0)).norm() / (w1 - w0).norm()) < 1e-3      # fp32 cancellation in w1 - w0
+    eng.step(x.cuda(), tgt.cuda())
+    g1 = eng.grad_views[(14, "conv_weight")].clone()
+    w2 = mb.conv7[3].weight.detach()
+    expect = 0.01 * (0.9 * (g0 + 1e-4 * w0) + (g1 + 1e-4 * w1))
+    assert float((w2 - w1 + expect).norm() / expect.norm()) < 1e-3
+    assert int(mb.state_dict()["conv0.1.num_batches_tracked"]) == 2 and int(sa["decode_conv6.1.num_batches_tracked"]) == 1
+
+
+def test_eval_after_training_uses_updated_running_stats():
+    m = _model(seed=7).cuda().train()
+    x, _ = _batch(2, seed=2)
+    with torch.no_grad():
+        m(x.cuda())                                                      # train-mode forward updates running stats
+    m.eval()
+    with torch.no_grad():
+        y = m(x.cuda())
+    yo = oracle.forward(m.state_dict(), x.numpy())
+    assert harness.rel_err(y.cpu().numpy(), yo) < 1e-3
