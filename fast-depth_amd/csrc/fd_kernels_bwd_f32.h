@@ -672,20 +672,28 @@ fd_dw_wgrad_f32(const float *__restrict__ zin, const float *__restrict__ st1, co
                 for (int j = 0; j < 4; ++j) acc[ky * K + kx] += r[j * S + kx] * dz[j];
         }
     }
-    // workgroup reduction over the pixel-threads, one tap at a time (fixed order)
+    // workgroup reduction over the pixel-threads (fixed order): lanes of a wave that share a channel group are combined with
+    // xor-shuffles (lane = c4 + lanes_c * pixel-thread), the waves' results meet in LDS
     __syncthreads();
-    float *red = smem;                                     // [npt][lanes_c][4]
-    const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
-#pragma unroll 1
+    float *red = smem;                                     // [K*K][4 waves][lanes_c] float4
+    const int wave = tid >> 6;
+#pragma unroll
     for (int t = 0; t < K * K; ++t) {
-        fd_st4(red + (pt * lanes_c + c4) * 4, acc[t]);
-        __syncthreads();
-        if (tid < lanes_c && c0 + tid * 4 < C) {
-            fd_f32x4 a = fd_zero4();
-            for (int i = 0; i < npt; ++i) a += fd_ld4(red + (i * lanes_c + tid) * 4);
-            fd_st4(wpart + (blk * K * K + t) * C + c0 + tid * 4, a);
+        fd_f32x4 v = acc[t];
+        for (int m = lanes_c; m < 64; m <<= 1) {
+            v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
         }
-        __syncthreads();
+        if ((tid & 63) < lanes_c) fd_st4(red + ((t * 4 + wave) * lanes_c + c4) * 4, v);
+    }
+    __syncthreads();
+    const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+    for (int i = tid; i < K * K * lanes_c; i += 256) {
+        const int t = i >> cbq, cc = i & (lanes_c - 1);
+        if (c0 + cc * 4 < C) {
+            const fd_f32x4 a = (fd_ld4(red + ((t * 4 + 0) * lanes_c + cc) * 4) + fd_ld4(red + ((t * 4 + 1) * lanes_c + cc) * 4)) +
+                               (fd_ld4(red + ((t * 4 + 2) * lanes_c + cc) * 4) + fd_ld4(red + ((t * 4 + 3) * lanes_c + cc) * 4));
+            fd_st4(wpart + (blk * K * K + t) * C + c0 + cc * 4, a);
+        }
     }
 }
 

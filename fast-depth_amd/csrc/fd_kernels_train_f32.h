@@ -354,6 +354,38 @@ fd_head_train_f32(const float *__restrict__ zin, const float *__restrict__ st1, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage A of the two-level deterministic reductions: slice y of the partial rows is summed into one row.
+//   out[y*width + j] = sum_{b in slice y} part[b*width + j]        slice y = rows [y*rows_per_slice, (y+1)*rows_per_slice)
+// 16 waves per workgroup split the rows of the slice, 4 independent loads in flight per lane; the partial buffers of
+// the large layers (up to 6272 workgroups) are cut into <= 64 slices, so that every finalize kernel sees <= 64 rows.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+fd_slice_sum_f32(const float *__restrict__ part, int nrows, int rows_per_slice, int width, float *__restrict__ out)
+{
+    __shared__ float sh[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_slice;
+    int r1 = r0 + rows_per_slice; if (r1 > nrows) r1 = nrows;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (j < width) {
+        int b = r0 + wave;
+        for (; b + 48 < r1; b += 64) {
+            a0 += part[(long)b * width + j]; a1 += part[(long)(b + 16) * width + j];
+            a2 += part[(long)(b + 32) * width + j]; a3 += part[(long)(b + 48) * width + j];
+        }
+        for (; b < r1; b += 16) a0 += part[(long)b * width + j];
+    }
+    sh[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && j < width) {
+        float s = 0.0f;
+        for (int w = 0; w < 16; ++w) s += sh[w][lane];
+        out[(long)blockIdx.y * width + j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // BatchNorm finalize: partial sums -> per-channel (scale, shift, mean, invstd) + running-statistics update.
 //   mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), running_var uses var_b * n_u/(n_u-1).
 // One workgroup of 1024 (16 waves) per 64 channels: lane = channel, wave w sums partial blocks b = w, w+16, ...

@@ -15,7 +15,10 @@ inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
     TLayer &L = c.p->layers[i];
-    FD_LAUNCH(fd_bn_bwd_finalize_f32, dim3(ceil_div(L.d.cout, 64)), dim3(1024), 0, c.s, tws(c.p, c.p->part_off), nblk, L.d.cout, L.n_stat,
+    int rows = 0, rc = FD_OK;
+    const float *pr = slice_rows(c.p, tws(c.p, c.p->part_off), nblk, 2 * L.d.cout, c.s, &rows, &rc);
+    if (rc) return rc;
+    FD_LAUNCH(fd_bn_bwd_finalize_f32, dim3(ceil_div(L.d.cout, 64)), dim3(1024), 0, c.s, pr, rows, L.d.cout, L.n_stat,
               tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off));
     return check_launch("fd_bn_bwd_finalize_f32");
 }
@@ -78,7 +81,10 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     int rc = check_launch("fd_dw_wgrad_f32");
     if (rc) return rc;
     const int kk = L.d.ksize * L.d.ksize;
-    FD_LAUNCH(fd_reduce_partials_tapmajor_f32, dim3(ceil_div((long)kk * L.d.cin, 64)), dim3(1024), 0, c.s, wpart, L.nblk, kk, L.d.cin, c.grads[i].conv_weight);
+    int rows = 0;
+    const float *pr = slice_rows(c.p, wpart, L.nblk, kk * L.d.cin, c.s, &rows, &rc);
+    if (rc) return rc;
+    FD_LAUNCH(fd_reduce_partials_tapmajor_f32, dim3(ceil_div((long)kk * L.d.cin, 64)), dim3(1024), 0, c.s, pr, rows, kk, L.d.cin, c.grads[i].conv_weight);
     return check_launch("fd_reduce_partials_tapmajor_f32");
 }
 
@@ -113,7 +119,10 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         int rc = check_launch("fd_pw_wgrad_f32");
         if (rc) return rc;
-        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div((long)N * K, 64)), dim3(1024), 0, c.s, tws(c.p, c.p->wpart_off), splits, (long)N * K, N * K, c.grads[i].conv_weight);
+        int srows = 0;
+        const float *pr = slice_rows(c.p, tws(c.p, c.p->wpart_off), splits, N * K, c.s, &srows, &rc);
+        if (rc) return rc;
+        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div((long)N * K, 64)), dim3(1024), 0, c.s, pr, srows, (long)N * K, N * K, c.grads[i].conv_weight);
         if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
     }
     // --- data: G_src[M][K]
@@ -177,7 +186,12 @@ int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, 
         if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_f32<FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), tws(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, tws(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
         else FD_LAUNCH((fd_head_bwd_f32<FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), tws(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, tws(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
         if ((rc = check_launch("fd_head_bwd_f32"))) return rc;
-        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(Hd.d.cin, 64)), dim3(1024), 0, s, wpart, nb2, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight);
+        {
+            int rows = 0;
+            const float *pr = slice_rows(plan, wpart, nb2, Hd.d.cin, s, &rows, &rc);
+            if (rc) return rc;
+            FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(Hd.d.cin, 64)), dim3(1024), 0, s, pr, rows, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight);
+        }
         if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
         // the BN partials of the head's producer are now in `part` (nb2 workgroups)
         if ((rc = bn_bwd_finalize(c, Hd.d.src, nb2))) return rc;
@@ -191,7 +205,12 @@ int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, 
         case FD_OP_STEM:
             FD_LAUNCH(fd_stem_wgrad_f32, L.grid, dim3(256), (size_t)(256 * 28 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), tws(plan, L.g_off), tws(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout);
             if ((rc = check_launch("fd_stem_wgrad_f32"))) return rc;
-            FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, wpart, L.nblk, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
+            {
+                int rows = 0;
+                const float *pr = slice_rows(plan, wpart, L.nblk, 27 * d.cout, s, &rows, &rc);
+                if (rc) return rc;
+                FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, pr, rows, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
+            }
             if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
             break;
         case FD_OP_DW: {

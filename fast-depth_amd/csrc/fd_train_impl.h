@@ -41,7 +41,7 @@ struct TLayer {
 struct fd_train_plan {
     std::vector<TLayer> layers;
     int B = 0, H = 0, W = 0;
-    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0;
+    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0, part2_off = 0, part2_bytes = 0;
     unsigned char *ws = nullptr;
     bool forward_done = false;
     float eps = 1e-5f;
@@ -51,6 +51,22 @@ struct fd_train_plan {
 namespace {
 
 inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
+
+// Two-level deterministic reduction, stage A: more than 64 partial rows are first summed into <= 64 slice rows.
+// Returns the buffer / row count the finalize kernel should read.
+const float *slice_rows(fd_train_plan *p, const float *part, int nrows, int width, hipStream_t s, int *rows_out, int *rc)
+{
+    *rc = FD_OK;
+    if (nrows <= 64) { *rows_out = nrows; return part; }
+    const int slices = std::min(64, ceil_div(nrows, 16));
+    const int rps = ceil_div(nrows, slices);
+    const int ns = ceil_div(nrows, rps);
+    float *out = tws(p, p->part2_off);
+    FD_LAUNCH(fd_slice_sum_f32, dim3(ceil_div(width, 64), ns), dim3(1024), 0, s, part, nrows, rps, width, out);
+    *rc = check_launch("fd_slice_sum_f32");
+    *rows_out = ns;
+    return out;
+}
 
 template <int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const float *zin, const float *st1, const float *zskip, const float *st2, const float *w,
@@ -96,7 +112,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     fd_train_plan *p = new fd_train_plan();
     p->B = batch; p->H = height; p->W = width;
     p->layers.resize(n_layers);
-    size_t off = 0, max_part = 0, max_wpart = 0, max_g = 0;
+    size_t off = 0, max_part = 0, max_wpart = 0, max_g = 0, max_width = 0;
 #define FD_BAD(...) do { int rc_ = fail(FD_ERR_INVALID, __VA_ARGS__); delete p; return rc_; } while (0)
     for (int i = 0; i < n_layers; ++i) {
         TLayer &L = p->layers[i];
@@ -181,6 +197,10 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.st_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         L.coef_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         max_part = std::max(max_part, (size_t)L.nblk * 2 * d.cout);
+        max_width = std::max(max_width, (size_t)2 * d.cout);
+        if (d.op == FD_OP_DW) max_width = std::max(max_width, (size_t)d.ksize * d.ksize * d.cin);
+        if (d.op == FD_OP_STEM) max_width = std::max(max_width, (size_t)27 * d.cout);
+        if (d.op == FD_OP_PW) max_width = std::max(max_width, (size_t)d.cin * d.cout);
         max_g = std::max(max_g, L.z_elems);
     }
     TLayer &last = p->layers.back();
@@ -199,6 +219,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
     p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
     p->wpart_off = off; p->wpart_bytes = align_up(std::max(max_wpart, (size_t)1) * 4, 256); off += p->wpart_bytes;
+    p->part2_off = off; p->part2_bytes = align_up(64 * std::max(max_width, (size_t)1) * 4, 256); off += p->part2_bytes;   // stage-A slices of the two-level reductions
     p->ws_bytes = off;
     *out_plan = p;
     return FD_OK;
@@ -267,7 +288,10 @@ int fd_train_forward(fd_train_plan *plan, const fd_layer_params *params, int32_t
             break;
         }
         if (rc) return rc;
-        FD_LAUNCH(fd_bn_finalize_f32, dim3(ceil_div(d.cout, 64)), dim3(1024), 0, s, part, L.nblk, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
+        int rows = 0;
+        const float *pr = slice_rows(plan, part, L.nblk, 2 * d.cout, s, &rows, &rc);
+        if (rc) return rc;
+        FD_LAUNCH(fd_bn_finalize_f32, dim3(ceil_div(d.cout, 64)), dim3(1024), 0, s, pr, rows, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
                   q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off));
         if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
     }
