@@ -139,7 +139,11 @@ PwCfg choose_pw(long M, int N)
     // Measured on MI355X (scratch/gemm, round 1): with the fp32 MFMA at 64 cycles per instruction the 64x64 tile
     // (one 32x32 accumulator per wave, 4+ workgroups per CU) beats the larger tiles on every shape of this
     // network -- latency hiding across workgroups matters more than operand reuse.
-    (void)blocks; (void)waste; (void)c128x128; (void)c128x64; (void)c64x128;
+    // Exception (same measurements): the 14x14 layers (M = 6272 at batch 32, N, K >= 256) run 13 % faster on 128x64 --
+    // both shapes are bound by the same wave quantisation (3.06 32x32 tiles per SIMD), the larger tile halves the
+    // L2 -> LDS bytes per flop.
+    (void)blocks; (void)waste; (void)c128x128; (void)c64x128;
+    if (M > 4096 && M <= 16384 && N >= 256) return c128x64;
     return c64x64;
 }
 

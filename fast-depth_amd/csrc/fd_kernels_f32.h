@@ -286,15 +286,16 @@ fd_dw3_rows_f32(const float *__restrict__ in, const float *__restrict__ wp, cons
 // Ragged M / N: source rows are clamped (finite garbage in rows that are never stored).
 // ------------------------------------------------------------------------------------------------
 template <int WGM, int WGN, int TM, int TN, int ACT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * WGM * WGN)
 fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
                float *__restrict__ out, int M, int N, int K, int K32, int m_tiles, int n_tiles)
 {
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    constexpr int NW = WGM * WGN;                          // waves per workgroup (1, 2 or 4)
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, BK = 32;
     constexpr int ROWS = BM + BN;                          // LDS rows per stage (A rows then W rows), 32 floats each
     constexpr int STAGE = ROWS * BK;                       // floats per stage
-    constexpr int RG = ROWS / 8 / 4;                       // LDS-DMA instructions (8 rows = 1 KiB each) per wave per K tile
+    constexpr int RG = ROWS / 8 / NW;                      // LDS-DMA instructions (8 rows = 1 KiB each) per wave per K tile
+    static_assert((ROWS / 8) % NW == 0, "row groups must divide evenly over the waves");
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,7 +312,7 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
     bool src_is_a[RG];
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
-        const int r = (wave + 4 * i) * 8 + (lane >> 3);     // row within the stage
+        const int r = (wave + NW * i) * 8 + (lane >> 3);    // row within the stage
         const int c = (lane & 7) ^ ((r >> 1) & 7);          // global chunk that lands in LDS slot (r, lane&7)
         src_chunk[i] = c * 4;
         src_is_a[i] = r < BM;
@@ -324,7 +325,7 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
         for (int i = 0; i < RG; ++i) {
             int k = t * BK + src_chunk[i];
             if (src_is_a[i] && k >= K) k = 0;                // ragged K: any finite data; the padded weights are 0 there
-            fd_glds16(src[i] + k, dst + i * 4 * 8 * BK);
+            fd_glds16(src[i] + k, dst + i * NW * 8 * BK);
         }
     };
 

@@ -145,6 +145,51 @@ class Engine:
                         b.value, f.value))
         return out
 
+    # ---- hipGraph replay, optionally with the batch split over several streams --------------------------------------------
+    def forward_graph(self, x, streams=1):
+        """Inference forward replayed from a captured HIP graph (opt-in: the returned tensor is a STATIC buffer that the next
+        call overwrites).  With streams = S > 1 the batch is cut into S sub-batches, each with its own plan/workspace, captured
+        on S forked streams: independent frames need no communication, and the MFMA-bound pointwise kernels of one sub-batch
+        overlap the HBM-bound depthwise kernels (and the ramp/tail) of another.  The graph is keyed by (input address, shape, S):
+        call it with the same input tensor object (e.g. a pinned staging buffer) to replay without a copy."""
+        if self.model.training or not x.is_cuda or x.dtype != torch.float32:
+            raise capi.FastDepthError("forward_graph is an inference path for float32 GPU tensors")
+        x = x.contiguous()
+        key = (x.data_ptr(), tuple(x.shape), streams)
+        g = self.__dict__.setdefault("_graphs", {}).get(key)
+        if g is None or g["version"] != self._version():
+            g = self._capture(x, streams)
+            self._graphs[key] = g
+        g["graph"].replay()
+        return g["y"]
+
+    def _capture(self, x, streams):
+        b = x.shape[0]
+        if b % streams:
+            raise capi.FastDepthError("batch %d is not divisible by %d streams" % (b, streams))
+        L = lib()
+        sub = b // streams
+        y = torch.empty((b, 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        plans = [_Plan(self, sub, x.shape[2], x.shape[3], x.device, False) for _ in range(streams)]
+        side = [torch.cuda.Stream(device=x.device) for _ in range(streams - 1)]
+        cur = torch.cuda.current_stream(x.device)
+        with torch.cuda.device(x.device):
+            for p in plans:                      # pack outside the capture (weights are static for the graph's lifetime)
+                self._pack(p, cur.cuda_stream)
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cap = torch.cuda.current_stream(x.device)
+                for i, p in enumerate(plans):
+                    s = cap if i == 0 else side[i - 1]
+                    if i:
+                        s.wait_stream(cap)
+                    xi, yi = x[i * sub:(i + 1) * sub], y[i * sub:(i + 1) * sub]
+                    capi.check(L, L.fd_forward(p.handle, xi.data_ptr(), yi.data_ptr(), s.cuda_stream), "fd_forward")
+                for s in side:
+                    cap.wait_stream(s)
+        return {"graph": graph, "y": y, "plans": plans, "x": x, "version": self._version(), "side": side}
+
     def layer_output(self, x, index):
         """Test hook: NCHW copy of fused layer `index`'s output from the last forward on x's plan."""
         L = lib()
