@@ -6,6 +6,7 @@
 // fixed grids, tile shapes and buffer addresses, so a forward is ~38 back-to-back launches on the
 // caller's stream with no host-side decisions, allocations or synchronisation in between.
 #include "fd_kernels_f32.h"
+#include "fd_kernels_h16.h"
 #include "../../include/fastdepth_hip.h"
 
 #include <algorithm>
@@ -63,7 +64,8 @@ struct Layer {
     size_t w_off = 0, w_bytes = 0, b_off = 0;   // packed weights / bias
     size_t w_elems = 0;          // unpadded weight element count (algorithmic bytes)
     bool to_output = false;      // writes the network output buffer directly
-    bool head = false;           // Cout == 1 pointwise: fd_head_pw1_f32
+    bool head = false;           // Cout == 1 pointwise: fd_head_pw1
+    bool pw_packed_t = false;    // packed weights are 16-bit (pointwise layers of a 16-bit plan)
     // dw tiling
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0;
     bool dw_rows = false;        // register-window 3x3 kernel (fd_dw3_rows_f32) instead of the LDS-tiled one
@@ -71,7 +73,7 @@ struct Layer {
     int chunk = 0;
     // pw
     PwCfg pw{};
-    int m_tiles = 0, n_tiles = 0;
+    int m_tiles = 0, n_tiles = 0, w_pitch = 0;
     size_t lds = 0;
     dim3 grid;
     std::string info, sym;
@@ -159,44 +161,44 @@ int check_launch(const char *what)
 }
 
 // ---- launches ------------------------------------------------------------------------------------
-template <int ACT>
-int launch_stem(const Layer &L, const float *x, const float *wp, const float *bias, float *y, int B, hipStream_t s)
+template <typename T, int ACT>
+int launch_stem(const Layer &L, const float *x, const float *wp, const float *bias, T *y, int B, hipStream_t s)
 {
     switch (L.chunk) {
-    case 32: FD_LAUNCH((fd_stem3x3s2_f32<ACT, 32>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
-    case 16: FD_LAUNCH((fd_stem3x3s2_f32<ACT, 16>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
-    default: FD_LAUNCH((fd_stem3x3s2_f32<ACT, 8>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    case 32: FD_LAUNCH((fd_stem3x3s2<T, ACT, 32>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    case 16: FD_LAUNCH((fd_stem3x3s2<T, ACT, 16>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
+    default: FD_LAUNCH((fd_stem3x3s2<T, ACT, 8>), L.grid, dim3(256), L.lds, s, x, wp, bias, y, B, L.in_h, L.in_w, L.d.cout); break;
     }
-    return check_launch("fd_stem3x3s2_f32");
+    return check_launch("fd_stem3x3s2");
 }
 
-template <int K, int S, int MODE, int ACT>
-int launch_dw_inst(const Layer &L, const float *in, const float *skip, const float *wp, const float *bias, float *out, hipStream_t s)
+template <typename T, int K, int S, int MODE, int ACT>
+int launch_dw_inst(const Layer &L, const T *in, const T *skip, const float *wp, const float *bias, T *out, hipStream_t s)
 {
-    FD_LAUNCH((fd_dwconv_f32<K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
+    FD_LAUNCH((fd_dwconv<T, K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
                        L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);
-    return check_launch("fd_dwconv_f32");
+    return check_launch("fd_dwconv");
 }
 
-template <int ACT>
-int launch_dw(const Layer &L, const float *in, const float *skip, const float *wp, const float *bias, float *out, hipStream_t s)
+template <typename T, int ACT>
+int launch_dw(const Layer &L, const T *in, const T *skip, const float *wp, const float *bias, T *out, hipStream_t s)
 {
     if (L.dw_rows) {
         if (L.d.stride == 1)
-            FD_LAUNCH((fd_dw3_rows_f32<1, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
+            FD_LAUNCH((fd_dw3_rows<T, 1, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
         else
-            FD_LAUNCH((fd_dw3_rows_f32<2, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
-        return check_launch("fd_dw3_rows_f32");
+            FD_LAUNCH((fd_dw3_rows<T, 2, ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.th);
+        return check_launch("fd_dw3_rows");
     }
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     switch (key) {
-    case 310: return launch_dw_inst<3, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
-    case 320: return launch_dw_inst<3, 2, 0, ACT>(L, in, skip, wp, bias, out, s);
-    case 510: return launch_dw_inst<5, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
-    case 511: return launch_dw_inst<5, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
-    case 512: return launch_dw_inst<5, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
-    case 311: return launch_dw_inst<3, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
-    case 312: return launch_dw_inst<3, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
+    case 310: return launch_dw_inst<T, 3, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
+    case 320: return launch_dw_inst<T, 3, 2, 0, ACT>(L, in, skip, wp, bias, out, s);
+    case 510: return launch_dw_inst<T, 5, 1, 0, ACT>(L, in, skip, wp, bias, out, s);
+    case 511: return launch_dw_inst<T, 5, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
+    case 512: return launch_dw_inst<T, 5, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
+    case 311: return launch_dw_inst<T, 3, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
+    case 312: return launch_dw_inst<T, 3, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
     }
     return fail(FD_ERR_INVALID, "depthwise k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
 }
@@ -209,7 +211,7 @@ int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias
 #define FD_PW_CASE(a, b, c, d) \
     case a * 1000 + b * 100 + c * 10 + d: \
         if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_pw_gemm_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        FD_LAUNCH((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, (K + 31) / 32 * 32, L.m_tiles, L.n_tiles); break;
+        FD_LAUNCH((fd_pw_gemm_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.m_tiles, L.n_tiles); break;
     switch (key) {
         FD_PW_CASE(2, 2, 2, 2)
         FD_PW_CASE(2, 2, 2, 1)
@@ -223,26 +225,59 @@ int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias
 }
 
 template <int ACT>
+int launch_pw_t(const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
+{
+    return launch_pw<ACT>(L, A, static_cast<const float *>(wp), bias, out, M, s);
+}
+template <int ACT, typename T>
+int launch_pw_t(const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s)
+{
+    const int K = L.d.cin;
+    FD_LAUNCH((fd_pw_gemm_h16<T, ACT>), L.grid, dim3(256), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, (K + 63) / 64 * 64,
+              L.m_tiles, L.n_tiles);
+    return check_launch("fd_pw_gemm_h16");
+}
+
+template <typename T, int ACT>
 int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hipStream_t s)
 {
-    const float *wp = reinterpret_cast<const float *>(p->ws + L.w_off);
+    const void *wp = p->ws + L.w_off;
+    const float *wpf = reinterpret_cast<const float *>(p->ws + L.w_off);
     const float *bias = reinterpret_cast<const float *>(p->ws + L.b_off);
-    float *out = L.to_output ? y : reinterpret_cast<float *>(p->ws + L.out_off);
-    const float *in = L.d.src < 0 ? x : reinterpret_cast<const float *>(p->ws + p->layers[L.d.src].out_off);
-    const float *skip = L.d.skip >= 0 ? reinterpret_cast<const float *>(p->ws + p->layers[L.d.skip].out_off) : nullptr;
+    T *out = reinterpret_cast<T *>(p->ws + L.out_off);
+    const T *in = L.d.src < 0 ? nullptr : reinterpret_cast<const T *>(p->ws + p->layers[L.d.src].out_off);
+    const T *skip = L.d.skip >= 0 ? reinterpret_cast<const T *>(p->ws + p->layers[L.d.skip].out_off) : nullptr;
     switch (L.d.op) {
-    case FD_OP_STEM: return launch_stem<ACT>(L, in, wp, bias, out, p->B, s);
-    case FD_OP_DW: return launch_dw<ACT>(L, in, skip, wp, bias, out, s);
+    case FD_OP_STEM: return launch_stem<T, ACT>(L, x, wpf, bias, out, p->B, s);
+    case FD_OP_DW: return launch_dw<T, ACT>(L, in, skip, wpf, bias, out, s);
     case FD_OP_PW:
         if (L.head) {
             const int h = L.d.upsample ? L.in_h / 2 : L.in_h, w = L.d.upsample ? L.in_w / 2 : L.in_w;
             const long npix = (long)p->B * h * w;
-            FD_LAUNCH((fd_head_pw1_f32<ACT>), L.grid, dim3(256), 0, s, in, wp, bias, out, npix, h, w, L.d.cin, L.d.upsample);
-            return check_launch("fd_head_pw1_f32");
+            FD_LAUNCH((fd_head_pw1<T, ACT>), L.grid, dim3(256), 0, s, in, wpf, bias, y, npix, h, w, L.d.cin, L.d.upsample);
+            return check_launch("fd_head_pw1");
         }
-        return launch_pw<ACT>(L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
+        return launch_pw_t<ACT>(L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
     }
     return fail(FD_ERR_INVALID, "bad op");
+}
+
+template <typename T>
+int run_layer_t(fd_plan *plan, const Layer &L, const float *x, float *out, hipStream_t s)
+{
+    switch (L.d.act) {
+    case FD_ACT_RELU: return launch_layer<T, FD_ACT_RELU_>(plan, L, x, out, s);
+    case FD_ACT_RELU6: return launch_layer<T, FD_ACT_RELU6_>(plan, L, x, out, s);
+    default: return launch_layer<T, FD_ACT_NONE_>(plan, L, x, out, s);
+    }
+}
+int run_layer(fd_plan *plan, const Layer &L, const float *x, float *out, hipStream_t s)
+{
+    switch (plan->dtype) {
+    case FD_F16: return run_layer_t<fd_half>(plan, L, x, out, s);
+    case FD_BF16: return run_layer_t<fd_bf16>(plan, L, x, out, s);
+    default: return run_layer_t<float>(plan, L, x, out, s);
+    }
 }
 
 }  // namespace
@@ -251,7 +286,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
 extern "C" {
 
 const char *fd_last_error(void) { return g_err.c_str(); }
-const char *fd_version(void) { return "fastdepth_hip 0.1 (gfx950, fp32 inference)"; }
+const char *fd_version(void) { return "fastdepth_hip 0.2 (gfx950; inference f32/f16/bf16, train step f32)"; }
 
 int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
                    int32_t dtype, uint32_t flags, fd_plan **out_plan)
@@ -259,11 +294,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
-    if (dtype != FD_F32) return fail(FD_ERR_INVALID, "dtype %d not supported by this build (fp32 only)", dtype);
+    if (dtype != FD_F32 && dtype != FD_F16 && dtype != FD_BF16) return fail(FD_ERR_INVALID, "unknown dtype %d", dtype);
     fd_plan *p = new fd_plan();
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
     p->layers.resize(n_layers);
-    const size_t esz = 4;
+    const size_t esz = dtype == FD_F32 ? 4 : 2;   // activation / pointwise-weight element size
     size_t woff = 0;
     for (int i = 0; i < n_layers; ++i) {
         Layer &L = p->layers[i];
@@ -293,7 +328,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
             L.lds = 256 * (L.chunk + 4) * 4;
             L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
-            L.w_bytes = (size_t)27 * d.cout * esz; L.w_elems = (size_t)27 * d.cout;
+            L.w_bytes = (size_t)27 * d.cout * 4; L.w_elems = (size_t)27 * d.cout;
             break;
         case FD_OP_DW: {
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4)
@@ -310,7 +345,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.th = th;
                 L.grid = dim3(gx, ceil_div(L.out_h, th), batch);
                 L.lds = 0;
-                L.w_bytes = (size_t)9 * d.cin * esz; L.w_elems = (size_t)9 * d.cin;
+                L.w_bytes = (size_t)9 * d.cin * 4; L.w_elems = (size_t)9 * d.cin;
                 break;
             }
             const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
@@ -323,13 +358,13 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
             L.lds = ((size_t)th_in * tw_in * (cb + 4) + (size_t)d.ksize * d.ksize * cb + cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
-            L.w_bytes = (size_t)d.ksize * d.ksize * d.cin * esz; L.w_elems = (size_t)d.ksize * d.ksize * d.cin;
+            L.w_bytes = (size_t)d.ksize * d.ksize * d.cin * 4; L.w_elems = (size_t)d.ksize * d.ksize * d.cin;
             break;
         }
         case FD_OP_PW:
             if (d.src < 0 || d.ksize != 1 || d.stride != 1 || d.cin % 4) FD_BAD("layer %d: pointwise needs k=1 stride=1 cin%%4==0", i);
             L.out_h = L.in_h; L.out_w = L.in_w;
-            L.w_bytes = (size_t)d.cin * d.cout * esz;
+            L.w_bytes = (size_t)d.cin * d.cout * 4;     // the 1-channel head keeps fp32 weights
             L.w_elems = (size_t)d.cin * d.cout;
             if (d.cout == 1) {
                 if (d.skip >= 0) FD_BAD("layer %d: head with skip is not part of this path", i);
@@ -339,8 +374,10 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             } else {
                 if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample is only supported for the 1-channel head", i);
                 const long M = (long)batch * L.out_h * L.out_w;
-                L.w_bytes = (size_t)d.cout * ((d.cin + 31) / 32 * 32) * esz;      // rows zero-padded to a multiple of BK = 32
-                L.pw = choose_pw(M, d.cout);
+                if (dtype != FD_F32 && d.cin % 8) FD_BAD("layer %d: 16-bit pointwise needs cin %% 8 == 0", i);
+                L.w_pitch = dtype == FD_F32 ? (d.cin + 31) / 32 * 32 : (d.cin + 63) / 64 * 64;   // rows zero-padded to a multiple of BK
+                L.w_bytes = (size_t)d.cout * L.w_pitch * esz;
+                L.pw = dtype == FD_F32 ? choose_pw(M, d.cout) : PwCfg{2, 2, 1, 1};
                 L.lds = pw_lds_bytes(L.pw);
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
                 L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
@@ -353,6 +390,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         L.w_off = woff; woff += align_up(L.w_bytes, 256);
         L.b_off = woff; woff += align_up((size_t)d.cout * 4, 256);
         L.out_bytes = align_up((size_t)batch * L.out_h * L.out_w * d.cout * esz, 256);
+        L.pw_packed_t = (d.op == FD_OP_PW && !L.head && dtype != FD_F32);
     }
     Layer &last = p->layers.back();
     if (last.d.cout != 1 || last.out_h != height || last.out_w != width)
@@ -387,7 +425,8 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         const double skip_elems = d.skip >= 0 ? (double)batch * L.in_h * L.in_w * d.cin : 0.0;
         const double out_elems = (double)batch * L.out_h * L.out_w * d.cout;
         const double w_elems = (double)L.w_elems + 2.0 * d.cout;
-        L.alg_bytes = (src_elems + skip_elems + out_elems + w_elems) * esz;
+        const double in_esz = d.src < 0 ? 4.0 : (double)esz, out_esz = L.to_output ? 4.0 : (double)esz;   // network input / output stay fp32
+        L.alg_bytes = (src_elems + skip_elems) * in_esz + out_elems * out_esz + (double)L.w_elems * (L.pw_packed_t ? esz : 4) + 2.0 * d.cout * 4;
         p->alg_bytes += L.alg_bytes;
         const double taps = d.op == FD_OP_STEM ? 27.0 : (d.op == FD_OP_DW ? (double)d.ksize * d.ksize : (double)d.cin);
         const double mac_px = L.head && d.upsample ? (double)L.out_h * L.out_w : (double)L.out_h * L.out_w;
@@ -395,23 +434,25 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         p->alg_flops += L.alg_flops;
         char buf[256];
         if (d.op == FD_OP_STEM)
-            snprintf(buf, sizeof buf, "stem3x3s2_f32<chunk %d> grid=%u lds=%zu", L.chunk, L.grid.x, L.lds);
+            snprintf(buf, sizeof buf, "stem3x3s2<chunk %d> grid=%u lds=%zu", L.chunk, L.grid.x, L.lds);
         else if (d.op == FD_OP_DW && L.dw_rows)
-            snprintf(buf, sizeof buf, "dw3_rows_f32<s%d> rows/item %d grid=%ux%ux%u", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
+            snprintf(buf, sizeof buf, "dw3_rows<s%d> rows/item %d grid=%ux%ux%u", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW)
-            snprintf(buf, sizeof buf, "dwconv_f32<k%d s%d mode%d> tile %dx%dx%d grid=%ux%ux%u lds=%zu", d.ksize, d.stride, L.mode,
+            snprintf(buf, sizeof buf, "dwconv<k%d s%d mode%d> tile %dx%dx%d grid=%ux%ux%u lds=%zu", d.ksize, d.stride, L.mode,
                      L.th, L.tw, 4 << L.cbq, L.grid.x, L.grid.y, L.grid.z, L.lds);
         else if (L.head)
-            snprintf(buf, sizeof buf, "head_pw1_f32 up=%d grid=%u", d.upsample, L.grid.x);
+            snprintf(buf, sizeof buf, "head_pw1 up=%d grid=%u", d.upsample, L.grid.x);
         else
-            snprintf(buf, sizeof buf, "pw_gemm_f32<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
+            snprintf(buf, sizeof buf, "pw_gemm<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
                      L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         L.info = buf;
-        if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2_f32<%d, %d>", d.act, L.chunk);
-        else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows_f32<%d, %d>", d.stride, d.act);
-        else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv_f32<%d, %d, %d, %d>", d.ksize, d.stride, L.mode, d.act);
-        else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1_f32<%d>", d.act);
-        else snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
+        const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
+        if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
+        else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
+        else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
+        else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
+        else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
+        else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);
         L.sym = buf;
     }
     *out_plan = p;
@@ -444,25 +485,23 @@ int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n
         if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
         const int inner = (int)(L.w_elems / L.d.cout);
         const int transpose = (L.d.op == FD_OP_PW) ? 0 : 1;          // stem/dw kernels want tap-major [inner][cout]
-        const int pitch = transpose ? inner : (int)(L.w_bytes / 4 / L.d.cout);   // pointwise rows are padded to 32 floats
+        const int pitch = transpose ? inner : (L.w_pitch ? L.w_pitch : inner);   // pointwise rows are zero-padded to the GEMM's BK
         const long total = std::max<long>((long)L.d.cout * std::max(inner, pitch), L.d.cout);
-        hipLaunchKernelGGL(fd_pack_fold_f32, dim3(ceil_div(total, 256)), dim3(256), 0, s, q.conv_weight, q.bn_weight, q.bn_bias,
-                           q.bn_mean, q.bn_var, bn_eps, reinterpret_cast<float *>(plan->ws + L.w_off),
-                           reinterpret_cast<float *>(plan->ws + L.b_off), L.d.cout, inner, transpose, pitch);
-        int rc = check_launch("fd_pack_fold_f32");
+        float *bptr = reinterpret_cast<float *>(plan->ws + L.b_off);
+        if (L.pw_packed_t && plan->dtype == FD_F16)
+            hipLaunchKernelGGL((fd_pack_fold<fd_half>), dim3(ceil_div(total, 256)), dim3(256), 0, s, q.conv_weight, q.bn_weight, q.bn_bias, q.bn_mean, q.bn_var, bn_eps,
+                               reinterpret_cast<fd_half *>(plan->ws + L.w_off), bptr, L.d.cout, inner, transpose, pitch);
+        else if (L.pw_packed_t)
+            hipLaunchKernelGGL((fd_pack_fold<fd_bf16>), dim3(ceil_div(total, 256)), dim3(256), 0, s, q.conv_weight, q.bn_weight, q.bn_bias, q.bn_mean, q.bn_var, bn_eps,
+                               reinterpret_cast<fd_bf16 *>(plan->ws + L.w_off), bptr, L.d.cout, inner, transpose, pitch);
+        else
+            hipLaunchKernelGGL((fd_pack_fold<float>), dim3(ceil_div(total, 256)), dim3(256), 0, s, q.conv_weight, q.bn_weight, q.bn_bias, q.bn_mean, q.bn_var, bn_eps,
+                               reinterpret_cast<float *>(plan->ws + L.w_off), bptr, L.d.cout, inner, transpose, pitch);
+        int rc = check_launch("fd_pack_fold");
         if (rc) return rc;
     }
     plan->packed = true;
     return FD_OK;
-}
-
-static int run_layer(fd_plan *plan, const Layer &L, const float *x, float *out, hipStream_t s)
-{
-    switch (L.d.act) {
-    case FD_ACT_RELU: return launch_layer<FD_ACT_RELU_>(plan, L, x, out, s);
-    case FD_ACT_RELU6: return launch_layer<FD_ACT_RELU6_>(plan, L, x, out, s);
-    default: return launch_layer<FD_ACT_NONE_>(plan, L, x, out, s);
-    }
 }
 
 int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)

@@ -58,4 +58,46 @@ __device__ __forceinline__ fd_f32x4 fd_act4(fd_f32x4 v)
 }
 __device__ __forceinline__ fd_f32x4 fd_ld4(const float *p) { return *reinterpret_cast<const fd_f32x4 *>(p); }
 __device__ __forceinline__ void fd_st4(float *p, fd_f32x4 v) { *reinterpret_cast<fd_f32x4 *>(p) = v; }
+
+// ---- 16-bit storage types (activations / pointwise weights; all arithmetic and accumulation stay fp32) ---------------
+typedef _Float16 fd_half;
+struct fd_bf16 { unsigned short v; };                       // raw bfloat16 bits
+typedef _Float16 fd_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 fd_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short fd_u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short fd_u16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float fd_bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+__device__ __forceinline__ unsigned short fd_f32_to_bf16(float f)
+{   // round to nearest even (NaN handling is not needed on this path: inputs are finite)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+// 4 consecutive channels: one 8-byte access
+__device__ __forceinline__ fd_f32x4 fd_ld4(const fd_half *p)
+{
+    const fd_f16x4 h = *reinterpret_cast<const fd_f16x4 *>(p);
+    fd_f32x4 r = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return r;
+}
+__device__ __forceinline__ void fd_st4(fd_half *p, fd_f32x4 v)
+{
+    fd_f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    *reinterpret_cast<fd_f16x4 *>(p) = h;
+}
+__device__ __forceinline__ fd_f32x4 fd_ld4(const fd_bf16 *p)
+{
+    const fd_u16x4 h = *reinterpret_cast<const fd_u16x4 *>(p);
+    fd_f32x4 r = {fd_bf16_to_f32(h.x), fd_bf16_to_f32(h.y), fd_bf16_to_f32(h.z), fd_bf16_to_f32(h.w)};
+    return r;
+}
+__device__ __forceinline__ void fd_st4(fd_bf16 *p, fd_f32x4 v)
+{
+    fd_u16x4 h = {fd_f32_to_bf16(v.x), fd_f32_to_bf16(v.y), fd_f32_to_bf16(v.z), fd_f32_to_bf16(v.w)};
+    *reinterpret_cast<fd_u16x4 *>(p) = h;
+}
+__device__ __forceinline__ void fd_st1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void fd_st1(fd_half *p, float v) { *p = (_Float16)v; }
+__device__ __forceinline__ void fd_st1(fd_bf16 *p, float v) { p->v = fd_f32_to_bf16(v); }
 __device__ __forceinline__ fd_f32x4 fd_zero4() { fd_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }

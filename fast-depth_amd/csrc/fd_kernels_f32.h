@@ -20,10 +20,11 @@
 // ------------------------------------------------------------------------------------------------
 // Weight packing: wp = w * scale[cout]  (optionally transposed to [inner][cout]),  bias = beta - mean*scale
 // ------------------------------------------------------------------------------------------------
+template <typename TW>
 __global__ void __launch_bounds__(256)
-fd_pack_fold_f32(const float *__restrict__ w, const float *__restrict__ gamma, const float *__restrict__ beta,
-                 const float *__restrict__ mean, const float *__restrict__ var, float eps,
-                 float *__restrict__ wp, float *__restrict__ bias, int cout, int inner, int transpose, int row_pitch)
+fd_pack_fold(const float *__restrict__ w, const float *__restrict__ gamma, const float *__restrict__ beta,
+             const float *__restrict__ mean, const float *__restrict__ var, float eps,
+             TW *__restrict__ wp, float *__restrict__ bias, int cout, int inner, int transpose, int row_pitch)
 {
     // transpose == 0: wp[co][row_pitch] (rows zero-padded beyond `inner`);  transpose == 1: wp[inner][cout]
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -33,7 +34,7 @@ fd_pack_fold_f32(const float *__restrict__ w, const float *__restrict__ gamma, c
         const int co = (int)(idx / per), i = (int)(idx - (long)co * per);
         const float scale = gamma[co] / sqrtf(var[co] + eps);
         const float v = i < inner ? w[(long)co * inner + i] * scale : 0.0f;
-        if (transpose) wp[(long)i * cout + co] = v; else wp[idx] = v;
+        if (transpose) fd_st1(wp + (long)i * cout + co, v); else fd_st1(wp + idx, v);
     }
     if (idx < cout) {
         const float scale = gamma[idx] / sqrtf(var[idx] + eps);
@@ -47,10 +48,10 @@ fd_pack_fold_f32(const float *__restrict__ w, const float *__restrict__ gamma, c
 // weights wp[27][Cout] are wave-uniform (scalar loads).  The per-pixel channel vector is transposed
 // through LDS so that the global store is dense.
 // ------------------------------------------------------------------------------------------------
-template <int ACT, int CHUNK>
+template <typename T, int ACT, int CHUNK>
 __global__ void __launch_bounds__(256)
-fd_stem3x3s2_f32(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
-                 float *__restrict__ y, int B, int H, int W, int Cout)
+fd_stem3x3s2(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+             T *__restrict__ y, int B, int H, int W, int Cout)
 {
     FD_DYN_SMEM(smem_raw);
     float *tile = reinterpret_cast<float *>(smem_raw);       // [256][CHUNK + 4]
@@ -108,11 +109,11 @@ fd_stem3x3s2_f32(const float *__restrict__ x, const float *__restrict__ wp, cons
 // row it pulls 3*S+K input vectors from LDS once and reuses them across the K taps and 4 outputs.
 // The upsampled / summed tensor is never written to HBM.
 // ------------------------------------------------------------------------------------------------
-template <int K, int S, int MODE, int ACT>
+template <typename T, int K, int S, int MODE, int ACT>
 __global__ void __launch_bounds__(256)
-fd_dwconv_f32(const float *__restrict__ in, const float *__restrict__ skip, const float *__restrict__ wp,
-              const float *__restrict__ bias, float *__restrict__ out, int Hin, int Win, int Ho, int Wo, int C,
-              int cbq, int TH, int TW, int tiles_x)
+fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ wp,
+          const float *__restrict__ bias, T *__restrict__ out, int Hin, int Win, int Ho, int Wo, int C,
+          int cbq, int TH, int TW, int tiles_x)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;                       // input columns feeding 4 adjacent outputs
@@ -206,10 +207,10 @@ fd_dwconv_f32(const float *__restrict__ in, const float *__restrict__ skip, cons
 // registers: per output row it loads only the 3*S new input vectors; the horizontal neighbours it needs are
 // the same words its neighbours load, so they are L1/L2 hits and HBM sees every input byte once.
 // ------------------------------------------------------------------------------------------------
-template <int S, int ACT>
+template <typename T, int S, int ACT>
 __global__ void __launch_bounds__(256)
-fd_dw3_rows_f32(const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
-                float *__restrict__ out, int H, int W, int Ho, int Wo, int C, int TH)
+fd_dw3_rows(const T *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
+            T *__restrict__ out, int H, int W, int Ho, int Wo, int C, int TH)
 {
     const int CG = C >> 2;
     const int q = blockIdx.x * 256 + threadIdx.x;            // output column-group index within a row
@@ -222,17 +223,17 @@ fd_dw3_rows_f32(const float *__restrict__ in, const float *__restrict__ wp, cons
 #pragma unroll
     for (int t = 0; t < 9; ++t) w[t] = fd_ld4(wp + (long)t * C + c4 * 4);
     const fd_f32x4 b4 = fd_ld4(bias + c4 * 4);
-    const float *img = in + (long)n * H * W * C + c4 * 4;
+    const T *img = in + (long)n * H * W * C + c4 * 4;
     const int x0 = xo * S - 1;                                  // leftmost input column of the window
     const bool okl = x0 >= 0, okr = (x0 + 2) < W;               // centre column x0+1 is always valid
     auto load_row = [&](int iy, fd_f32x4 &l, fd_f32x4 &c, fd_f32x4 &r) {
         if (iy < 0 || iy >= H) { l = c = r = fd_zero4(); return; }
-        const float *p = img + ((long)iy * W + x0) * C;
+        const T *p = img + ((long)iy * W + x0) * C;
         l = okl ? fd_ld4(p) : fd_zero4();
         c = fd_ld4(p + C);
         r = okr ? fd_ld4(p + 2 * C) : fd_zero4();
     };
-    float *o = out + (((long)n * Ho + oy0) * Wo) * C + (long)q * 4;
+    T *o = out + (((long)n * Ho + oy0) * Wo) * C + (long)q * 4;
     if (S == 1) {
         fd_f32x4 r0l, r0c, r0r, r1l, r1c, r1r, r2l, r2c, r2r;
         load_row(oy0 - 1, r0l, r0c, r0r);
@@ -420,10 +421,10 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
 // dense 128-byte reads), a 3-step wave shuffle reduces the dot product, lane 0 writes the value once
 // (up == 0) or as the 2x2 block it becomes after nearest upsampling (up == 1).
 // ------------------------------------------------------------------------------------------------
-template <int ACT>
+template <typename T, int ACT>
 __global__ void __launch_bounds__(256)
-fd_head_pw1_f32(const float *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
-                float *__restrict__ y, long npix, int h, int w, int Cin, int up)
+fd_head_pw1(const T *__restrict__ in, const float *__restrict__ wp, const float *__restrict__ bias,
+            float *__restrict__ y, long npix, int h, int w, int Cin, int up)
 {
     const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int l8 = threadIdx.x & 7;

@@ -1,0 +1,124 @@
+// fd_kernels_h16.h -- pointwise GEMM for 16-bit storage (fp16 or bf16 activations / weights, fp32 accumulate) on the
+// gfx950 2xK matrix instructions v_mfma_f32_32x32x16_{f16,bf16}.
+//
+// Same skeleton as fd_pw_gemm_f32 (LDS-DMA 3-stage ring issued two K tiles ahead, counted vmcnt + raw s_barrier, 128-byte
+// LDS rows with the XOR swizzle on the DMA source and on the fragment reads, XCD-aware 1-D grid, bias-initialised
+// accumulators).  A 128-byte row now holds 64 elements, so BK = 64, and a lane's 16-byte chunk IS the MFMA operand
+// (8 consecutive k of its row: lanes 0-31 chunk 2s, lanes 32-63 chunk 2s+1 of MFMA step s) -- one ds_read_b128 per operand
+// per instruction, no repacking.  In 16-bit the 1x1 layers are HBM-bound: the tile is 64 x 64 so that an
+// A panel is streamed once per N tile out of the XCD's L2, and the epilogue transposes the tile through LDS so that the
+// NHWC store is 16 bytes per lane.
+#pragma once
+#include "fd_device.h"
+
+#ifndef FD_EMU
+typedef __bf16 fd_bf16x8_hw __attribute__((ext_vector_type(8)));
+#endif
+
+__device__ __forceinline__ fd_f32x16 fd_mfma_32x32x16(fd_half, fd_u16x8 a, fd_u16x8 b, fd_f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fd_f16x8, a), __builtin_bit_cast(fd_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ fd_f32x16 fd_mfma_32x32x16(fd_bf16, fd_u16x8 a, fd_u16x8 b, fd_f32x16 c)
+{
+#ifdef FD_EMU
+    return hipemu_mfma_f32_32x32x16_bf16(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fd_bf16x8_hw, a), __builtin_bit_cast(fd_bf16x8_hw, b), c, 0, 0, 0);
+#endif
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256)
+fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *__restrict__ bias, T *__restrict__ out,
+               int M, int N, int K, int K64, int m_tiles, int n_tiles)
+{
+    constexpr int BM = 64, BN = 64, BK = 64;                // BK elements = 128 bytes per LDS row
+    constexpr int ROWS = BM + BN, STAGE = ROWS * 128;        // bytes per stage
+    constexpr int RG = ROWS / 8 / 4;
+    FD_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % n_tiles, mt = (slot / n_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const T *src[RG];
+    int src_k[RG];
+    bool src_is_a[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int r = (wave + 4 * i) * 8 + (lane >> 3);
+        src_k[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;        // element offset of the chunk that lands in LDS slot (r, lane&7)
+        src_is_a[i] = r < BM;
+        if (r < BM) { long row = m0 + r; if (row > M - 1) row = M - 1; src[i] = A + row * K; }
+        else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K64; }
+    }
+    auto issue = [&](int t) {
+        unsigned char *dst = smem + (t % 3) * STAGE + wave * 8 * 128;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int k = t * BK + src_k[i];
+            if (src_is_a[i] && k >= K) k = 0;                // ragged K: finite data; the zero-padded weights annihilate it
+            fd_glds16(reinterpret_cast<const float *>(src[i] + k), reinterpret_cast<float *>(dst + i * 4 * 8 * 128));
+        }
+    };
+    fd_f32x16 acc;
+    {
+        const int col = n0 + wn * 32 + (lane & 31);
+        const float bv = col < N ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bv;
+    }
+    const int h = lane >> 5;
+    int a_off[4], b_off[4];                                   // byte offsets within a stage
+    {
+        const int ra = wm * 32 + (lane & 31), rb = BM + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
+            b_off[s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
+        }
+    }
+    const int Tn = K64 / BK;
+    issue(0);
+    if (Tn > 1) issue(1);
+    for (int t = 0; t < Tn; ++t) {
+        if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        fd_block_barrier();
+        if (t + 2 < Tn) issue(t + 2);
+        const unsigned char *cur = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const fd_u16x8 a = *reinterpret_cast<const fd_u16x8 *>(cur + a_off[s]);
+            const fd_u16x8 b = *reinterpret_cast<const fd_u16x8 *>(cur + b_off[s]);
+            acc = fd_mfma_32x32x16(T{}, a, b, acc);
+        }
+    }
+    // epilogue: activation, conversion, transpose through LDS (each wave owns a [32][32+8] T tile), 16-byte stores
+    __syncthreads();                                          // every wave is done reading the operand stages
+    T *tile = reinterpret_cast<T *>(smem) + wave * 32 * 40;
+    const int col = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        fd_st1(tile + row * 40 + col, fd_act<ACT>(acc[r]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = lane + 64 * i;                         // 128 chunks of 8 elements: row = id / 4, chunk = id % 4
+        const int row = id >> 2, c8 = (id & 3) * 8;
+        const long grow = m0 + wm * 32 + row;
+        const int gcol = n0 + wn * 32 + c8;
+        if (grow < M && gcol < N) {
+            if (gcol + 8 <= N) {
+                *reinterpret_cast<fd_u16x8 *>(out + grow * N + gcol) = *reinterpret_cast<const fd_u16x8 *>(tile + row * 40 + c8);
+            } else {
+                for (int j = 0; j < 8 && gcol + j < N; ++j) out[grow * N + gcol + j] = tile[row * 40 + c8 + j];
+            }
+        }
+    }
+}

@@ -21,6 +21,9 @@ def lib():
     return _LIB
 
 
+_DTYPES = {torch.float32: capi.FD_F32, torch.float16: capi.FD_F16, torch.bfloat16: capi.FD_BF16}
+
+
 class _Plan:
     def __init__(self, engine, batch, height, width, device, keep=False):
         L = lib()
@@ -28,8 +31,9 @@ class _Plan:
         n = len(self.layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         handle = ctypes.c_void_p()
-        capi.check(L, L.fd_plan_create(descs, n, batch, height, width, capi.FD_F32,
+        capi.check(L, L.fd_plan_create(descs, n, batch, height, width, _DTYPES[engine.dtype],
                                        capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0, ctypes.byref(handle)), "fd_plan_create")
+        self.dtype = engine.dtype
         self.handle = handle
         self.shape = (batch, height, width)
         self.workspace = torch.empty(L.fd_plan_workspace_bytes(handle) + 256, dtype=torch.uint8, device=device)
@@ -50,11 +54,19 @@ class _Plan:
 class Engine:
     """One per model instance (created lazily by MobileNetSkipAdd.forward)."""
 
-    def __init__(self, model, keep_activations=False):
+    def __init__(self, model, keep_activations=False, dtype=torch.float32):
         self.model = model
         self.layers = layers_of(model)
         self.keep = keep_activations
         self.plans = {}
+        self.set_dtype(dtype)
+
+    def set_dtype(self, dtype):
+        """Storage type of the intermediate activations and the packed pointwise weights: float32 (default), float16 or
+        bfloat16.  Parameters, the network input and the network output stay float32; accumulation is always fp32."""
+        if dtype not in _DTYPES:
+            raise capi.FastDepthError("unsupported compute dtype %r" % (dtype,))
+        self.dtype = dtype
 
     def invalidate(self):
         for p in self.plans.values():
@@ -69,7 +81,7 @@ class Engine:
 
     def plan_for(self, x):
         b, c, h, w = x.shape
-        key = (b, h, w, x.device.index)
+        key = (b, h, w, x.device.index, self.dtype)
         p = self.plans.get(key)
         if p is None:
             p = self.plans[key] = _Plan(self, b, h, w, x.device, self.keep)
@@ -199,5 +211,6 @@ class Engine:
         capi.check(L, L.fd_layer_output(plan.handle, index, ctypes.byref(ptr), *[ctypes.byref(d) for d in dims]), "fd_layer_output")
         n, h, w, c = [d.value for d in dims]
         off = ptr.value - plan.workspace.data_ptr()
-        flat = plan.workspace[off:off + n * h * w * c * 4].view(torch.float32)
-        return flat.view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
+        esz = 4 if plan.dtype == torch.float32 else 2
+        flat = plan.workspace[off:off + n * h * w * c * esz].view(plan.dtype)
+        return flat.view(n, h, w, c).permute(0, 3, 1, 2).float().contiguous()

@@ -119,6 +119,13 @@ class MobileNetSkipAdd(nn.Module):
         state.pop('_fd_engine', None)
         return state
 
+    def set_compute_dtype(self, dtype):
+        """MI355X extension (not in the reference): storage type of the activations / pointwise weights inside the HIP
+        engine -- torch.float32 (default), torch.float16 or torch.bfloat16.  The module's parameters, its input and its
+        output stay float32; accumulation is fp32."""
+        self._engine().set_dtype(dtype)
+        return self
+
     def repack(self):
         """Drop cached packed weights (call after in-place edits the version counters cannot see)."""
         eng = self.__dict__.get('_fd_engine')

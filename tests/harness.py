@@ -29,15 +29,17 @@ def get_lib(kind):
 class CPlan:
     """fd_plan + workspace for `model` at x's shape on x's device."""
 
-    def __init__(self, kind, model, x, keep=True):
+    def __init__(self, kind, model, x, keep=True, dtype=torch.float32):
         self.lib = L = get_lib(kind)
         self.kind, self.model, self.dev = kind, model, x.device
+        self.dtype = dtype
+        fd_dtype = {torch.float32: capi.FD_F32, torch.float16: capi.FD_F16, torch.bfloat16: capi.FD_BF16}[dtype]
         self.layers = layers_of(model)
         n = len(self.layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         self.h = ctypes.c_void_p()
         b, _, hh, ww = x.shape
-        capi.check(L, L.fd_plan_create(descs, n, b, hh, ww, capi.FD_F32, capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0,
+        capi.check(L, L.fd_plan_create(descs, n, b, hh, ww, fd_dtype, capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0,
                                        ctypes.byref(self.h)), "fd_plan_create")
         nbytes = L.fd_plan_workspace_bytes(self.h)
         self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
@@ -68,7 +70,8 @@ class CPlan:
         capi.check(self.lib, self.lib.fd_layer_output(self.h, i, ctypes.byref(ptr), *[ctypes.byref(v) for v in d]), "fd_layer_output")
         n, h, w, c = [v.value for v in d]
         off = ptr.value - self.ws.data_ptr()
-        return self.ws[off:off + n * h * w * c * 4].view(torch.float32).view(n, h, w, c).permute(0, 3, 1, 2).contiguous().cpu()
+        esz = 4 if self.dtype == torch.float32 else 2
+        return self.ws[off:off + n * h * w * c * esz].view(self.dtype).view(n, h, w, c).permute(0, 3, 1, 2).float().contiguous().cpu()
 
     def info(self):
         return [self.lib.fd_plan_kernel_info(self.h, i).decode() for i in range(self.lib.fd_plan_num_kernels(self.h))]
@@ -97,13 +100,13 @@ def randomize_bn(model, seed):
     return model
 
 
-def compare_with_oracle(kind, model, x, device):
+def compare_with_oracle(kind, model, x, device, dtype=torch.float32):
     """Runs the C ABI path and the C oracle on the same weights/input; returns (rel err of the output,
     [rel err per fused layer], plan info)."""
     from oracle import oracle
     model = model.eval()
     y_ref, taps_ref = oracle.forward(model.state_dict(), x.numpy(), taps=True)
-    plan = CPlan(kind, model, x.to(device))
+    plan = CPlan(kind, model, x.to(device), dtype=dtype)
     y = plan.forward(x.to(device)).cpu().numpy()
     errs = [rel_err(plan.tap(i).numpy(), taps_ref[i]) for i in range(len(taps_ref) - 1)]
     errs.append(rel_err(y, y_ref))

@@ -231,6 +231,43 @@ inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipem
     return d;
 }
 
+/* v_mfma_f32_32x32x16_{f16,bf16}: lane l holds A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31], j = 0..7 (layout confirmed on an
+ * MI355X, scratch/probe); D as for the f32 32x32 form.  Products and sums in fp32 (the hardware accumulates in fp32). */
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short hipemu_u16x8 __attribute__((ext_vector_type(8)));
+inline hipemu_f32x16 hipemu_mfma_32x32x16_generic(const float (&av)[8], const float (&bv)[8], hipemu_f32x16 c)
+{
+    hipemu::WaveXchg &x = hipemu::wave_xchg();
+    const int l = hipemu::lane_id();
+    for (int j = 0; j < 8; ++j) { x.f[l][j] = av[j]; x.f[l][8 + j] = bv[j]; }
+    hipemu::yield(hipemu::COLLECTIVE);
+    hipemu_f32x16 d;
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(x.f[row + 32 * (k >> 3)][k & 7], x.f[col + 32 * (k >> 3)][8 + (k & 7)], acc);
+        d[r] = acc;
+    }
+    hipemu::yield(hipemu::COLLECTIVE);
+    return d;
+}
+inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c, int, int, int)
+{
+    float av[8], bv[8];
+    for (int j = 0; j < 8; ++j) { av[j] = (float)a[j]; bv[j] = (float)b[j]; }
+    return hipemu_mfma_32x32x16_generic(av, bv, c);
+}
+inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_u16x8 a, hipemu_u16x8 b, hipemu_f32x16 c)
+{
+    float av[8], bv[8];
+    for (int j = 0; j < 8; ++j) {
+        unsigned ua = (unsigned)a[j] << 16, ub = (unsigned)b[j] << 16;
+        memcpy(&av[j], &ua, 4); memcpy(&bv[j], &ub, 4);
+    }
+    return hipemu_mfma_32x32x16_generic(av, bv, c);
+}
+
 /* ---- host runtime shim: synchronous, "device" memory is host memory ---- */
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
     hipemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })

@@ -104,3 +104,38 @@ def test_repack_after_parameter_update():
         mg.decode_conv6[1].bias.add_(0.5)            # in-place edit bumps the version counter
         y1 = mg(xg)
     assert float((y1 - y0).mean()) == pytest.approx(0.5, abs=1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol,mtol", [(torch.float16, 4e-3, 2e-3), (torch.bfloat16, 3e-2, 1e-2)])
+def test_16bit_storage_golden_case(dtype, tol, mtol):
+    """fp16 / bf16 activation + pointwise-weight storage with fp32 accumulation (BASELINE.json configs 3-5 run in 16 bit).
+    The 1e-3 criterion is an fp32 criterion: the REFERENCE itself drifts by 9e-4 (fp16) / 7.6e-3 (bf16) max-rel when its module is
+    cast to 16 bit on CPU; bounds here: element-wise `tol`, depth metrics within `mtol` relative."""
+    m, x, y_ref, meta = inputs.golden_case("base_s0")
+    m = m.cuda().set_compute_dtype(dtype)
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert y.dtype == torch.float32
+    assert harness.rel_err(y.cpu().numpy(), y_ref.numpy()) < tol
+    got = metrics.evaluate(y[:1].cpu().numpy(), inputs.load_sample()[1].numpy())
+    want = meta["metrics_vs_sample_depth"]
+    for k in ("rmse", "mae", "absrel", "delta1"):
+        assert abs(got[k] - want[k]) <= mtol * max(abs(want[k]), 1e-6) + 1e-6, (k, got[k], want[k])
+    m.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        assert harness.rel_err(m(x.cuda()).cpu().numpy(), y_ref.numpy()) < TOL      # switching back re-plans in fp32
+
+
+def test_pruned_fp16_batch64_config5():
+    """BASELINE.json configs[4]: pruned plan (irregular channel counts, multiples of 8), batch 64, fp16."""
+    models = inputs.product_models()
+    torch.manual_seed(11)
+    m = harness.randomize_bn(models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS), 12).eval()
+    x = inputs.batch_variants(inputs.load_sample()[0], 64, seed=4)
+    yo = oracle.forward(m.state_dict(), x[:6].numpy())
+    mg = m.cuda().set_compute_dtype(torch.float16)
+    with torch.no_grad():
+        y = mg(x.cuda())
+    assert harness.rel_err(y[:6].cpu().numpy(), yo) < 1e-2
+    err, per_layer, info = harness.compare_with_oracle("hip", m.cpu(), x[:2], torch.device("cuda"), dtype=torch.float16)
+    assert max(per_layer) < 2e-2, [(i, e, info[i]) for i, e in enumerate(per_layer) if e >= 2e-2]

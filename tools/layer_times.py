@@ -6,11 +6,11 @@ sys.path.insert(0, os.path.join(REPO, "fast-depth_amd")); sys.path.insert(0, REP
 import numpy as np, torch
 import models
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--pruned", action="store_true"); a = ap.parse_args()
+ap.add_argument("--pruned", action="store_true"); ap.add_argument("--dtype", default="f32"); a = ap.parse_args()
 torch.manual_seed(0)
 m = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if a.pruned else None).eval().cuda()
 x = torch.rand(a.batch, 3, 224, 224, device="cuda")
-eng = m._engine()
+eng = m._engine(); eng.set_dtype({"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[a.dtype])
 with torch.no_grad():
     for _ in range(3): m(x)
     torch.cuda.synchronize()
