@@ -7,6 +7,7 @@
 // caller's stream with no host-side decisions, allocations or synchronisation in between.
 #include "fd_kernels_f32.h"
 #include "fd_kernels_h16.h"
+#include "fd_kernels_fused_f32.h"
 #include "../../include/fastdepth_hip.h"
 
 #include <algorithm>
@@ -15,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #ifndef FD_EMU
@@ -68,6 +70,9 @@ struct Layer {
     bool pw_packed_t = false;    // packed weights are 16-bit (pointwise layers of a 16-bit plan)
     // dw tiling
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0;
+    bool skipped = false;        // depthwise layer executed inside the following pointwise layer's fused kernel
+    int fused_dw = -1;           // pointwise layer: index of the depthwise layer fused into it
+    int np = 0, flat = 0, gpw = 0;   // fused kernel: patch pixels, tile mapping, LDS-DMA instructions per wave per chunk
     bool dw_rows = false;        // register-window 3x3 kernel (fd_dw3_rows_f32) instead of the LDS-tiled one
     // stem
     int chunk = 0;
@@ -224,6 +229,24 @@ int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias
     return check_launch("fd_pw_gemm_f32");
 }
 
+template <int K, int ACT2>
+int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *in, const float *wdw, const float *bdw, const float *wp,
+                 const float *bias, float *out, hipStream_t s)
+{
+    const int C = L.d.cin;
+#define FD_SEP(A1, G)                                                                                                             \
+    do {                                                                                                                          \
+        (void)hipFuncSetAttribute((const void *)fd_sep_unit_f32<K, A1, ACT2, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        FD_LAUNCH((fd_sep_unit_f32<K, A1, ACT2, G>), L.grid, dim3(256), L.lds, s, in, wdw, bdw, wp, bias, out, p->B, D.in_h, D.in_w, C,  \
+                  L.w_pitch, L.d.cout, L.np, L.flat, L.m_tiles, L.n_tiles);                                                       \
+    } while (0)
+#define FD_SEP_G(A1) do { if (L.gpw <= 5) FD_SEP(A1, 5); else if (L.gpw == 6) FD_SEP(A1, 6); else FD_SEP(A1, 7); } while (0)
+    if (D.d.act == FD_ACT_RELU6) FD_SEP_G(FD_ACT_RELU6_); else FD_SEP_G(FD_ACT_RELU_);
+#undef FD_SEP_G
+#undef FD_SEP
+    return check_launch("fd_sep_unit_f32");
+}
+
 template <int ACT>
 int launch_pw_t(const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
 {
@@ -256,6 +279,17 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
             const long npix = (long)p->B * h * w;
             FD_LAUNCH((fd_head_pw1<T, ACT>), L.grid, dim3(256), 0, s, in, wpf, bias, y, npix, h, w, L.d.cin, L.d.upsample);
             return check_launch("fd_head_pw1");
+        }
+        if (L.fused_dw >= 0) {
+            if constexpr (std::is_same<T, float>::value) {
+                const Layer &D = p->layers[L.fused_dw];
+                const float *din = reinterpret_cast<const float *>(p->ws + p->layers[D.d.src].out_off);
+                const float *wdw = reinterpret_cast<const float *>(p->ws + D.w_off), *bdw = reinterpret_cast<const float *>(p->ws + D.b_off);
+                if (D.d.ksize == 3) return launch_sep_k<3, ACT>(p, L, D, din, wdw, bdw, wpf, bias, out, s);
+                return launch_sep_k<5, ACT>(p, L, D, din, wdw, bdw, wpf, bias, out, s);
+            } else {
+                return fail(FD_ERR_INVALID, "fused units are fp32 only");
+            }
         }
         return launch_pw_t<ACT>(L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
     }
@@ -399,19 +433,45 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     last.to_output = true;
     p->weights_bytes = woff;
 
+    // ---- fusion: depthwise (stride 1, input as stored) -> pointwise pairs become ONE kernel (fd_sep_unit_f32) -------------
+    // EXPERIMENTAL, opt-in (FD_PLAN_FUSE_SEPARABLE): measured on MI355X at batch 32 the fused kernel is SLOWER than the two tuned
+    // kernels it replaces (conv7.3: 87 us vs 11.5 + 41 us) -- with M = 6272 rows the depthwise work is recomputed by each of the
+    // N/64 column tiles, and the two phases of a workgroup serialise behind barriers.  Kept for larger batches / future tuning.
+    if (dtype == FD_F32 && (flags & FD_PLAN_FUSE_SEPARABLE) && !(flags & FD_PLAN_KEEP_ACTIVATIONS)) {
+        for (int i = 0; i + 1 < n_layers; ++i) {
+            Layer &D = p->layers[i], &Pw = p->layers[i + 1];
+            if (D.d.op != FD_OP_DW || D.mode != 0 || D.d.stride != 1 || Pw.d.op != FD_OP_PW || Pw.head || Pw.d.src != i) continue;
+            const int P = D.d.ksize / 2, W = D.in_w, H = D.in_h;
+            int np = 0, flat = 0;
+            if (W <= 28 && (64 + 2 * P * (W + 1) + 7) / 8 * 8 <= 128) { flat = 1; np = (64 + 2 * P * (W + 1) + 7) / 8 * 8; }
+            else if (W % 8 == 0 && H % 8 == 0 && ((8 + 2 * P) * (8 + 2 * P) + 7) / 8 * 8 <= 128) { flat = 0; np = ((8 + 2 * P) * (8 + 2 * P) + 7) / 8 * 8; }
+            else continue;
+            D.skipped = true;
+            Pw.fused_dw = i; Pw.np = np; Pw.flat = flat;
+            Pw.pw = PwCfg{2, 2, 1, 1};
+            Pw.m_tiles = flat ? ceil_div((long)batch * H * W, 64) : batch * (H / 8) * (W / 8);
+            Pw.n_tiles = ceil_div(Pw.d.cout, 64);
+            Pw.grid = dim3((unsigned)((Pw.m_tiles + 7) / 8 * 8 * Pw.n_tiles));
+            const int taprows = (D.d.ksize * D.d.ksize + 7) / 8 * 8;
+            Pw.lds = ((size_t)3 * (np * 32 + 64 * 32 + taprows * 32) + 64 * 32 + 256) * 4;   // 3-stage ring + A tile + dump group
+            Pw.gpw = (np / 8 + 8 + taprows / 8 + 3) / 4;
+        }
+    }
+
     // activation arena
     std::vector<int> last_use(n_layers, -1);
     for (int i = 0; i < n_layers; ++i) {
         if (p->layers[i].d.src >= 0) last_use[p->layers[i].d.src] = i;
         if (p->layers[i].d.skip >= 0) last_use[p->layers[i].d.skip] = i;
+        if (p->layers[i].fused_dw >= 0) last_use[p->layers[p->layers[i].fused_dw].d.src] = i;   // the fused kernel reads the depthwise layer's input
     }
     FreeList fl;
     for (int i = 0; i < n_layers; ++i) {
         Layer &L = p->layers[i];
-        if (L.to_output) continue;
+        if (L.to_output || L.skipped) continue;
         if (!(flags & FD_PLAN_KEEP_ACTIVATIONS))
             for (int j = 0; j < i; ++j)
-                if (last_use[j] == i - 1 && !p->layers[j].to_output) fl.release(p->layers[j].out_off - woff, p->layers[j].out_bytes);
+                if (last_use[j] == i - 1 && !p->layers[j].to_output && !p->layers[j].skipped) fl.release(p->layers[j].out_off - woff, p->layers[j].out_bytes);
         // (a buffer whose last reader is layer i-1 is free from layer i on; readers of layer i keep theirs)
         L.out_off = woff + fl.alloc(L.out_bytes);
     }
@@ -433,7 +493,12 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         L.alg_flops = 2.0 * batch * mac_px * d.cout * taps;
         p->alg_flops += L.alg_flops;
         char buf[256];
-        if (d.op == FD_OP_STEM)
+        if (L.skipped)
+            snprintf(buf, sizeof buf, "(fused into layer %d)", i + 1);
+        else if (L.fused_dw >= 0)
+            snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
+                     L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
+        else if (d.op == FD_OP_STEM)
             snprintf(buf, sizeof buf, "stem3x3s2<chunk %d> grid=%u lds=%zu", L.chunk, L.grid.x, L.lds);
         else if (d.op == FD_OP_DW && L.dw_rows)
             snprintf(buf, sizeof buf, "dw3_rows<s%d> rows/item %d grid=%ux%ux%u", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
@@ -447,7 +512,9 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                      L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         L.info = buf;
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
-        if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
+        if (L.skipped) buf[0] = 0;
+        else if (L.fused_dw >= 0) snprintf(buf, sizeof buf, "fd_sep_unit_f32<%d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.act, d.act, L.gpw <= 5 ? 5 : (L.gpw == 6 ? 6 : 7));
+        else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
@@ -510,6 +577,7 @@ int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)
     if (!plan->ws || !plan->packed) return fail(FD_ERR_STATE, "plan needs a bound workspace and packed weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (const Layer &L : plan->layers) {
+        if (L.skipped) continue;
         int rc = run_layer(plan, L, static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
         if (rc) return rc;
     }
@@ -530,13 +598,16 @@ int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, f
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
     int rc = FD_OK;
     for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
+        if (plan->layers[i].skipped) continue;
         g_ev_start = ev[2 * i]; g_ev_stop = ev[2 * i + 1];
         rc = run_layer(plan, plan->layers[i], static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
     }
     g_ev_start = g_ev_stop = nullptr;
     if (rc == FD_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(FD_ERR_HIP, "hipStreamSynchronize failed");
-    for (int i = 0; i < n_layers && rc == FD_OK; ++i)
+    for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
+        if (plan->layers[i].skipped) { ms_per_layer[i] = 0.0f; continue; }
         if (hipEventElapsedTime(&ms_per_layer[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
+    }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 #endif
@@ -548,6 +619,7 @@ int fd_layer_output(const fd_plan *plan, int32_t layer, const void **device_ptr,
     if (!(plan->flags & FD_PLAN_KEEP_ACTIVATIONS)) return fail(FD_ERR_STATE, "plan was not created with FD_PLAN_KEEP_ACTIVATIONS");
     const Layer &L = plan->layers[layer];
     if (L.to_output) return fail(FD_ERR_STATE, "the last layer writes the caller's output buffer");
+    if (L.skipped) return fail(FD_ERR_STATE, "layer %d is fused into its consumer and has no stored output", layer);
     if (!plan->ws) return fail(FD_ERR_STATE, "no workspace bound");
     if (device_ptr) *device_ptr = plan->ws + L.out_off;
     if (n) *n = plan->B;
@@ -557,7 +629,7 @@ int fd_layer_output(const fd_plan *plan, int32_t layer, const void **device_ptr,
     return FD_OK;
 }
 
-int32_t fd_plan_num_kernels(const fd_plan *plan) { return plan ? (int32_t)plan->layers.size() : 0; }
+int32_t fd_plan_num_kernels(const fd_plan *plan) { return plan ? (int32_t)plan->layers.size() : 0; }   /* = number of layers; fused-away layers report an empty symbol */
 
 const char *fd_plan_kernel_info(const fd_plan *plan, int32_t layer)
 {
@@ -577,8 +649,12 @@ double fd_plan_algorithmic_flops(const fd_plan *plan) { return plan ? plan->alg_
 int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_bytes, double *algorithmic_flops)
 {
     if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return fail(FD_ERR_INVALID, "bad layer index");
-    if (algorithmic_bytes) *algorithmic_bytes = plan->layers[layer].alg_bytes;
-    if (algorithmic_flops) *algorithmic_flops = plan->layers[layer].alg_flops;
+    // the per-unit convention of SURVEY.md 8(d) is kept: a fused launch is credited with both of its units' algorithmic work
+    const Layer &L = plan->layers[layer];
+    double b = L.skipped ? 0.0 : L.alg_bytes, f = L.skipped ? 0.0 : L.alg_flops;
+    if (L.fused_dw >= 0) { b += plan->layers[L.fused_dw].alg_bytes; f += plan->layers[L.fused_dw].alg_flops; }
+    if (algorithmic_bytes) *algorithmic_bytes = b;
+    if (algorithmic_flops) *algorithmic_flops = f;
     return FD_OK;
 }
 

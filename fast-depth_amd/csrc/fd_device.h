@@ -18,6 +18,7 @@
 inline void fd_glds16(const float *g, float *lds_wave_base) { memcpy((char *)lds_wave_base + hipemu::lane_id() * 16, g, 16); }
 template <int N> inline void fd_wait_vmcnt() {}
 #define FD_SCHED_FENCE() ((void)0)
+inline void fd_block_barrier_lds() { __syncthreads(); }
 inline void fd_block_barrier() { __syncthreads(); }
 #else
 __device__ __forceinline__ void fd_glds16(const float *g, float *lds_wave_base)
@@ -31,6 +32,8 @@ template <int N> __device__ __forceinline__ void fd_wait_vmcnt() { asm volatile(
 #define FD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // raw s_barrier: unlike __syncthreads() it does not drain vmcnt, so LDS-DMA loads stay in flight across it
 __device__ __forceinline__ void fd_block_barrier() { __builtin_amdgcn_s_barrier(); }
+// the same, after this wave's own LDS writes/reads have completed (lgkmcnt) -- still without draining vector-memory loads
+__device__ __forceinline__ void fd_block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #endif
 
 typedef float fd_f32x4 __attribute__((ext_vector_type(4)));

@@ -9,6 +9,7 @@ FD_F32, FD_F16, FD_BF16 = 0, 1, 2
 FD_OP_STEM, FD_OP_DW, FD_OP_PW = 0, 1, 2
 FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
 FD_PLAN_KEEP_ACTIVATIONS = 1
+FD_PLAN_FUSE_SEPARABLE = 4
 
 
 class LayerDesc(ctypes.Structure):

@@ -53,6 +53,7 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 
 /* plan flags */
 #define FD_PLAN_KEEP_ACTIVATIONS 1u /* one private buffer per layer output (needed for fd_layer_output); default: lifetime-based reuse */
+#define FD_PLAN_FUSE_SEPARABLE 4u   /* experimental: run depthwise(stride 1)+pointwise pairs as ONE kernel (fd_sep_unit_f32); measured slower at batch 32 */
 
 typedef struct fd_layer_desc {
     int32_t op;       /* enum fd_op */

@@ -29,7 +29,7 @@ def get_lib(kind):
 class CPlan:
     """fd_plan + workspace for `model` at x's shape on x's device."""
 
-    def __init__(self, kind, model, x, keep=True, dtype=torch.float32):
+    def __init__(self, kind, model, x, keep=True, dtype=torch.float32, flags=0):
         self.lib = L = get_lib(kind)
         self.kind, self.model, self.dev = kind, model, x.device
         self.dtype = dtype
@@ -39,7 +39,7 @@ class CPlan:
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         self.h = ctypes.c_void_p()
         b, _, hh, ww = x.shape
-        capi.check(L, L.fd_plan_create(descs, n, b, hh, ww, fd_dtype, capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0,
+        capi.check(L, L.fd_plan_create(descs, n, b, hh, ww, fd_dtype, (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | flags,
                                        ctypes.byref(self.h)), "fd_plan_create")
         nbytes = L.fd_plan_workspace_bytes(self.h)
         self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)

@@ -51,3 +51,21 @@ def test_emulated_16bit_forward_matches_oracle(name, plan, dtype, tol):
     err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), dtype=dtype)
     assert err < tol, (err, max(per_layer))
     assert max(per_layer) < 4 * tol, [(i, e, info[i]) for i, e in enumerate(per_layer) if e >= 4 * tol]
+
+
+@pytest.mark.parametrize("name,plan,hw", [("tiny", TINY, (64, 64)), ("ragged", RAGGED, (64, 64)), ("tiny_rect", TINY, (32, 96)), ("tiny128", TINY, (128, 128))])
+def test_emulated_fused_separable_units(name, plan, hw):
+    """Opt-in plans (FD_PLAN_FUSE_SEPARABLE) fuse depthwise(stride 1) + pointwise pairs into fd_sep_unit_f32 (flat-64 tiles on small
+    maps, 8x8 tiles on maps whose sides are multiples of 8).  Checked against the oracle relative to the output's RANGE (the head bias dominates max|y|)."""
+    import numpy as np
+    from oracle import oracle
+    m = small_model(plan[0], plan[1], seed=1).eval()
+    m.decode_conv6[1].bias.data.fill_(1.0)
+    x = torch.rand(1 if hw[0] > 64 else 2, 3, *hw, generator=torch.Generator().manual_seed(2))
+    yo = oracle.forward(m.state_dict(), x.numpy())
+    cp = harness.CPlan("emu", m, x, keep=False, flags=harness.capi.FD_PLAN_FUSE_SEPARABLE)
+    info = cp.info()
+    y = cp.forward(x).numpy()
+    cp.close()
+    assert sum("sep_unit" in i for i in info) == 10 and sum("fused into" in i for i in info) == 10
+    assert float(np.abs(y - yo).max()) / float(yo.max() - yo.min()) < 1e-4
