@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the host-CPU baseline sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10, help="instrumented steps for the per-kernel roofline")
+    ap.add_argument("--extra-steps", type=int, default=30, help="timed steps for each entry of `other_configs` (pruned fp16 B=64, "
+                    "bf16 / fp16 B=32, fp32 B=1 latency); 0 disables")
     ap.add_argument("--train-steps", type=int, default=20, help="timed fp32 train steps (fwd + L1 + bwd [+ RCCL all-reduce] + SGD) reported as "
                     "`train_step`; 0 disables")
     args = ap.parse_args()
@@ -103,7 +105,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FD_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL code path on one rank
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -177,7 +179,8 @@ def main():
         tm = models.MobileNetSkipAdd((224, 224), pretrained=False)
         tm.decode_conv6[1].bias.data.fill_(2.8)
         tm = tm.to(dev).train()
-        teng = TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None))
+        teng = TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
+                           force_buckets=os.environ.get("FD_BENCH_FORCE_DIST") == "1")
         tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=g)).to(dev)     # synthetic depth, U[0.7, 10) m
         for _ in range(3):
             loss = teng.step(x, tgt)
@@ -200,6 +203,42 @@ def main():
                                 if world > 1 else "single GPU", "final_loss": round(float(loss), 5)}
         del teng, tm
 
+    # ---- other BASELINE.json configurations, measured briefly on rank 0 only (N=1): parity for them is in tests/test_gpu_parity.py
+    extras = []
+    if args.extra_steps > 0 and world == 1:
+        import models
+
+        def timed(mod, xin, steps, fn=None):
+            fn = fn or (lambda: mod(xin))
+            with torch.no_grad():
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / steps
+
+        torch.manual_seed(0)
+        pm = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS).eval().to(dev)
+        x64 = torch.rand(64, 3, 224, 224, generator=g).to(dev)
+        pm.set_compute_dtype(torch.float16)
+        dt = timed(pm, x64, args.extra_steps)
+        extras.append({"config": "configs[4]: pruned plan (mobilenet-nnconv5dw-skipadd-pruned), batch=64, fp16 storage / fp32 accumulate, inference",
+                       "value": round(64 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f16"})
+        for dtype, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+            model.set_compute_dtype(dtype)
+            dt = timed(model, x, args.extra_steps)
+            extras.append({"config": "unpruned, batch=32, %s storage / fp32 accumulate, inference" % tag, "value": round(args.batch / dt, 1),
+                           "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": tag})
+        model.set_compute_dtype(torch.float32)
+        x1 = x[:1].contiguous()
+        dt = timed(model, x1, args.extra_steps, fn=lambda: eng.forward_graph(x1))
+        extras.append({"config": "unpruned, batch=1, fp32, hipGraph replay (latency; the reference publishes 5.6 ms for the PRUNED model on a Jetson TX2)",
+                       "value": round(1 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f32"})
+        del pm
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = {
@@ -218,6 +257,7 @@ def main():
                            "roofline_bound_ms": None},
             "kernels": kernels,
             "train_step": train,
+            "other_configs": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds)

@@ -19,6 +19,9 @@
 
 // coefficient table [4][C] of the BatchNorm backward, written in the cancellation-free form
 //   dz = A * ((G - C1) - (z - MU) * C2),   A = gamma*invstd,  C1 = dbeta/n,  MU = batch mean,  C2 = invstd * dgamma / n
+#ifndef FD_BWD_STAGES
+#define FD_BWD_STAGES 2     // LDS ring depth of the backward GEMMs: 2 stages = 48 KiB -> 3 workgroups per CU (measured faster than 3 stages / 2 per CU)
+#endif
 #define FD_CF_A 0
 #define FD_CF_C1 1
 #define FD_CF_MU 2
@@ -252,7 +255,7 @@ fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int N32 = (N + 31) / 32 * 32;
-    float *tab = smem + 3 * STAGE;                             // [4][N32] coefficient table (zero beyond N)
+    float *tab = smem + FD_BWD_STAGES * STAGE;                 // [4][N32] coefficient table (zero beyond N)
     float *red = tab + 4 * N32;                                // [2][2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
@@ -282,7 +285,7 @@ fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
         src_w[i] = Wt + kc;
     }
     auto issue = [&](int t) {
-        float *dst = smem + (t % 3) * STAGE;
+        float *dst = smem + (t % FD_BWD_STAGES) * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int n = t * BR + chunk_gz[i]; if (n >= N) n = 0;
@@ -306,12 +309,12 @@ fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
     const int T = N32 / BR;
     __syncthreads();
     issue(0);
-    if (T > 1) issue(1);
+    if (FD_BWD_STAGES > 2 && T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
+        if (FD_BWD_STAGES > 2 && t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
-        if (t + 2 < T) issue(t + 2);
-        const float *cur = smem + (t % 3) * STAGE;
+        if (t + FD_BWD_STAGES - 1 < T) issue(t + FD_BWD_STAGES - 1);
+        const float *cur = smem + (t % FD_BWD_STAGES) * STAGE;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int nb = (2 * g + h) * 4;                     // this lane's 4 reduction indices within the tile
@@ -388,7 +391,7 @@ fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
         colg[i] = cn; colk[i] = ck;
     }
     auto issue = [&](int t) {
-        float *dst = smem + (t % 3) * STAGE;
+        float *dst = smem + (t % FD_BWD_STAGES) * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             long m = mbeg + (long)t * BR + rowi[i]; if (m > M - 1) m = M - 1;
@@ -409,12 +412,12 @@ fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
     const int hh = lane >> 5;
     const int acol = wn * 32 + (lane & 31), bcol = wk * 32 + (lane & 31);
     if (T > 0) issue(0);
-    if (T > 1) issue(1);
+    if (FD_BWD_STAGES > 2 && T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
+        if (FD_BWD_STAGES > 2 && t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
-        if (t + 2 < T) issue(t + 2);
-        const float *cur = smem + (t % 3) * STAGE;
+        if (t + FD_BWD_STAGES - 1 < T) issue(t + FD_BWD_STAGES - 1);
+        const float *cur = smem + (t % FD_BWD_STAGES) * STAGE;
         const long mrow = mbeg + (long)t * BR;
 #pragma unroll
         for (int j = 0; j < BR / 2; ++j) {

@@ -113,7 +113,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         splits = ceil_div(M, rows);
         const size_t need = (size_t)splits * N * K * 4;
         if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
-        const size_t lds = (size_t)3 * 3 * 32 * 64 * 4;
+        const size_t lds = (size_t)FD_BWD_STAGES * 3 * 32 * 64 * 4;
         (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds, c.s, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
@@ -129,7 +129,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     {
         const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
         const int N32 = (N + 31) / 32 * 32;
-        const size_t lds = ((size_t)3 * (2 * 64 * 32 + 32 * 64) + 4 * N32 + 256) * 4;
+        const size_t lds = ((size_t)FD_BWD_STAGES * (2 * 64 * 32 + 32 * 64) + 4 * N32 + 256) * 4;
         const bool add = P.skip_consumer >= 0;
         dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * k_tiles));
         if (add) {

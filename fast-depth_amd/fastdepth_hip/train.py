@@ -180,7 +180,7 @@ class TrainEngine(TrainCore):
     step is: local forward/backward on this rank's sub-batch; the flat gradient buffer is all-reduced (sum) bucket by bucket
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
-    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4):
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4, force_buckets=False):
         super().__init__(model)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.group = process_group
@@ -198,8 +198,9 @@ class TrainEngine(TrainCore):
             off += p.numel()
         self.sgd_table = torch.tensor(rec, dtype=torch.int64).to(self.device)
         self.layer_bytes = [4 * (self.layer_span[i][1] - self.layer_span[i][0]) for i in range(self.n)]
-        self.buckets = make_buckets(self.layer_bytes, n_buckets if self.world > 1 else 1)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self.use_comm = process_group is not None and (self.world > 1 or force_buckets)     # force_buckets: exercise the path on 1 rank
+        self.buckets = make_buckets(self.layer_bytes, n_buckets if self.use_comm else 1)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_comm else None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dpred = None
         self._scratch = torch.empty(lib().fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
@@ -221,13 +222,13 @@ class TrainEngine(TrainCore):
             works = []
             for from_layer, to_layer in self.buckets:
                 self.backward_range(self._dpred, from_layer, to_layer)
-                if self.world > 1:
+                if self.use_comm:
                     ev = torch.cuda.Event()
                     ev.record(cur)
                     self.comm_stream.wait_event(ev)
                     with torch.cuda.stream(self.comm_stream):
                         works.append(self.dist.all_reduce(self.bucket_slice(from_layer, to_layer), group=self.group, async_op=True))
-            if self.world > 1:
+            if self.use_comm:
                 for w in works:
                     w.wait()                       # makes the current stream wait for the collective (no host sync)
                 cur.wait_stream(self.comm_stream)
