@@ -135,6 +135,54 @@ fd_l1_loss_final_f32(const float *__restrict__ part, int nblk, float inv_numel, 
     if (threadIdx.x == 0) loss[0] = f * inv_numel;
 }
 
+// ---- depth metrics (row f-2): every sum of reference metrics.py:31-55 in ONE pass, no per-scalar host synchronisation --------
+// sums[0] = #valid, [1] = sum ad^2, [2] = sum ad, [3] = sum |log10 o - log10 t|, [4] = sum ad/t, [5..7] = #(maxRatio < 1.25^k),
+// [8] = sum (1/o - 1/t)^2, [9] = sum |1/o - 1/t|;  valid = (target > 0) or (output > 0), o = 1e3*output, t = 1e3*target (mm).
+__global__ void __launch_bounds__(256)
+fd_depth_metrics_f32(const float *__restrict__ output, const float *__restrict__ target, long numel, double *__restrict__ part)
+{
+    __shared__ double red[4][10];
+    double s[10];
+    for (int k = 0; k < 10; ++k) s[k] = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const float ov = output[i], tv = target[i];
+        if (tv > 0.0f || ov > 0.0f) {
+            const float o = 1e3f * ov, t = 1e3f * tv;
+            const float ad = fabsf(o - t);
+            const float ratio = fmaxf(o / t, t / o);
+            const float inv = fabsf(1.0f / o - 1.0f / t);
+            s[0] += 1.0; s[1] += (double)(ad * ad); s[2] += ad;
+            s[3] += fabsf(logf(o) / 2.302585093f - logf(t) / 2.302585093f);
+            s[4] += ad / t;
+            s[5] += ratio < 1.25f ? 1.0 : 0.0; s[6] += ratio < 1.5625f ? 1.0 : 0.0; s[7] += ratio < 1.953125f ? 1.0 : 0.0;
+            s[8] += (double)(inv * inv); s[9] += inv;
+        }
+    }
+    // fixed-order reduction: lanes -> wave (shuffles on the two 32-bit halves of each double), waves -> block
+    for (int k = 0; k < 10; ++k) {
+        double v = s[k];
+        for (int m = 1; m < 64; m <<= 1) {
+            unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            float lo = __builtin_bit_cast(float, (unsigned)(u & 0xffffffffu)), hi = __builtin_bit_cast(float, (unsigned)(u >> 32));
+            lo = __shfl_xor(lo, m); hi = __shfl_xor(hi, m);
+            const unsigned long long w = ((unsigned long long)__builtin_bit_cast(unsigned, hi) << 32) | __builtin_bit_cast(unsigned, lo);
+            v += __builtin_bit_cast(double, w);
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) part[(long)blockIdx.x * 10 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(64)
+fd_depth_metrics_final_f32(const double *__restrict__ part, int nblk, double *__restrict__ sums)
+{
+    if (threadIdx.x < 10) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += part[(long)b * 10 + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+}
+
 // ---- fused multi-tensor SGD ------------------------------------------------------------------------------------------
 struct fd_sgd_rec { float *param; const float *grad; float *buf; long numel; };
 __global__ void __launch_bounds__(256)

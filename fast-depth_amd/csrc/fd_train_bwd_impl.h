@@ -235,6 +235,20 @@ int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, 
     return FD_OK;
 }
 
+size_t fd_depth_metrics_scratch_bytes(void) { return (size_t)1024 * 10 * sizeof(double); }
+
+int fd_depth_metrics(const void *output, const void *target, int64_t numel, double *sums_device, void *scratch, void *stream)
+{
+    if (!output || !target || !sums_device || !scratch || numel <= 0) return fail(FD_ERR_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::min<int64_t>(1024, (numel + 255) / 256);
+    FD_LAUNCH(fd_depth_metrics_f32, dim3(nb), dim3(256), 0, s, static_cast<const float *>(output), static_cast<const float *>(target), (long)numel, static_cast<double *>(scratch));
+    int rc = check_launch("fd_depth_metrics_f32");
+    if (rc) return rc;
+    FD_LAUNCH(fd_depth_metrics_final_f32, dim3(1), dim3(64), 0, s, static_cast<const double *>(scratch), nb, sums_device);
+    return check_launch("fd_depth_metrics_final_f32");
+}
+
 size_t fd_l1_loss_scratch_bytes(int64_t numel) { (void)numel; return 1024 * sizeof(float); }
 
 int fd_l1_loss(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream)

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Evaluation harness with the reference's CLI and printout (reference main.py:26-127, utils.py:12-34), for the MI355X path.
+
+    python3 evaluate.py --evaluate [path_to_trained_model] [--gpu N] [-p FREQ] [--batch-size B] [--samples DIR|FILE.npz]
+
+Differences from the reference, all deliberate:
+  * `t_GPU` is measured with the device synchronised (the reference's synchronize() calls are commented out at main.py:69,76,
+    so it prints launch latency);
+  * any batch size (the reference validates with batch 1, main.py:40-41);
+  * metrics come from ONE fused device reduction per batch (metrics.py of this package) instead of ~12 host syncs;
+  * the NYU-Depth-v2 HDF5 loader is not rebuilt (dataset absent, h5py absent; dataloaders/ depends on removed SciPy/NumPy
+    APIs): samples are `.npz` files holding `rgb` ([H,W,3] uint8 or float in [0,1]) and `depth` ([H,W] float32 metres) already at
+    the network resolution, or -- by default -- the reference's own shipped sample (deploy/data) replicated.
+A checkpoint is the reference's pickle ({'epoch','best_result','model'} or a bare module, main.py:49-57); without one, a seeded
+random-weight model is evaluated (useful only as a smoke test of the loop).
+"""
+import argparse
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+import models  # noqa: E402
+from metrics import AverageMeter, Result  # noqa: E402
+
+
+def parse_command(argv=None):
+    parser = argparse.ArgumentParser(description='FastDepth (MI355X path)')
+    parser.add_argument('--data', metavar='DATA', default='nyudepthv2', choices=['nyudepthv2'],
+                        help='dataset: nyudepthv2 (default: nyudepthv2)')
+    parser.add_argument('--modality', '-m', metavar='MODALITY', default='rgb', choices=['rgb'], help='modality: rgb (default: rgb)')
+    parser.add_argument('-j', '--workers', default=16, type=int, metavar='N', help='accepted for CLI compatibility; samples are read in-process')
+    parser.add_argument('--print-freq', '-p', default=50, type=int, metavar='N', help='print frequency (default: 50)')
+    parser.add_argument('-e', '--evaluate', default='', type=str, metavar='PATH')
+    parser.add_argument('--gpu', default='0', type=str, metavar='N', help="gpu id")
+    parser.add_argument('--batch-size', default=1, type=int)
+    parser.add_argument('--samples', default='', help='directory of .npz samples or one .npz file (default: the reference sample)')
+    parser.add_argument('--repeat', default=8, type=int, help='how many times the default sample is replicated')
+    parser.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'], help='activation storage inside the engine')
+    return parser.parse_args(argv)
+
+
+def load_samples(args):
+    files = []
+    if args.samples:
+        files = sorted(glob.glob(os.path.join(args.samples, '*.npz'))) if os.path.isdir(args.samples) else [args.samples]
+    if files:
+        out = []
+        for f in files:
+            z = np.load(f)
+            rgb = z['rgb'].astype(np.float32)
+            if rgb.max() > 1.5:
+                rgb = rgb / 255.0
+            out.append((torch.from_numpy(rgb).permute(2, 0, 1).contiguous(), torch.from_numpy(z['depth'].astype(np.float32))[None]))
+        return out
+    gold = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+    rgb = np.load(os.path.join(gold, 'sample_rgb_u8.npy')).astype(np.float64) / 255.0
+    depth = np.load(os.path.join(gold, 'sample_depth.npy'))
+    one = (torch.from_numpy(rgb).permute(2, 0, 1).float().contiguous(), torch.from_numpy(depth)[None])
+    return [one] * args.repeat
+
+
+def validate(samples, model, args, device):
+    """The reference's validate() loop (main.py:63-119) over in-memory samples."""
+    average_meter = AverageMeter()
+    model.eval()
+    n_batches = (len(samples) + args.batch_size - 1) // args.batch_size
+    end = time.time()
+    for i in range(n_batches):
+        chunk = samples[i * args.batch_size:(i + 1) * args.batch_size]
+        inp = torch.stack([c[0] for c in chunk]).to(device, non_blocking=True)
+        target = torch.stack([c[1] for c in chunk]).to(device, non_blocking=True)
+        torch.cuda.synchronize(device)
+        data_time = time.time() - end
+        end = time.time()
+        with torch.no_grad():
+            pred = model(inp)
+        torch.cuda.synchronize(device)
+        gpu_time = time.time() - end
+        result = Result()
+        result.evaluate(pred.data, target.data)
+        average_meter.update(result, gpu_time, data_time, inp.size(0))
+        end = time.time()
+        if (i + 1) % args.print_freq == 0:
+            print('Test: [{0}/{1}]\t'
+                  't_GPU={gpu_time:.3f}({average.gpu_time:.3f})\n\t'
+                  'RMSE={result.rmse:.2f}({average.rmse:.2f}) '
+                  'MAE={result.mae:.2f}({average.mae:.2f}) '
+                  'Delta1={result.delta1:.3f}({average.delta1:.3f}) '
+                  'REL={result.absrel:.3f}({average.absrel:.3f}) '
+                  'Lg10={result.lg10:.3f}({average.lg10:.3f}) '.format(
+                      i + 1, n_batches, gpu_time=gpu_time, result=result, average=average_meter.average()))
+    avg = average_meter.average()
+    print('\n*\n'
+          'RMSE={average.rmse:.3f}\n'
+          'MAE={average.mae:.3f}\n'
+          'Delta1={average.delta1:.3f}\n'
+          'REL={average.absrel:.3f}\n'
+          'Lg10={average.lg10:.3f}\n'
+          't_GPU={time:.3f}\n'.format(average=avg, time=avg.gpu_time))
+    return avg
+
+
+def main(argv=None):
+    args = parse_command(argv)
+    print(args)
+    device = torch.device('cuda', int(args.gpu))
+    if args.evaluate:
+        assert os.path.isfile(args.evaluate), "=> no model found at '{}'".format(args.evaluate)
+        print("=> loading model '{}'".format(args.evaluate))
+        checkpoint = torch.load(args.evaluate, weights_only=False)
+        if type(checkpoint) is dict:
+            print("=> loaded best model (epoch {})".format(checkpoint.get('epoch')))
+            model = checkpoint['model']
+        else:
+            model = checkpoint
+    else:
+        print("=> no checkpoint given: evaluating a seeded random-weight model (loop smoke test)")
+        torch.manual_seed(0)
+        model = models.MobileNetSkipAdd((224, 224), pretrained=False)
+        model.decode_conv6[1].bias.data.fill_(2.8)
+    model = model.to(device)
+    if args.dtype != 'f32':
+        model.set_compute_dtype({'f16': torch.float16, 'bf16': torch.bfloat16}[args.dtype])
+    return validate(load_samples(args), model, args, device)
+
+
+if __name__ == '__main__':
+    main()

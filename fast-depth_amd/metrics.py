@@ -1,0 +1,89 @@
+"""Drop-in `metrics` module (reference /root/reference/metrics.py): `Result` and `AverageMeter` with the same fields and
+methods, but `Result.evaluate(output, target)` is ONE fused device reduction (fd_depth_metrics) followed by a single 80-byte
+device->host copy, instead of the reference's ~12 `float(tensor)` synchronisations per sample (metrics.py:38-55).
+SURVEY.md row f-2.  As everywhere in this package there is no CPU path: both tensors must live on the GPU."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+
+class Result(object):
+    def __init__(self):
+        self.irmse, self.imae = 0, 0
+        self.mse, self.rmse, self.mae = 0, 0, 0
+        self.absrel, self.lg10 = 0, 0
+        self.delta1, self.delta2, self.delta3 = 0, 0, 0
+        self.data_time, self.gpu_time = 0, 0
+
+    def set_to_worst(self):
+        self.irmse, self.imae = np.inf, np.inf
+        self.mse, self.rmse, self.mae = np.inf, np.inf, np.inf
+        self.absrel, self.lg10 = np.inf, np.inf
+        self.delta1, self.delta2, self.delta3 = 0, 0, 0
+        self.data_time, self.gpu_time = 0, 0
+
+    def update(self, irmse, imae, mse, rmse, mae, absrel, lg10, delta1, delta2, delta3, gpu_time, data_time):
+        self.irmse, self.imae = irmse, imae
+        self.mse, self.rmse, self.mae = mse, rmse, mae
+        self.absrel, self.lg10 = absrel, lg10
+        self.delta1, self.delta2, self.delta3 = delta1, delta2, delta3
+        self.data_time, self.gpu_time = data_time, gpu_time
+
+    def evaluate(self, output, target):
+        """Same definitions as reference metrics.py:31-55 (valid = target>0 or output>0, millimetres, delta_k thresholds 1.25^k)."""
+        from fastdepth_hip import capi
+        from fastdepth_hip.engine import lib
+        if not (output.is_cuda and target.is_cuda):
+            raise RuntimeError("fast-depth_amd metrics run on the GPU only (no CPU path in this package)")
+        o = output.detach().float().contiguous()
+        t = target.detach().float().contiguous()
+        if o.numel() != t.numel():
+            raise ValueError("output and target must have the same number of elements")
+        L = lib()
+        sums = torch.empty(10, dtype=torch.float64, device=o.device)
+        scratch = torch.empty(L.fd_depth_metrics_scratch_bytes(), dtype=torch.uint8, device=o.device)
+        with torch.cuda.device(o.device):
+            capi.check(L, L.fd_depth_metrics(o.data_ptr(), t.data_ptr(), o.numel(), sums.data_ptr(), scratch.data_ptr(),
+                                             torch.cuda.current_stream(o.device).cuda_stream), "fd_depth_metrics")
+        s = sums.cpu().numpy()                      # the single synchronisation
+        n = s[0]
+        self.mse = float(s[1] / n)
+        self.rmse = math.sqrt(self.mse)
+        self.mae = float(s[2] / n)
+        self.lg10 = float(s[3] / n)
+        self.absrel = float(s[4] / n)
+        self.delta1, self.delta2, self.delta3 = float(s[5] / n), float(s[6] / n), float(s[7] / n)
+        self.data_time = 0
+        self.gpu_time = 0
+        self.irmse = math.sqrt(s[8] / n)
+        self.imae = float(s[9] / n)
+
+
+class AverageMeter(object):
+    """n-weighted running sums of Result fields (reference metrics.py:58-95)."""
+    _FIELDS = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.count = 0.0
+        for f in self._FIELDS:
+            setattr(self, "sum_" + f, 0)
+        self.sum_data_time, self.sum_gpu_time = 0, 0
+
+    def update(self, result, gpu_time, data_time, n=1):
+        self.count += n
+        for f in self._FIELDS:
+            setattr(self, "sum_" + f, getattr(self, "sum_" + f) + n * getattr(result, f))
+        self.sum_data_time += n * data_time
+        self.sum_gpu_time += n * gpu_time
+
+    def average(self):
+        avg = Result()
+        c = self.count
+        avg.update(self.sum_irmse / c, self.sum_imae / c, self.sum_mse / c, self.sum_rmse / c, self.sum_mae / c, self.sum_absrel / c,
+                   self.sum_lg10 / c, self.sum_delta1 / c, self.sum_delta2 / c, self.sum_delta3 / c, self.sum_gpu_time / c, self.sum_data_time / c)
+        return avg

@@ -178,6 +178,15 @@ typedef struct fd_sgd_tensor { float *param; const float *grad; float *momentum_
 int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t total_numel, float lr, float momentum,
                 float weight_decay, float grad_scale, int32_t first_step, void *stream);
 
+/* Depth metrics (reference metrics.py:31-55 Result.evaluate): one fused reduction over output/target
+ * (fp32, any shape, `numel` elements) producing the 10 sums from which every metric follows:
+ *   sums[0] #valid, [1] sum ad^2, [2] sum ad, [3] sum |log10 o - log10 t|, [4] sum ad/t, [5..7] #(max(o/t,t/o) < 1.25^k),
+ *   [8] sum (1/o-1/t)^2, [9] sum |1/o-1/t|      with valid = (target>0)|(output>0), o = 1e3*output, t = 1e3*target.
+ * `sums_device` = 10 doubles on the device; `scratch` needs fd_depth_metrics_scratch_bytes() bytes.  The reference issues ~12
+ * device->host synchronisations per sample for the same numbers (one float() per metric). */
+size_t fd_depth_metrics_scratch_bytes(void);
+int fd_depth_metrics(const void *output, const void *target, int64_t numel, double *sums_device, void *scratch, void *stream);
+
 const char *fd_last_error(void);
 const char *fd_version(void);
 

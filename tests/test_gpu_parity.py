@@ -139,3 +139,28 @@ def test_pruned_fp16_batch64_config5():
     assert harness.rel_err(y[:6].cpu().numpy(), yo) < 1e-2
     err, per_layer, info = harness.compare_with_oracle("hip", m.cpu(), x[:2], torch.device("cuda"), dtype=torch.float16)
     assert max(per_layer) < 2e-2, [(i, e, info[i]) for i, e in enumerate(per_layer) if e >= 2e-2]
+
+
+def test_on_device_metrics_and_eval_harness(tmp_path):
+    """Rows f-2 / f-1: the fused metrics kernel reproduces the reference's known answer on its own sample triple, and the
+    main.py-compatible harness runs a reference-format checkpoint end to end."""
+    import sys
+    sys.path.insert(0, inputs.PKG)
+    import metrics as fd_metrics
+    import evaluate as fd_eval
+    pred = torch.from_numpy(np.load(inputs.GOLD + "/sample_tvm_pred.npy")).cuda()
+    depth = inputs.load_sample()[1].cuda()
+    r = fd_metrics.Result()
+    r.evaluate(pred, depth)
+    kat = inputs.golden_meta()["metrics_kat"]
+    for k, v in kat.items():
+        assert getattr(r, k) == pytest.approx(v, rel=5e-6), k
+    with pytest.raises(RuntimeError):
+        r.evaluate(pred.cpu(), depth.cpu())
+    # reference checkpoint format: {'epoch', 'best_result', 'model'} with the module pickled whole (main.py:49-57)
+    m, x, y_ref, meta = inputs.golden_case("base_s0")
+    ck = str(tmp_path / "model_best.pth.tar")
+    torch.save({"epoch": 7, "best_result": None, "model": m}, ck)
+    avg = fd_eval.main(["--evaluate", ck, "--batch-size", "4", "--repeat", "8", "-p", "1"])
+    want = meta["metrics_vs_sample_depth"]
+    assert avg.rmse == pytest.approx(want["rmse"], rel=1e-4) and avg.delta1 == pytest.approx(want["delta1"], rel=1e-4)
