@@ -100,6 +100,9 @@ __device__ __forceinline__ void fd_st4(fd_bf16 *p, fd_f32x4 v)
     fd_u16x4 h = {fd_f32_to_bf16(v.x), fd_f32_to_bf16(v.y), fd_f32_to_bf16(v.z), fd_f32_to_bf16(v.w)};
     *reinterpret_cast<fd_u16x4 *>(p) = h;
 }
+__device__ __forceinline__ float fd_ld1(const float *p) { return *p; }
+__device__ __forceinline__ float fd_ld1(const fd_half *p) { return (float)*p; }
+__device__ __forceinline__ float fd_ld1(const fd_bf16 *p) { return fd_bf16_to_f32(p->v); }
 __device__ __forceinline__ void fd_st1(float *p, float v) { *p = v; }
 __device__ __forceinline__ void fd_st1(fd_half *p, float v) { *p = (_Float16)v; }
 __device__ __forceinline__ void fd_st1(fd_bf16 *p, float v) { p->v = fd_f32_to_bf16(v); }

@@ -1,4 +1,5 @@
-// fd_kernels_bwd_f32.h -- fp32 backward kernels of the FastDepth train step (gfx950).
+// fd_kernels_bwd.h -- backward kernels of the FastDepth train step (gfx950).  T = storage type of the saved z and of the
+// activation gradients G (float or fd_bf16); arithmetic, reductions, tables and parameter gradients are fp32.
 //
 // The train step is not in the reference tree; these kernels implement the autograd of the
 // reference's forward (models.py:706-732 in .train()) by hand:
@@ -15,7 +16,7 @@
 //   Activation masks are strict (ReLU: y > 0; ReLU6: 0 < y < 6), as torch's threshold/hardtanh backward.
 // All reductions are two-stage with a fixed summation order (deterministic).
 #pragma once
-#include "fd_kernels_train_f32.h"
+#include "fd_kernels_train.h"
 
 // coefficient table [4][C] of the BatchNorm backward, written in the cancellation-free form
 //   dz = A * ((G - C1) - (z - MU) * C2),   A = gamma*invstd,  C1 = dbeta/n,  MU = batch mean,  C2 = invstd * dgamma / n
@@ -238,11 +239,11 @@ fd_head_bwd_reduce_f32(const float *__restrict__ dpred, const float *__restrict_
 // ---- head backward, step 2: the 1-channel pointwise conv.  per low-res pixel p, channel k:
 //   dz = A*G + Bc*z + D (scalars, C == 1);  a_in = act_in(z_in*s+t);  dW[k] += dz*a_in;  dA = dz*w[k];
 //   G_in = mask_in(y_in)*dA  (+ BN partials of the producer).  8 lanes share a pixel, PPB pixels per work-item group.
-template <int ACT_IN, int PPB>
+template <typename T, int ACT_IN, int PPB>
 __global__ void __launch_bounds__(256)
-fd_head_bwd_f32(const float *__restrict__ g, const float *__restrict__ zlow, const float *__restrict__ coef,
-                const float *__restrict__ zin, const float *__restrict__ st_in, const float *__restrict__ w,
-                float *__restrict__ g_in, float *__restrict__ part_in, float *__restrict__ wpart, long npix, int Cin)
+fd_head_bwd(const float *__restrict__ g, const float *__restrict__ zlow, const float *__restrict__ coef,
+                const T *__restrict__ zin, const float *__restrict__ st_in, const float *__restrict__ w,
+                T *__restrict__ g_in, float *__restrict__ part_in, float *__restrict__ wpart, long npix, int Cin)
 {
     // work-item (group = tid>>3 in 0..31, l8): channel groups c = l8*4 + 32*j; block covers 32*PPB pixels
     FD_DYN_SMEM(smem_raw);
@@ -260,7 +261,7 @@ fd_head_bwd_f32(const float *__restrict__ g, const float *__restrict__ zlow, con
                 const float dz = fd_dz(g[p], zlow[p], cA, c1, cM, c2);
                 const fd_f32x4 z = fd_ld4(zin + p * Cin + c);
                 const fd_f32x4 y = z * s4 + t4;
-                const fd_f32x4 gi = fd_actmask4<ACT_IN>(y) * (w4 * dz);
+                const fd_f32x4 gi = fd_round4(T{}, fd_actmask4<ACT_IN>(y) * (w4 * dz));
                 fd_st4(g_in + p * Cin + c, gi);
                 sg += gi; sgx += gi * ((z - m4) * i4);
                 sw += fd_act4<ACT_IN>(y) * dz;
@@ -499,11 +500,11 @@ fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
 //   MODE 2: as MODE 1, and skipgrad_out = din at full resolution                   (input was up2(a_in) + a_skip)
 // plus the producer's BN partials  part[blk*2*C + {0,C} + c].
 // ------------------------------------------------------------------------------------------------
-template <int K, int S, int MODE, int ACT_IN, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
 __global__ void __launch_bounds__(256)
-fd_dw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
-                const float *__restrict__ w, const float *__restrict__ Zin, const float *__restrict__ st_in,
-                const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ SGout, float *__restrict__ part,
+fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
+                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x)
 {
     constexpr int P = K / 2;
@@ -584,7 +585,7 @@ fd_dw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
             const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
             if (ADD_SG) v += fd_ld4(SG + o);
             const fd_f32x4 z = fd_ld4(Zin + o);
-            v = v * fd_actmask4<ACT_IN>(z * sc + sh);
+            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
             fd_st4(Gin + o, v);
             ssum += v; ssx += v * ((z - mu) * is);
         }
@@ -603,7 +604,7 @@ fd_dw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
             fd_f32x4 v = (d00 + d01) + (d10 + d11);
             const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg;
             const fd_f32x4 z = fd_ld4(Zin + ol);
-            v = v * fd_actmask4<ACT_IN>(z * sc + sh);
+            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
             fd_st4(Gin + ol, v);
             ssum += v; ssx += v * ((z - mu) * is);
         }
@@ -630,10 +631,10 @@ fd_dw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
 // work-item accumulates the K*K tap sums of its 4 channels over its output strips, the workgroup reduces them through
 // LDS and writes wpart[blk][K*K][C].
 // ------------------------------------------------------------------------------------------------
-template <int K, int S, int MODE, int ACT1, int ACT2>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
 __global__ void __launch_bounds__(256)
-fd_dw_wgrad_f32(const float *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ zskip,
-                const float *__restrict__ st2, const float *__restrict__ G, const float *__restrict__ Z,
+fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
+                const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
                 int cbq, int TH, int TW, int tiles_x)
 {
@@ -752,8 +753,9 @@ fd_dw_wgrad_f32(const float *__restrict__ zin, const float *__restrict__ st1, co
 // Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps; workgroup = 256 pixels.
 // wpart[blk][Cout*27].
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(256)
-fd_stem_wgrad_f32(const float *__restrict__ x, const float *__restrict__ G, const float *__restrict__ Z,
+fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__restrict__ Z,
                   const float *__restrict__ coef, float *__restrict__ wpart, int B, int H, int W, int Cout)
 {
     FD_DYN_SMEM(smem_raw);
@@ -775,7 +777,7 @@ fd_stem_wgrad_f32(const float *__restrict__ x, const float *__restrict__ G, cons
             }
     for (int co = 0; co < Cout; ++co) {
         float dz = 0.0f;
-        if (valid) dz = fd_dz(G[p * Cout + co], Z[p * Cout + co], coef[FD_CF_A * Cout + co], coef[FD_CF_C1 * Cout + co], coef[FD_CF_MU * Cout + co], coef[FD_CF_C2 * Cout + co]);
+        if (valid) dz = fd_dz(fd_ld1(G + p * Cout + co), fd_ld1(Z + p * Cout + co), coef[FD_CF_A * Cout + co], coef[FD_CF_C1 * Cout + co], coef[FD_CF_MU * Cout + co], coef[FD_CF_C2 * Cout + co]);
         s_dz[tid * (Cout + 1) + co] = dz;
     }
     __syncthreads();

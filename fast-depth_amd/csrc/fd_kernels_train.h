@@ -1,4 +1,5 @@
-// fd_kernels_train_f32.h -- fp32 TRAIN-mode forward kernels of the FastDepth hot path (gfx950).
+// fd_kernels_train.h -- TRAIN-mode forward kernels of the FastDepth hot path (gfx950).  T = storage type of the saved raw
+// conv outputs z (float, or fd_bf16 for the 16-bit train plan); all arithmetic, statistics and tables are fp32.
 //
 // Train mode changes BatchNorm to batch statistics (reference: nn.BatchNorm2d instantiated at
 // imagenet/mobilenet.py:25,32,36 and models.py:66,73, module in .train()): the statistics of a unit's conv
@@ -25,14 +26,27 @@ __device__ __forceinline__ fd_f32x4 fd_bn_act4(fd_f32x4 z, fd_f32x4 s, fd_f32x4 
 {
     return fd_act4<ACT>(z * s + t);
 }
+// value a T-typed store will hold: the batch statistics are taken over the STORED (rounded) z, so that forward
+// normalisation and the BatchNorm backward see exactly the same tensor
+__device__ __forceinline__ fd_f32x4 fd_round4(float, fd_f32x4 v) { return v; }
+__device__ __forceinline__ fd_f32x4 fd_round4(fd_bf16, fd_f32x4 v)
+{
+    fd_f32x4 r = {fd_bf16_to_f32(fd_f32_to_bf16(v.x)), fd_bf16_to_f32(fd_f32_to_bf16(v.y)), fd_bf16_to_f32(fd_f32_to_bf16(v.z)), fd_bf16_to_f32(fd_f32_to_bf16(v.w))};
+    return r;
+}
+__device__ __forceinline__ fd_f32x4 fd_round4(fd_half, fd_f32x4 v)
+{
+    fd_f32x4 r = {(float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w};
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Stem, train mode: raw weights w[Cout][27] (torch layout), raw output z (NHWC) + stats partials
 // part[(blockIdx.x)*2*Cout + {0: sum, Cout: sumsq} + c].
 // ------------------------------------------------------------------------------------------------
-template <int CHUNK>
+template <typename T, int CHUNK>
 __global__ void __launch_bounds__(256)
-fd_stem_train_f32(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ z,
+fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__restrict__ z,
                   float *__restrict__ part, int B, int H, int W, int Cout)
 {
     FD_DYN_SMEM(smem_raw);
@@ -68,7 +82,7 @@ fd_stem_train_f32(const float *__restrict__ x, const float *__restrict__ w, floa
         for (int j = 0; j < CHUNK; j += 4) {
             fd_f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
             if (!valid) v = fd_zero4();
-            fd_st4(tile + tid * TS + j, v);
+            fd_st4(tile + tid * TS + j, fd_round4(T{}, v));
         }
         __syncthreads();
         constexpr int Q = CHUNK / 4;
@@ -98,17 +112,17 @@ fd_stem_train_f32(const float *__restrict__ x, const float *__restrict__ w, floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// Depthwise K x K, stride S, train mode (LDS-tiled, same geometry as fd_dwconv_f32).
+// Depthwise K x K, stride S, train mode (LDS-tiled, same geometry as fd_dwconv).
 //   input  = act1(z_in * s1 + t1)                                   (MODE 0)
 //          = up2(act1(z_in * s1 + t1))                              (MODE 1)
 //          = up2(act1(z_in * s1 + t1)) + act2(z_skip * s2 + t2)     (MODE 2)
 // weights are the live parameter w[C][K*K]; output is the raw conv result + stats partials
 // part[blk*2*C + {0,C} + c] with blk = blockIdx.z * gridDim.x + blockIdx.x.
 // ------------------------------------------------------------------------------------------------
-template <int K, int S, int MODE, int ACT1, int ACT2>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
 __global__ void __launch_bounds__(256)
-fd_dwconv_train_f32(const float *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ zskip,
-                    const float *__restrict__ st2, const float *__restrict__ w, float *__restrict__ zout,
+fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
+                    const float *__restrict__ st2, const float *__restrict__ w, T *__restrict__ zout,
                     float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x)
 {
     constexpr int P = K / 2;
@@ -197,8 +211,9 @@ fd_dwconv_train_f32(const float *__restrict__ zin, const float *__restrict__ st1
             for (int j = 0; j < 4; ++j) {
                 const int gx = ox0 + ox + j;
                 if (gx < Wo) {
-                    fd_st4(zout + (((long)n * Ho + gy) * Wo + gx) * C + cg, acc[j]);
-                    ssum += acc[j]; ssq += acc[j] * acc[j];
+                    const fd_f32x4 zr = fd_round4(T{}, acc[j]);
+                    fd_st4(zout + (((long)n * Ho + gy) * Wo + gx) * C + cg, zr);
+                    ssum += zr; ssq += zr * zr;
                 }
             }
         }
@@ -323,9 +338,9 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
 // upsampling commutes with the 1x1 conv; BN statistics over the replicated tensor equal the low-res ones, the
 // unbiased correction uses the full-resolution count -- SURVEY.md Appendix F).  part[blk*2 + {0,1}].
 // ------------------------------------------------------------------------------------------------
-template <int ACT1>
+template <typename T, int ACT1>
 __global__ void __launch_bounds__(256)
-fd_head_train_f32(const float *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w,
+fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w,
                   float *__restrict__ zlow, float *__restrict__ part, long npix, int Cin)
 {
     __shared__ float red[8];

@@ -1,0 +1,413 @@
+// fd_kernels_train_h16.h -- pointwise (1x1) kernels of the 16-bit TRAIN step: z, G and the GEMM operands are stored as
+// T = fd_bf16 (fd_half also compiles; the C ABI only offers bf16 because fp16 gradients would need loss scaling), the
+// matrix instructions are v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation, statistics / tables / parameter
+// gradients / master weights stay fp32.
+//
+//   forward   z = act1(z_in*s+t) x W^T     fd_pw_gemm_train_h16   BN+activation of the producer applied to the A fragment
+//                                                                 after the ds_read (fp32 math, re-packed to T)
+//   backward  dz = BN-backward(G, z)       fd_bn_bwd_apply_h16    once per unit, IN PLACE over G: both backward GEMMs read
+//                                                                 the same operand, so forming it on the fly would do the
+//                                                                 fp32 table math twice per element per tile
+//             G_in = mask * (dz x W)       fd_pw_dgrad_h16        B operand = W^T stored [K][N64]
+//             dW   = dz^T x a_in           fd_pw_wgrad_h16        the reduction index (pixels) is the ROW index of both
+//                                                                 operands in memory: tiles are transposed on their way
+//                                                                 into LDS (16-byte global reads, 2-byte LDS writes), so
+//                                                                 that fragments are single ds_read_b128
+// The per-step conversion of the fp32 master weights into the two 16-bit operand layouts is fd_pack_train_w_h16.
+#pragma once
+#include "fd_kernels_h16.h"
+#include "fd_kernels_bwd.h"
+
+__device__ __forceinline__ void fd_unpack8(fd_bf16, fd_u16x8 r, float (&f)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fd_bf16_to_f32(r[j]);
+}
+__device__ __forceinline__ void fd_unpack8(fd_half, fd_u16x8 r, float (&f)[8])
+{
+    const fd_f16x8 h = __builtin_bit_cast(fd_f16x8, r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
+}
+__device__ __forceinline__ fd_u16x8 fd_pack8(fd_bf16, const float (&f)[8])
+{
+    fd_u16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = fd_f32_to_bf16(f[j]);
+    return r;
+}
+__device__ __forceinline__ fd_u16x8 fd_pack8(fd_half, const float (&f)[8])
+{
+    fd_f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)f[j];
+    return __builtin_bit_cast(fd_u16x8, h);
+}
+__device__ __forceinline__ fd_u16x8 fd_ld8(const void *p) { return *reinterpret_cast<const fd_u16x8 *>(p); }
+__device__ __forceinline__ void fd_st8(void *p, fd_u16x8 v) { *reinterpret_cast<fd_u16x8 *>(p) = v; }
+
+// ------------------------------------------------------------------------------------------------
+// Master weights W[N][K] (fp32, torch layout) -> wt[N][K64] and wtt[K][N64] in T, zero padded along the reduction index of
+// the GEMM that reads them (forward: k, backward-data: n).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+fd_pack_train_w_h16(const float *__restrict__ w, T *__restrict__ wt, T *__restrict__ wtt, int N, int K, int K64, int N64)
+{
+    const long a = (long)N * K64, total = a + (long)K * N64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        if (i < a) {
+            const int n = (int)(i / K64), k = (int)(i - (long)n * K64);
+            fd_st1(wt + i, k < K ? w[(long)n * K + k] : 0.0f);
+        } else {
+            const long j = i - a;
+            const int k = (int)(j / N64), n = (int)(j - (long)k * N64);
+            fd_st1(wtt + j, n < N ? w[(long)n * K + k] : 0.0f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward.  Skeleton of fd_pw_gemm_h16 (LDS-DMA 3-stage ring, swizzled 128-byte rows, XCD-aware 1-D grid); the scale/shift
+// table of the producer sits in LDS as [2][K64] floats, zero beyond K (so a ragged last K tile contributes act(0) * 0).
+// Epilogue: z rounded to T, transposed through LDS for 16-byte NHWC stores, per-column statistics of the ROUNDED values
+// -> part[mt*2*N + {0,N} + col].
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT1>
+__global__ void __launch_bounds__(256)
+fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, const T *__restrict__ Wt, T *__restrict__ out,
+                     float *__restrict__ part, int M, int N, int K, int K64, int m_tiles, int n_tiles)
+{
+    constexpr int BM = 64, BN = 64, BK = 64;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
+    FD_DYN_SMEM(smem);
+    float *tab = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][K64]
+    float *red = tab + 2 * K64;                                   // [2][2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % n_tiles, mt = (slot / n_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    for (int k = tid; k < K64; k += 256) {
+        tab[k] = k < K ? st1[FD_ST_SCALE * K + k] : 0.0f;
+        tab[K64 + k] = k < K ? st1[FD_ST_SHIFT * K + k] : 0.0f;
+    }
+    const T *src[RG];
+    int src_k[RG];
+    bool src_is_a[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int r = (wave + 4 * i) * 8 + (lane >> 3);
+        src_k[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        src_is_a[i] = r < BM;
+        if (r < BM) { long row = m0 + r; if (row > M - 1) row = M - 1; src[i] = A + row * K; }
+        else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K64; }
+    }
+    auto issue = [&](int t) {
+        unsigned char *dst = smem + (t % 3) * STAGE + wave * 8 * 128;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int k = t * BK + src_k[i];
+            if (src_is_a[i] && k >= K) k = 0;
+            fd_glds16(reinterpret_cast<const float *>(src[i] + k), reinterpret_cast<float *>(dst + i * 4 * 8 * 128));
+        }
+    };
+    fd_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int h = lane >> 5;
+    int a_off[4], b_off[4];
+    {
+        const int ra = wm * 32 + (lane & 31), rb = BM + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
+            b_off[s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
+        }
+    }
+    const int Tn = K64 / BK;
+    __syncthreads();                                              // table visible, before any LDS-DMA is in flight
+    issue(0);
+    if (Tn > 1) issue(1);
+    for (int t = 0; t < Tn; ++t) {
+        if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        fd_block_barrier();
+        if (t + 2 < Tn) issue(t + 2);
+        const unsigned char *cur = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kb = t * BK + (2 * s + h) * 8;
+            float f[8];
+            fd_unpack8(T{}, fd_ld8(cur + a_off[s]), f);
+            const fd_f32x4 s0 = fd_ld4(tab + kb), s1 = fd_ld4(tab + kb + 4), t0 = fd_ld4(tab + K64 + kb), t1 = fd_ld4(tab + K64 + kb + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = fd_act<ACT1>(fmaf(f[j], s0[j], t0[j]));
+                f[4 + j] = fd_act<ACT1>(fmaf(f[4 + j], s1[j], t1[j]));
+            }
+            acc = fd_mfma_32x32x16(T{}, fd_pack8(T{}, f), fd_ld8(cur + b_off[s]), acc);
+        }
+    }
+    // epilogue
+    __syncthreads();
+    T *tile = reinterpret_cast<T *>(smem) + wave * 32 * 40;
+    const int col = lane & 31;
+    const long rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    float s = 0.0f, q = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2);
+        fd_st1(tile + (rl + 4 * (lane >> 5)) * 40 + col, acc[r]);
+        const float zr = fd_ld1(tile + (rl + 4 * (lane >> 5)) * 40 + col);          // the rounded value (own write)
+        if (rbase + rl < M && n0 + wn * 32 + col < N) { s += zr; q = fmaf(zr, zr, q); }
+    }
+    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+    if (lane < 32) { red[(wm * 2 + 0) * 64 + wn * 32 + lane] = s; red[(wm * 2 + 1) * 64 + wn * 32 + lane] = q; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = lane + 64 * i;
+        const int row = id >> 2, c8 = (id & 3) * 8;
+        const long grow = m0 + wm * 32 + row;
+        const int gcol = n0 + wn * 32 + c8;
+        if (grow < M && gcol < N) fd_st8(out + grow * N + gcol, fd_ld8(tile + row * 40 + c8));   // N % 8 == 0 (checked by the plan)
+    }
+    if (tid < 64 && n0 + tid < N) {
+        part[(long)mt * 2 * N + n0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
+        part[(long)mt * 2 * N + N + n0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward as an elementwise map:  DZ[m][n] = A*((G - C1) - (z - MU)*C2), 8 channels per item.  DZ == G (in place)
+// in product plans; plans created with FD_PLAN_KEEP_ACTIVATIONS keep G and write dz to a buffer of its own.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__restrict__ coef, long chunks, int N)
+{
+    const int n8 = N >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long)gridDim.x * 256) {
+        const int n = (int)(i % n8) * 8;
+        float g[8], z[8];
+        fd_unpack8(T{}, fd_ld8(G + i * 8), g);
+        fd_unpack8(T{}, fd_ld8(Z + i * 8), z);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            g[j] = fd_dz(g[j], z[j], coef[FD_CF_A * N + n + j], coef[FD_CF_C1 * N + n + j], coef[FD_CF_MU * N + n + j], coef[FD_CF_C2 * N + n + j]);
+        fd_st8(DZ + i * 8, fd_pack8(T{}, g));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward-data:  G_in[M][K] = mask_in(y_in) * (dz[M][N] x W[N][K] (+ skipgrad)),  + the producer's BN partials.
+// Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed
+// through LDS so that z_in / skipgrad are read and G_in is written 8 channels (16 bytes) per lane.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
+                const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles)
+{
+    constexpr int BM = 64, BKO = 64, BR = 64;
+    constexpr int ROWS = BM + BKO, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
+    FD_DYN_SMEM(smem);
+    float *red = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wk = wave & 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int kt = slot % k_tiles, mt = (slot / k_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * BM;
+    const int k0 = kt * BKO;
+    const T *src[RG];
+    int src_n[RG];
+    bool src_is_a[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int r = (wave + 4 * i) * 8 + (lane >> 3);
+        src_n[i] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        src_is_a[i] = r < BM;
+        if (r < BM) { long row = m0 + r; if (row > M - 1) row = M - 1; src[i] = DZ + row * N; }
+        else { int row = k0 + (r - BM); if (row > K - 1) row = K - 1; src[i] = Wtt + (long)row * N64; }
+    }
+    auto issue = [&](int t) {
+        unsigned char *dst = smem + (t % 3) * STAGE + wave * 8 * 128;
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+            int n = t * BR + src_n[i];
+            if (src_is_a[i] && n >= N) n = 0;                     // finite data; the zero-padded weights annihilate it
+            fd_glds16(reinterpret_cast<const float *>(src[i] + n), reinterpret_cast<float *>(dst + i * 4 * 8 * 128));
+        }
+    };
+    fd_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int h = lane >> 5;
+    int a_off[4], b_off[4];
+    {
+        const int ra = wm * 32 + (lane & 31), rb = BM + wk * 32 + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
+            b_off[s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
+        }
+    }
+    const int Tn = N64 / BR;
+    issue(0);
+    if (Tn > 1) issue(1);
+    for (int t = 0; t < Tn; ++t) {
+        if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        fd_block_barrier();
+        if (t + 2 < Tn) issue(t + 2);
+        const unsigned char *cur = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = fd_mfma_32x32x16(T{}, fd_ld8(cur + a_off[s]), fd_ld8(cur + b_off[s]), acc);
+    }
+    // epilogue: fp32 tile [32][36] per wave
+    __syncthreads();
+    float *tile = reinterpret_cast<float *>(smem) + wave * 32 * 36;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[r];
+    __syncthreads();
+    const int c8 = (lane & 3) * 8;
+    const int gcol = k0 + wk * 32 + c8;
+    float sg_[8], sx_[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sg_[j] = 0.0f; sx_[j] = 0.0f; }
+    if (gcol < K) {                                               // K % 8 == 0: a chunk is entirely inside or outside
+        float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = st_in[FD_ST_SCALE * K + gcol + j]; sh[j] = st_in[FD_ST_SHIFT * K + gcol + j];
+            mu[j] = st_in[FD_ST_MEAN * K + gcol + j]; is[j] = st_in[FD_ST_INVSTD * K + gcol + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (lane >> 2) + 16 * i;
+            const long grow = m0 + wm * 32 + row;
+            if (grow < M) {
+                float z[8], v[8];
+                fd_unpack8(T{}, fd_ld8(Zin + grow * K + gcol), z);
+                const fd_f32x4 v0 = fd_ld4(tile + row * 36 + c8), v1 = fd_ld4(tile + row * 36 + c8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+                if (ADD_SG) {
+                    float g[8];
+                    fd_unpack8(T{}, fd_ld8(SG + grow * K + gcol), g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += g[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= fd_actmask<ACT_IN>(fmaf(z[j], sc[j], sh[j]));
+                const fd_u16x8 packed = fd_pack8(T{}, v);
+                fd_st8(Gin + grow * K + gcol, packed);
+                fd_unpack8(T{}, packed, v);                       // statistics of the stored (rounded) gradient
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { sg_[j] += v[j]; sx_[j] = fmaf(v[j], (z[j] - mu[j]) * is[j], sx_[j]); }
+            }
+        }
+    }
+    // lanes that share (lane & 3) hold the same 8 columns for different rows
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        for (int m = 4; m < 64; m <<= 1) { sg_[j] += __shfl_xor(sg_[j], m); sx_[j] += __shfl_xor(sx_[j], m); }
+    if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(wm * 2 + 0) * 64 + wk * 32 + c8 + j] = sg_[j]; red[(wm * 2 + 1) * 64 + wk * 32 + c8 + j] = sx_[j]; }
+    }
+    __syncthreads();
+    if (tid < 64 && k0 + tid < K) {
+        part[(long)mt * 2 * K + k0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
+        part[(long)mt * 2 * K + K + k0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward-weights:  wpart[split][n][k] = sum over the split's pixels m of dz[m][n] * a_in[m][k],  a_in = act_in(z_in*s+t).
+// Workgroup = 64 (n) x 64 (k) output tile, 64 pixels per step.  LDS image: dzT[64 n][64 m], aT[64 k][64 m] in T, rows of
+// 144 bytes, the 16-byte chunk (8 consecutive m) of row r stored at chunk position c ^ ((r >> 3) & 7): the 2-byte transposing
+// writes of a wave then spread over the banks, and a fragment is one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT_IN>
+__global__ void __launch_bounds__(256)
+fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
+                int M, int N, int K, int k_tiles, int rows_per_split)
+{
+    constexpr int BT = 64, BR = 64, PITCH = 144;
+    __shared__ __attribute__((aligned(16))) unsigned char s_dz[BT * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[BT * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int nt = blockIdx.x / k_tiles, kt = blockIdx.x - nt * k_tiles;
+    const int n0 = nt * BT, k0 = kt * BT;
+    const long mbeg = (long)blockIdx.y * rows_per_split;
+    long mend = mbeg + rows_per_split; if (mend > M) mend = M;
+    const int Tn = (int)((mend - mbeg + BR - 1) / BR);
+    // loader mapping: chunk cc = tid & 7 (8 columns), rows (tid >> 3) and (tid >> 3) + 32 of the 64-pixel step
+    const int cc = tid & 7, lr = tid >> 3;
+    const int ncol = n0 + cc * 8, kcol = k0 + cc * 8;
+    const bool n_ok = ncol < N, k_ok = kcol < K;                  // N, K % 8 == 0
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = k_ok ? st_in[FD_ST_SCALE * K + kcol + j] : 0.0f; sh[j] = k_ok ? st_in[FD_ST_SHIFT * K + kcol + j] : 0.0f; }
+    fd_u16x8 rdz[2], rzi[2];
+    const fd_u16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long m = mbeg + (long)t * BR + lr + 32 * i;
+            const bool ok = m < mend;
+            rdz[i] = (ok && n_ok) ? fd_ld8(DZ + m * N + ncol) : zero8;
+            rzi[i] = (ok && k_ok) ? fd_ld8(Zin + m * K + kcol) : zero8;
+        }
+    };
+    auto stage = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ml = lr + 32 * i;                           // pixel within the step
+            const long m = mbeg + (long)t * BR + ml;
+            float a[8];
+            fd_unpack8(T{}, rzi[i], a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (m < mend && k_ok) ? fd_act<ACT_IN>(fmaf(a[j], sc[j], sh[j])) : 0.0f;
+            const fd_u16x8 pa = fd_pack8(T{}, a);
+            const int pos = (((ml >> 3) ^ cc) << 4) + (ml & 7) * 2;   // rows cc*8 .. cc*8+7 all have (r >> 3) & 7 == cc
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                *reinterpret_cast<unsigned short *>(s_dz + (cc * 8 + j) * PITCH + pos) = rdz[i][j];
+                *reinterpret_cast<unsigned short *>(s_a + (cc * 8 + j) * PITCH + pos) = pa[j];
+            }
+        }
+    };
+    fd_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int hh = lane >> 5;
+    const int ra = wn * 32 + (lane & 31), rb = wk * 32 + (lane & 31);
+    if (Tn > 0) load(0);
+    for (int t = 0; t < Tn; ++t) {
+        __syncthreads();                                          // the previous step's fragment reads are done
+        stage(t);
+        __syncthreads();
+        if (t + 1 < Tn) load(t + 1);                              // in flight during the MFMAs
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const fd_u16x8 a = fd_ld8(s_dz + ra * PITCH + (((2 * s + hh) ^ ((ra >> 3) & 7)) << 4));
+            const fd_u16x8 b = fd_ld8(s_a + rb * PITCH + (((2 * s + hh) ^ ((rb >> 3) & 7)) << 4));
+            acc = fd_mfma_32x32x16(T{}, a, b, acc);
+        }
+    }
+    float *o = wpart + (long)blockIdx.y * N * K;
+    const int col = k0 + wk * 32 + (lane & 31);
+    const int rbn = n0 + wn * 32 + 4 * (lane >> 5);
+    if (col < K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbn + (r & 3) + 8 * (r >> 2);
+            if (row < N) o[(long)row * K + col] = acc[r];
+        }
+    }
+}

@@ -23,7 +23,7 @@ int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
     return check_launch("fd_bn_bwd_finalize_f32");
 }
 
-template <int K, int S, int MODE, int ACT_IN, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
 int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
 {
     TLayer &L = c.p->layers[i];
@@ -35,30 +35,30 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
     const size_t lds = dw_bwd_lds(ph, pw, cb, K);
     dim3 grid(tiles_x * tiles_y, ceil_div(L.d.cin, cb), c.p->B);
     const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
-    FD_LAUNCH((fd_dw_dgrad_f32<K, S, MODE, ACT_IN, ADD_SG>), grid, dim3(256), lds, c.s, tws(c.p, L.g_off), tws(c.p, L.z_off), tws(c.p, L.coef_off),
-              c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? tws(c.p, P.sg_off) : (const float *)nullptr,
-              tws(c.p, P.g_off), Kp ? tws(c.p, Kp->sg_off) : (float *)nullptr, tws(c.p, c.p->part_off),
+    FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
+              c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
+              twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, tws(c.p, c.p->part_off),
               L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x);
     *nblk_out = tiles_x * tiles_y * c.p->B;
-    return check_launch("fd_dw_dgrad_f32");
+    return check_launch("fd_dw_dgrad");
 }
 
-template <int ACT_IN, int ADD_SG>
+template <typename T, int ACT_IN, int ADD_SG>
 int dispatch_dw_dgrad(BwdCtx &c, int i, int *nblk)
 {
     const TLayer &L = c.p->layers[i];
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     switch (key) {
-    case 310: return launch_dw_dgrad<3, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
-    case 320: return launch_dw_dgrad<3, 2, 0, ACT_IN, ADD_SG>(c, i, nblk);
-    case 510: return launch_dw_dgrad<5, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
-    case 511: return launch_dw_dgrad<5, 1, 1, ACT_IN, ADD_SG>(c, i, nblk);
-    case 512: return launch_dw_dgrad<5, 1, 2, ACT_IN, ADD_SG>(c, i, nblk);
+    case 310: return launch_dw_dgrad<T, 3, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
+    case 320: return launch_dw_dgrad<T, 3, 2, 0, ACT_IN, ADD_SG>(c, i, nblk);
+    case 510: return launch_dw_dgrad<T, 5, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
+    case 511: return launch_dw_dgrad<T, 5, 1, 1, ACT_IN, ADD_SG>(c, i, nblk);
+    case 512: return launch_dw_dgrad<T, 5, 1, 2, ACT_IN, ADD_SG>(c, i, nblk);
     }
     return fail(FD_ERR_INVALID, "train: depthwise backward k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
 }
 
-template <int ACT1, int ACT2>
+template <typename T, int ACT1, int ACT2>
 int launch_dw_wgrad_acts(BwdCtx &c, int i)
 {
     TLayer &L = c.p->layers[i];
@@ -68,9 +68,9 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     float *wpart = tws(c.p, c.p->wpart_off);
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
-        FD_LAUNCH((fd_dw_wgrad_f32<K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, c.s, tws(c.p, P.z_off), tws(c.p, P.st_off),  \
-                  Kp ? tws(c.p, Kp->z_off) : (const float *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
-                  tws(c.p, L.g_off), tws(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
+        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
+                  Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
+                  twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
                   L.cbq, L.th, L.tw, L.tiles_x);                                                                                   \
         break;
     switch (key) {
@@ -78,7 +78,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     default: return fail(FD_ERR_INVALID, "train: depthwise wgrad has no kernel for this layer");
     }
 #undef FD_DWW
-    int rc = check_launch("fd_dw_wgrad_f32");
+    int rc = check_launch("fd_dw_wgrad");
     if (rc) return rc;
     const int kk = L.d.ksize * L.d.ksize;
     int rows = 0;
@@ -88,14 +88,65 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     return check_launch("fd_reduce_partials_tapmajor_f32");
 }
 
+template <typename T>
 int launch_dw_wgrad(BwdCtx &c, int i)
 {
     const TLayer &L = c.p->layers[i];
     const int a1 = c.p->layers[L.d.src].d.act, a2 = L.d.skip >= 0 ? c.p->layers[L.d.skip].d.act : FD_ACT_RELU6;
-    if (a1 == FD_ACT_RELU6 && a2 == FD_ACT_RELU6) return launch_dw_wgrad_acts<FD_ACT_RELU6_, FD_ACT_RELU6_>(c, i);
-    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6) return launch_dw_wgrad_acts<FD_ACT_RELU_, FD_ACT_RELU6_>(c, i);
-    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU) return launch_dw_wgrad_acts<FD_ACT_RELU_, FD_ACT_RELU_>(c, i);
-    return launch_dw_wgrad_acts<FD_ACT_RELU6_, FD_ACT_RELU_>(c, i);
+    if (a1 == FD_ACT_RELU6 && a2 == FD_ACT_RELU6) return launch_dw_wgrad_acts<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(c, i);
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6) return launch_dw_wgrad_acts<T, FD_ACT_RELU_, FD_ACT_RELU6_>(c, i);
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU) return launch_dw_wgrad_acts<T, FD_ACT_RELU_, FD_ACT_RELU_>(c, i);
+    return launch_dw_wgrad_acts<T, FD_ACT_RELU6_, FD_ACT_RELU_>(c, i);
+}
+
+template <typename T, int ACT_IN>
+int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
+{
+    TLayer &L = c.p->layers[i];
+    TLayer &P = c.p->layers[L.d.src];
+    const int M = (int)L.M, N = L.d.cout, K = L.d.cin;
+    const T *Gsrc = twt<T>(c.p, L.g_off);
+    T *G = L.dz_off ? twt<T>(c.p, L.dz_off) : twt<T>(c.p, L.g_off);     // dz: the operand of both GEMMs below
+    int rc;
+    // dz = BatchNorm-backward(G, z), in place over G: the operand of both GEMMs below
+    {
+        const long chunks = (long)M * N / 8;
+        FD_LAUNCH((fd_bn_bwd_apply_h16<T>), dim3((unsigned)std::min<long>(4096, ceil_div(chunks, 256))), dim3(256), 0, c.s, Gsrc, G, twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), chunks, N);
+        if ((rc = check_launch("fd_bn_bwd_apply_h16"))) return rc;
+    }
+    {
+        const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
+        int splits = std::max(1, std::min(ceil_div(2048, (long)n_tiles * k_tiles), ceil_div(M, 256)));
+        int rows = ceil_div(ceil_div(M, splits), 64) * 64;
+        splits = ceil_div(M, rows);
+        const size_t need = (size_t)splits * N * K * 4;
+        if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
+        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.s, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+                  tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
+        if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
+        int srows = 0;
+        const float *pr = slice_rows(c.p, tws(c.p, c.p->wpart_off), splits, N * K, c.s, &srows, &rc);
+        if (rc) return rc;
+        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div((long)N * K, 64)), dim3(1024), 0, c.s, pr, srows, (long)N * K, N * K, c.grads[i].conv_weight);
+        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+    }
+    {
+        const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
+        const size_t lds = (size_t)3 * 128 * 128 + 256 * 4;
+        const bool add = P.skip_consumer >= 0;
+        dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * k_tiles));
+        if (add) {
+            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, 1>), grid, dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+                      twt<T>(c.p, P.sg_off), twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);
+        } else {
+            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, 0>), grid, dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+                      (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);
+        }
+        *nblk = m_tiles;
+        return check_launch("fd_pw_dgrad_h16");
+    }
 }
 
 template <int ACT_IN>
@@ -109,7 +160,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     {
         const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
         int splits = std::max(1, std::min(ceil_div(2048, (long)n_tiles * k_tiles), ceil_div(M, 256)));
-        int rows = ceil_div(ceil_div(M, splits), 32) * 32;
+        int rows = ceil_div(ceil_div(M, splits), 64) * 64;
         splits = ceil_div(M, rows);
         const size_t need = (size_t)splits * N * K * 4;
         if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
@@ -146,6 +197,82 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     }
 }
 
+template <typename T>
+int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
+                     const void *dy, int32_t from_layer, int32_t to_layer, void *stream)
+{
+    constexpr bool F32 = std::is_same<T, float>::value;
+    BwdCtx c{plan, params, grads, static_cast<hipStream_t>(stream)};
+    hipStream_t s = c.s;
+    float *part = tws(plan, plan->part_off), *wpart = tws(plan, plan->wpart_off);
+    int rc;
+    // ---- head
+    const int hi = n_layers - 1;
+    TLayer &Hd = plan->layers[hi];
+    TLayer &Hp = plan->layers[Hd.d.src];
+    if (from_layer == hi) {
+        const int nb = ceil_div(Hd.M, 256);
+        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        if ((rc = check_launch("fd_head_bwd_reduce_f32"))) return rc;
+        if ((rc = bn_bwd_finalize(c, hi, nb))) return rc;
+        constexpr int PPB = 16;
+        const int nb2 = ceil_div(Hd.M, 32 * PPB);
+        const size_t lds = (size_t)32 * Hd.d.cin * 3 * 4;
+        if ((size_t)nb2 * Hd.d.cin * 4 > plan->wpart_bytes) return fail(FD_ERR_STATE, "wpart too small for the head");
+        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
+        else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
+        if ((rc = check_launch("fd_head_bwd"))) return rc;
+        {
+            int rows = 0;
+            const float *pr = slice_rows(plan, wpart, nb2, Hd.d.cin, s, &rows, &rc);
+            if (rc) return rc;
+            FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(Hd.d.cin, 64)), dim3(1024), 0, s, pr, rows, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight);
+        }
+        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+        // the BN partials of the head's producer are now in `part` (nb2 workgroups)
+        if ((rc = bn_bwd_finalize(c, Hd.d.src, nb2))) return rc;
+    }
+    // ---- remaining units in reverse order; invariant: coef_i and the BN grads of unit i are final when unit i is processed
+    for (int i = std::min(hi - 1, (int)from_layer); i >= to_layer; --i) {
+        TLayer &L = plan->layers[i];
+        const fd_layer_desc &d = L.d;
+        int nblk = 0;
+        switch (d.op) {
+        case FD_OP_STEM:
+            FD_LAUNCH((fd_stem_wgrad<T>), L.grid, dim3(256), (size_t)(256 * 28 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout);
+            if ((rc = check_launch("fd_stem_wgrad"))) return rc;
+            {
+                int rows = 0;
+                const float *pr = slice_rows(plan, wpart, L.nblk, 27 * d.cout, s, &rows, &rc);
+                if (rc) return rc;
+                FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, pr, rows, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
+            }
+            if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+            break;
+        case FD_OP_DW: {
+            if ((rc = launch_dw_wgrad<T>(c, i))) return rc;
+            const TLayer &P = plan->layers[d.src];
+            const bool add = P.skip_consumer >= 0 && L.mode == 0;
+            if (P.d.act == FD_ACT_RELU6) rc = add ? dispatch_dw_dgrad<T, FD_ACT_RELU6_, 1>(c, i, &nblk) : dispatch_dw_dgrad<T, FD_ACT_RELU6_, 0>(c, i, &nblk);
+            else rc = add ? dispatch_dw_dgrad<T, FD_ACT_RELU_, 1>(c, i, &nblk) : dispatch_dw_dgrad<T, FD_ACT_RELU_, 0>(c, i, &nblk);
+            if (rc) return rc;
+            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+            break;
+        }
+        case FD_OP_PW: {
+            const TLayer &P = plan->layers[d.src];
+            if constexpr (F32) rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd<FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd<FD_ACT_RELU_>(c, i, &nblk);
+            else rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd_h16<T, FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd_h16<T, FD_ACT_RELU_>(c, i, &nblk);
+            if (rc) return rc;
+            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+            break;
+        }
+        }
+    }
+    return FD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -165,74 +292,8 @@ int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, 
     if (from_layer < to_layer || from_layer >= n_layers || to_layer < 0) return fail(FD_ERR_INVALID, "bad layer range %d..%d", from_layer, to_layer);
     for (int i = 0; i < n_layers; ++i)
         if (!grads[i].conv_weight || !grads[i].bn_weight || !grads[i].bn_bias) return fail(FD_ERR_INVALID, "layer %d: null gradient pointer", i);
-    BwdCtx c{plan, params, grads, static_cast<hipStream_t>(stream)};
-    hipStream_t s = c.s;
-    float *part = tws(plan, plan->part_off), *wpart = tws(plan, plan->wpart_off);
-    int rc;
-    // ---- head
-    const int hi = n_layers - 1;
-    TLayer &Hd = plan->layers[hi];
-    TLayer &Hp = plan->layers[Hd.d.src];
-    if (from_layer == hi) {
-        const int nb = ceil_div(Hd.M, 256);
-        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
-        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
-        if ((rc = check_launch("fd_head_bwd_reduce_f32"))) return rc;
-        if ((rc = bn_bwd_finalize(c, hi, nb))) return rc;
-        constexpr int PPB = 16;
-        const int nb2 = ceil_div(Hd.M, 32 * PPB);
-        const size_t lds = (size_t)32 * Hd.d.cin * 3 * 4;
-        if ((size_t)nb2 * Hd.d.cin * 4 > plan->wpart_bytes) return fail(FD_ERR_STATE, "wpart too small for the head");
-        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_f32<FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), tws(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, tws(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
-        else FD_LAUNCH((fd_head_bwd_f32<FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), tws(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, tws(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
-        if ((rc = check_launch("fd_head_bwd_f32"))) return rc;
-        {
-            int rows = 0;
-            const float *pr = slice_rows(plan, wpart, nb2, Hd.d.cin, s, &rows, &rc);
-            if (rc) return rc;
-            FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(Hd.d.cin, 64)), dim3(1024), 0, s, pr, rows, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight);
-        }
-        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
-        // the BN partials of the head's producer are now in `part` (nb2 workgroups)
-        if ((rc = bn_bwd_finalize(c, Hd.d.src, nb2))) return rc;
-    }
-    // ---- remaining units in reverse order; invariant: coef_i and the BN grads of unit i are final when unit i is processed
-    for (int i = std::min(hi - 1, (int)from_layer); i >= to_layer; --i) {
-        TLayer &L = plan->layers[i];
-        const fd_layer_desc &d = L.d;
-        int nblk = 0;
-        switch (d.op) {
-        case FD_OP_STEM:
-            FD_LAUNCH(fd_stem_wgrad_f32, L.grid, dim3(256), (size_t)(256 * 28 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), tws(plan, L.g_off), tws(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout);
-            if ((rc = check_launch("fd_stem_wgrad_f32"))) return rc;
-            {
-                int rows = 0;
-                const float *pr = slice_rows(plan, wpart, L.nblk, 27 * d.cout, s, &rows, &rc);
-                if (rc) return rc;
-                FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, pr, rows, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
-            }
-            if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
-            break;
-        case FD_OP_DW: {
-            if ((rc = launch_dw_wgrad(c, i))) return rc;
-            const TLayer &P = plan->layers[d.src];
-            const bool add = P.skip_consumer >= 0 && L.mode == 0;
-            if (P.d.act == FD_ACT_RELU6) rc = add ? dispatch_dw_dgrad<FD_ACT_RELU6_, 1>(c, i, &nblk) : dispatch_dw_dgrad<FD_ACT_RELU6_, 0>(c, i, &nblk);
-            else rc = add ? dispatch_dw_dgrad<FD_ACT_RELU_, 1>(c, i, &nblk) : dispatch_dw_dgrad<FD_ACT_RELU_, 0>(c, i, &nblk);
-            if (rc) return rc;
-            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
-            break;
-        }
-        case FD_OP_PW: {
-            const TLayer &P = plan->layers[d.src];
-            rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd<FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd<FD_ACT_RELU_>(c, i, &nblk);
-            if (rc) return rc;
-            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
-            break;
-        }
-        }
-    }
-    return FD_OK;
+    return plan->dtype == FD_BF16 ? train_backward_t<fd_bf16>(plan, params, grads, n_layers, dy, from_layer, to_layer, stream)
+                                  : train_backward_t<float>(plan, params, grads, n_layers, dy, from_layer, to_layer, stream);
 }
 
 size_t fd_depth_metrics_scratch_bytes(void) { return (size_t)1024 * 10 * sizeof(double); }

@@ -2,14 +2,17 @@
 // fd_api.hip so that it shares that translation unit's helpers (fail(), FD_LAUNCH, ceil_div, ...).
 //
 // Workspace layout of a train plan:
-//   [z_i]   raw conv output of every unit, NHWC fp32, all kept (they are the saved tensors of backward)
+//   [z_i]   raw conv output of every unit, NHWC, fp32 or bf16 (plan dtype), all kept (they are the saved tensors of backward)
 //   [st_i]  per-unit BatchNorm table [4][C]: scale, shift, mean, invstd (fd_bn_finalize_f32)
 //   [part]  one shared buffer for per-workgroup reduction partials (consumed right after each producer)
 //   backward only: [g_a, g_b] ping-pong dLoss/d(BN output) buffers, [skipgrad_k] decoder->skip gradient buffers,
 //   [coef_i] per-unit BN-backward coefficient tables, [wpart] weight-gradient partials.
+//   bf16 plans: [wt_i, wtt_i] the 16-bit operand copies of every pointwise weight (re-made from the fp32 masters each step).
 #pragma once
-#include "fd_kernels_train_f32.h"
-#include "fd_kernels_bwd_f32.h"
+#include <type_traits>
+#include "fd_kernels_train.h"
+#include "fd_kernels_bwd.h"
+#include "fd_kernels_train_h16.h"
 
 namespace {
 
@@ -34,13 +37,17 @@ struct TLayer {
     int skip_consumer = -1;          // decoder unit that reads this output as `skip` (-1: none)
     size_t g_off = 0;                // dLoss/dy buffer of this unit
     size_t sg_off = 0;               // decoder->skip gradient buffer (only for skip sources)
+    size_t wt_off = 0, wtt_off = 0;  // 16-bit plans: W as [N][K64] and W^T as [K][N64]
+    size_t dz_off = 0;               // 16-bit pointwise units under FD_PLAN_KEEP_ACTIVATIONS: dz kept apart from G (0 = in place)
+    int k64 = 0, n64 = 0;
 };
 
 }  // namespace
 
 struct fd_train_plan {
     std::vector<TLayer> layers;
-    int B = 0, H = 0, W = 0;
+    int B = 0, H = 0, W = 0, dtype = FD_F32;
+    size_t esz = 4;                  // bytes per stored activation / activation-gradient element
     size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0, part2_off = 0, part2_bytes = 0;
     unsigned char *ws = nullptr;
     bool forward_done = false;
@@ -51,6 +58,7 @@ struct fd_train_plan {
 namespace {
 
 inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
+template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reinterpret_cast<T *>(p->ws + off); }
 
 // Two-level deterministic reduction, stage A: more than 64 partial rows are first summed into <= 64 slice rows.
 // Returns the buffer / row count the finalize kernel should read.
@@ -68,14 +76,14 @@ const float *slice_rows(fd_train_plan *p, const float *part, int nrows, int widt
     return out;
 }
 
-template <int ACT1, int ACT2>
-int launch_dw_train(const TLayer &L, const float *zin, const float *st1, const float *zskip, const float *st2, const float *w,
-                    float *zout, float *part, hipStream_t s)
+template <typename T, int ACT1, int ACT2>
+int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
+                    T *zout, float *part, hipStream_t s)
 {
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
 #define FD_DWT(K_, S_, M_)                                                                                                   \
     case K_ * 100 + S_ * 10 + M_:                                                                                            \
-        FD_LAUNCH((fd_dwconv_train_f32<K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
+        FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
                   L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);                                  \
         break;
     switch (key) {
@@ -83,19 +91,104 @@ int launch_dw_train(const TLayer &L, const float *zin, const float *st1, const f
     default: return fail(FD_ERR_INVALID, "train: depthwise k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
     }
 #undef FD_DWT
-    return check_launch("fd_dwconv_train_f32");
+    return check_launch("fd_dwconv_train");
 }
 
 // activation of the producer(s) decides the template instance: encoder = ReLU6, decoder = ReLU (both appear as act1; act2 is
 // the skip tensor's activation, always an encoder unit)
-int dispatch_dw_train(const TLayer &L, int act1, int act2, const float *zin, const float *st1, const float *zskip, const float *st2,
-                      const float *w, float *zout, float *part, hipStream_t s)
+template <typename T>
+int dispatch_dw_train(const TLayer &L, int act1, int act2, const T *zin, const float *st1, const T *zskip, const float *st2,
+                      const float *w, T *zout, float *part, hipStream_t s)
 {
-    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
-    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
-    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
-    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
     return fail(FD_ERR_INVALID, "train: unsupported producer activations %d/%d", act1, act2);
+}
+
+template <typename T>
+int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t n_layers, float bn_eps, float bn_momentum,
+                    const void *x_nchw, void *y, void *stream)
+{
+    constexpr bool F32 = std::is_same<T, float>::value;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float *x = static_cast<const float *>(x_nchw);
+    float *part = tws(plan, plan->part_off);
+    plan->eps = bn_eps;
+    plan->x_saved = x_nchw;
+    for (int i = 0; i < n_layers; ++i) {
+        const TLayer &L = plan->layers[i];
+        const fd_layer_desc &d = L.d;
+        const fd_layer_params &q = params[i];
+        if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
+        T *z = twt<T>(plan, L.z_off);
+        const TLayer *P = d.src >= 0 ? &plan->layers[d.src] : nullptr;
+        const T *zin = P ? twt<T>(plan, P->z_off) : nullptr;
+        const float *st1 = P ? tws(plan, P->st_off) : nullptr;
+        int rc = FD_OK;
+        switch (d.op) {
+        case FD_OP_STEM:
+            switch (L.chunk) {
+            case 32: FD_LAUNCH((fd_stem_train<T, 32>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
+            case 16: FD_LAUNCH((fd_stem_train<T, 16>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
+            default: FD_LAUNCH((fd_stem_train<T, 8>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
+            }
+            rc = check_launch("fd_stem_train");
+            break;
+        case FD_OP_DW: {
+            const TLayer *K = d.skip >= 0 ? &plan->layers[d.skip] : nullptr;
+            rc = dispatch_dw_train<T>(L, P->d.act, K ? K->d.act : FD_ACT_RELU6, zin, st1, K ? twt<T>(plan, K->z_off) : (const T *)nullptr,
+                                      K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s);
+            break;
+        }
+        case FD_OP_PW:
+            if (L.head) {
+                const long npix = L.M;
+                float *zl = tws(plan, L.z_off);
+                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_train<T, FD_ACT_RELU6_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, zl, part, npix, d.cin);
+                else FD_LAUNCH((fd_head_train<T, FD_ACT_RELU_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, zl, part, npix, d.cin);
+                rc = check_launch("fd_head_train");
+            } else {
+                if constexpr (F32) {
+                    if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                    else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                    rc = check_launch("fd_pw_gemm_train_f32");
+                } else {
+                    // 16-bit operand copies of the live fp32 master weights (read again by this unit's backward)
+                    T *wt = twt<T>(plan, L.wt_off), *wtt = twt<T>(plan, L.wtt_off);
+                    const long tot = (long)d.cout * L.k64 + (long)d.cin * L.n64;
+                    FD_LAUNCH((fd_pack_train_w_h16<T>), dim3((unsigned)std::min<long>(1024, ceil_div(tot, 256))), dim3(256), 0, s, q.conv_weight, wt, wtt, d.cout, d.cin, L.k64, L.n64);
+                    if ((rc = check_launch("fd_pack_train_w_h16"))) return rc;
+                    if (P->d.act == FD_ACT_RELU6) {
+                        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, FD_ACT_RELU6_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
+                        FD_LAUNCH((fd_pw_gemm_train_h16<T, FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles);
+                    } else {
+                        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, FD_ACT_RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
+                        FD_LAUNCH((fd_pw_gemm_train_h16<T, FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles);
+                    }
+                    rc = check_launch("fd_pw_gemm_train_h16");
+                }
+            }
+            break;
+        }
+        if (rc) return rc;
+        int rows = 0;
+        const float *pr = slice_rows(plan, part, L.nblk, 2 * d.cout, s, &rows, &rc);
+        if (rc) return rc;
+        FD_LAUNCH(fd_bn_finalize_f32, dim3(ceil_div(d.cout, 64)), dim3(1024), 0, s, pr, rows, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
+                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off));
+        if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
+    }
+    const TLayer &Hd = plan->layers.back();
+    if (Hd.d.act == FD_ACT_RELU6)
+        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU6_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+    else
+        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+    int rc = check_launch("fd_head_apply_f32");
+    if (rc) return rc;
+    plan->forward_done = true;
+    return FD_OK;
 }
 
 }  // namespace
@@ -108,9 +201,13 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
-    if (dtype != FD_F32) return fail(FD_ERR_INVALID, "train plan: dtype %d not supported by this build (fp32 only)", dtype);
+    if (dtype != FD_F32 && dtype != FD_BF16)
+        return fail(FD_ERR_INVALID, "train plan: dtype %d not supported (fp32 or bf16; fp16 gradients would need loss scaling)", dtype);
     fd_train_plan *p = new fd_train_plan();
-    p->B = batch; p->H = height; p->W = width;
+    p->B = batch; p->H = height; p->W = width; p->dtype = dtype;
+    const bool h16 = dtype != FD_F32;
+    const size_t esz = h16 ? 2 : 4;
+    p->esz = esz;
     p->layers.resize(n_layers);
     size_t off = 0, max_part = 0, max_wpart = 0, max_g = 0, max_width = 0;
 #define FD_BAD(...) do { int rc_ = fail(FD_ERR_INVALID, __VA_ARGS__); delete p; return rc_; } while (0)
@@ -124,6 +221,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         if (d.src < 0) { src_h = height; src_w = width; src_c = 3; }
         else { const TLayer &S = p->layers[d.src]; src_h = S.out_h; src_w = S.out_w; src_c = S.d.cout; }
         if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
+        if (h16 && (d.cout % 8 || (d.op != FD_OP_STEM && d.cin % 8)) && !(d.op == FD_OP_PW && d.cout == 1))
+            FD_BAD("layer %d: the 16-bit train plan needs channel counts that are multiples of 8", i);
         L.in_h = d.upsample ? 2 * src_h : src_h;
         L.in_w = d.upsample ? 2 * src_w : src_w;
         if (d.src >= 0) { if (p->layers[d.src].consumer >= 0) FD_BAD("layer %d: producer %d already has a consumer", i, d.src); p->layers[d.src].consumer = i; }
@@ -175,12 +274,13 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 const long M = (long)batch * L.out_h * L.out_w;
                 L.m_tiles = ceil_div(M, 64); L.n_tiles = ceil_div(d.cout, 64);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
-                L.lds = (3 * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
+                L.k64 = (d.cin + 63) / 64 * 64; L.n64 = (d.cout + 63) / 64 * 64;
+                L.lds = h16 ? (size_t)3 * 128 * 128 + ((size_t)2 * L.k64 + 256) * 4 : (size_t)(3 * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
                 L.nblk = L.m_tiles;
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
                     const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
                     int splits = std::max(1, std::min(ceil_div(2048, (long)nt * kt), ceil_div(M, 256)));
-                    const int rows = ceil_div(ceil_div(M, splits), 32) * 32;
+                    const int rows = ceil_div(ceil_div(M, splits), 64) * 64;
                     splits = ceil_div(M, rows);
                     max_wpart = std::max(max_wpart, (size_t)splits * d.cout * d.cin);
                 }
@@ -193,7 +293,11 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.z_elems = (size_t)L.M * d.cout;
         L.n_stat = (double)L.M;
         L.n_unbiased = (L.head && d.upsample) ? 4.0 * (double)L.M : (double)L.M;
-        L.z_off = off; off += align_up(L.z_elems * 4, 256);
+        L.z_off = off; off += align_up(L.z_elems * ((L.head) ? 4 : esz), 256);       // the 1-channel head stays fp32
+        if (h16 && d.op == FD_OP_PW && !L.head) {
+            L.wt_off = off; off += align_up((size_t)d.cout * L.k64 * esz, 256);
+            L.wtt_off = off; off += align_up((size_t)d.cin * L.n64 * esz, 256);
+        }
         L.st_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         L.coef_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         max_part = std::max(max_part, (size_t)L.nblk * 2 * d.cout);
@@ -208,13 +312,17 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
 #undef FD_BAD
     // backward buffers: the gradient of unit i is consumed by unit i's own backward kernels right after unit i+1's, so two
     // ping-pong buffers suffice; skip sources get a private buffer for the decoder's contribution
-    size_t g0 = off; off += align_up(max_g * 4, 256);
-    size_t g1 = off; off += align_up(max_g * 4, 256);
+    const size_t g_bytes = std::max(max_g * esz, p->layers.back().z_elems * 4);   // the head's gradient is fp32 in every plan
+    size_t g0 = off; off += align_up(g_bytes, 256);
+    size_t g1 = off; off += align_up(g_bytes, 256);
     for (int i = 0; i < n_layers; ++i) {
         TLayer &L = p->layers[i];
         L.g_off = (i & 1) ? g1 : g0;
-        if (flags & FD_PLAN_KEEP_ACTIVATIONS) { L.g_off = off; off += align_up(L.z_elems * 4, 256); }   // private gradient buffers (layer-wise tests)
-        if (L.skip_consumer >= 0) { L.sg_off = off; off += align_up(L.z_elems * 4, 256); }
+        if (flags & FD_PLAN_KEEP_ACTIVATIONS) {   // private gradient buffers (layer-wise tests)
+            L.g_off = off; off += align_up(L.z_elems * (L.head ? 4 : esz), 256);
+            if (h16 && L.d.op == FD_OP_PW && !L.head) { L.dz_off = off; off += align_up(L.z_elems * esz, 256); }
+        }
+        if (L.skip_consumer >= 0) { L.sg_off = off; off += align_up(L.z_elems * esz, 256); }
     }
     // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
     p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
@@ -244,72 +352,14 @@ int fd_train_forward(fd_train_plan *plan, const fd_layer_params *params, int32_t
     if (!plan || !params || !x_nchw || !y) return fail(FD_ERR_INVALID, "null argument");
     if (!plan->ws) return fail(FD_ERR_STATE, "bind a workspace first");
     if (n_layers != (int)plan->layers.size()) return fail(FD_ERR_INVALID, "expected %zu layer parameter sets", plan->layers.size());
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const float *x = static_cast<const float *>(x_nchw);
-    float *part = tws(plan, plan->part_off);
-    plan->eps = bn_eps;
-    plan->x_saved = x_nchw;
-    for (int i = 0; i < n_layers; ++i) {
-        const TLayer &L = plan->layers[i];
-        const fd_layer_desc &d = L.d;
-        const fd_layer_params &q = params[i];
-        if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
-        float *z = tws(plan, L.z_off);
-        const TLayer *P = d.src >= 0 ? &plan->layers[d.src] : nullptr;
-        const float *zin = P ? tws(plan, P->z_off) : nullptr;
-        const float *st1 = P ? tws(plan, P->st_off) : nullptr;
-        int rc = FD_OK;
-        switch (d.op) {
-        case FD_OP_STEM:
-            switch (L.chunk) {
-            case 32: FD_LAUNCH((fd_stem_train_f32<32>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
-            case 16: FD_LAUNCH((fd_stem_train_f32<16>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
-            default: FD_LAUNCH((fd_stem_train_f32<8>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
-            }
-            rc = check_launch("fd_stem_train_f32");
-            break;
-        case FD_OP_DW: {
-            const TLayer *K = d.skip >= 0 ? &plan->layers[d.skip] : nullptr;
-            rc = dispatch_dw_train(L, P->d.act, K ? K->d.act : FD_ACT_RELU6, zin, st1, K ? tws(plan, K->z_off) : nullptr,
-                                   K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s);
-            break;
-        }
-        case FD_OP_PW:
-            if (L.head) {
-                const long npix = L.M;
-                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, z, part, npix, d.cin);
-                else FD_LAUNCH((fd_head_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, z, part, npix, d.cin);
-                rc = check_launch("fd_head_train_f32");
-            } else {
-                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
-                else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
-                rc = check_launch("fd_pw_gemm_train_f32");
-            }
-            break;
-        }
-        if (rc) return rc;
-        int rows = 0;
-        const float *pr = slice_rows(plan, part, L.nblk, 2 * d.cout, s, &rows, &rc);
-        if (rc) return rc;
-        FD_LAUNCH(fd_bn_finalize_f32, dim3(ceil_div(d.cout, 64)), dim3(1024), 0, s, pr, rows, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
-                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off));
-        if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
-    }
-    const TLayer &Hd = plan->layers.back();
-    if (Hd.d.act == FD_ACT_RELU6)
-        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU6_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
-    else
-        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
-    int rc = check_launch("fd_head_apply_f32");
-    if (rc) return rc;
-    plan->forward_done = true;
-    return FD_OK;
+    return plan->dtype == FD_BF16 ? train_forward_t<fd_bf16>(plan, params, n_layers, bn_eps, bn_momentum, x_nchw, y, stream)
+                                  : train_forward_t<float>(plan, params, n_layers, bn_eps, bn_momentum, x_nchw, y, stream);
 }
 
 int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n, int32_t *h,
                           int32_t *w, int32_t *c)
 {
-    if (!plan || layer < 0 || layer >= (int)plan->layers.size() || which < 0 || which > 2) return fail(FD_ERR_INVALID, "bad layer index / selector");
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size() || which < 0 || which > 4) return fail(FD_ERR_INVALID, "bad layer index / selector");
     if (!plan->ws) return fail(FD_ERR_STATE, "no workspace bound");
     const TLayer &L = plan->layers[layer];
     if (which == 2) {   // the BatchNorm table [4][C]: scale, shift, mean, invstd
@@ -320,7 +370,9 @@ int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t whic
         if (c) *c = L.d.cout;
         return FD_OK;
     }
-    if (device_ptr) *device_ptr = plan->ws + (which == 0 ? L.z_off : L.g_off);
+    if (which == 3 && L.skip_consumer < 0) return fail(FD_ERR_INVALID, "layer %d is not a skip source", layer);
+    if (which == 4 && !L.dz_off) return fail(FD_ERR_INVALID, "layer %d keeps no separate dz (16-bit pointwise units of a KEEP_ACTIVATIONS plan only)", layer);
+    if (device_ptr) *device_ptr = plan->ws + (which == 0 ? L.z_off : which == 1 ? L.g_off : which == 3 ? L.sg_off : L.dz_off);
     if (n) *n = plan->B;
     if (h) *h = L.out_h;
     if (w) *w = L.out_w;

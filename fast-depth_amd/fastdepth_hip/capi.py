@@ -6,6 +6,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libfastdepth_hip.so")
 
 FD_F32, FD_F16, FD_BF16 = 0, 1, 2
+
+
+class _DtypeMap(dict):
+    def __missing__(self, key):
+        import torch
+        m = {torch.float32: FD_F32, torch.float16: FD_F16, torch.bfloat16: FD_BF16}
+        self.update(m)
+        return m[key]
+
+
+DTYPE_OF = _DtypeMap()      # torch dtype -> fd_dtype (torch imported lazily: this module is also used by tests without torch tensors)
 FD_OP_STEM, FD_OP_DW, FD_OP_PW = 0, 1, 2
 FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
 FD_PLAN_KEEP_ACTIVATIONS = 1

@@ -106,9 +106,12 @@ class Engine:
         if self.model.training:
             # train mode: batch-statistics BatchNorm + hand-written backward behind a torch.autograd.Function
             from .train import TrainCore, autograd_forward
+            tdt = torch.bfloat16 if self.dtype == torch.bfloat16 else torch.float32   # set_compute_dtype(bfloat16) -> bf16 train plan
+            if self.dtype == torch.float16:
+                raise capi.FastDepthError("train mode supports float32 or bfloat16 storage (fp16 gradients would need loss scaling)")
             core = self.__dict__.get("_train_core")
-            if core is None:
-                core = self._train_core = TrainCore(self.model)
+            if core is None or core.dtype != tdt:
+                core = self._train_core = TrainCore(self.model, tdt)
             if torch.is_grad_enabled():
                 return autograd_forward(core, x)
             return core.forward(x)

@@ -22,12 +22,12 @@ from .plan import layers_of
 
 
 class _TrainPlan:
-    def __init__(self, layers, batch, height, width, device):
+    def __init__(self, layers, batch, height, width, device, dtype=torch.float32):
         L = lib()
         n = len(layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in layers])
         handle = ctypes.c_void_p()
-        capi.check(L, L.fd_train_plan_create(descs, n, batch, height, width, capi.FD_F32, 0, ctypes.byref(handle)), "fd_train_plan_create")
+        capi.check(L, L.fd_train_plan_create(descs, n, batch, height, width, capi.DTYPE_OF[dtype], 0, ctypes.byref(handle)), "fd_train_plan_create")
         self.handle = handle
         nbytes = L.fd_train_plan_workspace_bytes(handle)
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
@@ -52,8 +52,11 @@ class TrainCore:
     """Shared plumbing: parameter tables, flat gradient buffer (reverse layer order, so that finished buckets are
     contiguous slices), train plans per input shape."""
 
-    def __init__(self, model):
+    def __init__(self, model, dtype=torch.float32):
         self.model = model
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise capi.FastDepthError("train step storage type must be float32 or bfloat16 (fp16 gradients would need loss scaling)")
+        self.dtype = dtype                        # storage of saved activations / activation gradients / GEMM operands
         self.layers = layers_of(model)
         self.n = len(self.layers)
         dev = self.layers[0].conv.weight.device
@@ -96,10 +99,10 @@ class TrainCore:
 
     def plan_for(self, x):
         b, c, h, w = x.shape
-        key = (b, h, w, x.device.index)
+        key = (b, h, w, x.device.index, self.dtype)
         p = self.plans.get(key)
         if p is None:
-            p = self.plans[key] = _TrainPlan(self.layers, b, h, w, x.device)
+            p = self.plans[key] = _TrainPlan(self.layers, b, h, w, x.device, self.dtype)
         return p
 
     def forward(self, x):
@@ -180,8 +183,9 @@ class TrainEngine(TrainCore):
     step is: local forward/backward on this rank's sub-batch; the flat gradient buffer is all-reduced (sum) bucket by bucket
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
-    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4, force_buckets=False):
-        super().__init__(model)
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4, force_buckets=False,
+                 dtype=torch.float32):
+        super().__init__(model, dtype)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.group = process_group
         self.world = 1

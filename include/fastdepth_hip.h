@@ -140,6 +140,10 @@ typedef struct fd_layer_grads {
     float *bn_bias;
 } fd_layer_grads;
 
+/* dtype: FD_F32, or FD_BF16 = the saved conv outputs z, the activation gradients G and the operands of the pointwise matrix
+ * products are stored in bfloat16 (v_mfma_f32_32x32x16_bf16, fp32 accumulation); master parameters, their gradients, batch
+ * statistics, BatchNorm tables, the 1-channel head, loss and SGD stay fp32.  Channel counts must
+ * then be multiples of 8.  FD_F16 is rejected (fp16 gradients would need loss scaling). */
 int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
                          int32_t dtype, uint32_t flags, fd_train_plan **out_plan);
 void fd_train_plan_destroy(fd_train_plan *plan);
@@ -161,8 +165,10 @@ int fd_train_backward(fd_train_plan *plan, const fd_layer_params *params, const 
 int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
                             const void *dy, int32_t from_layer, int32_t to_layer, void *stream);
 
-/* Test hook: raw conv output z (which == 0) or dLoss/d(BN output) (which == 1) of a layer, NHWC fp32; which == 2: the
- * layer's BatchNorm table as n=1, h=4 (scale, shift, mean, invstd), w=1, c=C. */
+/* Test hook: raw conv output z (which == 0) or dLoss/d(BN output) G (which == 1) of a layer, NHWC in the plan's dtype (the
+ * 1-channel head is fp32 in every plan); which == 2: the layer's BatchNorm table as n=1, h=4 (scale, shift, mean, invstd),
+ * w=1, c=C, fp32; which == 3: the decoder->skip gradient buffer of a skip source; which == 4: the BatchNorm-backward output dz
+ * of a 16-bit pointwise unit (only plans created with FD_PLAN_KEEP_ACTIVATIONS keep G and dz apart and keep per-layer G). */
 int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n,
                           int32_t *h, int32_t *w, int32_t *c);
 

@@ -96,3 +96,47 @@ def test_eval_after_training_uses_updated_running_stats():
         y = m(x.cuda())
     yo = oracle.forward(m.state_dict(), x.numpy())
     assert harness.rel_err(y.cpu().numpy(), yo) < 1e-3
+
+
+@pytest.mark.parametrize("pruned,dtype", [(False, torch.float32), (False, torch.bfloat16), (True, torch.bfloat16)])
+def test_train_step_layer_local_parity_full_size(pruned, dtype):
+    """Every unit's forward and backward kernels on their own stored inputs vs an fp64 single-unit autograd reference, at
+    224x224 (harness.local_train_parity).  For the bf16 plan this is the rigorous parity statement:
+    stored tensors within one bf16 rounding (2^-8 of the tensor's max), everything kept in fp32 at fp32 accuracy."""
+    from test_emu_train import assert_local_parity
+    m = _model(pruned=pruned)
+    x, tgt = _batch(2)
+    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
+    assert_local_parity(rep, dtype)
+
+
+def test_bf16_train_step_end_to_end():
+    """SURVEY.md 8(d) config 3, end to end (the rigorous statement is the layer-local test above).  This randomly initialised
+    train-mode network amplifies relative perturbations ~300x from input to prediction (fp32 rounding, 6e-8, arrives as 2e-5:
+    measured, and the fp64 gradient itself moves by 20 % under 1e-5 parameter noise, see above), so bf16 storage noise (2e-3)
+    saturates the element-wise comparison; what IS stable, and asserted: the loss of the first step against the fp64 oracle, and
+    the optimisation trajectory -- 12 SGD steps on one batch reduce the loss like the fp32 plan does."""
+    from fastdepth_hip.train import TrainEngine
+    x, tgt = _batch(8, seed=4)
+    base = _model(seed=11)
+    p = torch_ref.params_from_state(base.state_dict(), torch.float64, requires_grad=True)
+    loss64, _ = torch_ref.l1_train_grads(p, x.double(), tgt.double())
+    losses = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = copy.deepcopy(base).cuda().train()
+        eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=1e-4, dtype=dt)
+        losses[dt] = [float(eng.step(x.cuda(), tgt.cuda())) for _ in range(12)]
+        assert all(np.isfinite(losses[dt]))
+    assert losses[torch.float32][0] == pytest.approx(float(loss64), rel=1e-4)
+    assert losses[torch.bfloat16][0] == pytest.approx(float(loss64), rel=2e-2)
+    assert losses[torch.float32][-1] < 0.9 * losses[torch.float32][0] and losses[torch.bfloat16][-1] < 0.9 * losses[torch.bfloat16][0]
+    assert losses[torch.bfloat16][-1] == pytest.approx(losses[torch.float32][-1], rel=0.1), losses
+    # the drop-in module honours set_compute_dtype(bfloat16) in train mode: same kernels, same order -> bitwise equal prediction
+    ma, mb = copy.deepcopy(base).cuda().train(), copy.deepcopy(base).cuda().train().set_compute_dtype(torch.bfloat16)
+    pred = TrainEngine(ma, dtype=torch.bfloat16).forward(x.cuda())
+    out = mb(x.cuda())
+    torch.nn.L1Loss()(out, tgt.cuda()).backward()
+    assert torch.equal(out.detach(), pred)
+    assert mb.conv7[3].weight.grad is not None and bool(torch.isfinite(mb.conv7[3].weight.grad).all())
+    with pytest.raises(RuntimeError):
+        copy.deepcopy(base).cuda().train().set_compute_dtype(torch.float16)(x.cuda())       # fp16 training is not offered
