@@ -170,38 +170,44 @@ def main():
                for s, e in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])]
     total_bytes = sum(s[3] for s in stats); total_flops = sum(s[4] for s in stats)
 
-    # ---- secondary measurement: the train step (BASELINE.json metric: "fwd + train-step"), same batch per GPU, fp32
-    train = None
+    # ---- secondary measurement: the train step (BASELINE.json metric: "fwd + train-step"), same batch per GPU: fp32 plan
+    # (`train_step`) and bf16 plan (`train_step_bf16`, BASELINE.json configs[2]/[3]: bf16 storage + bf16 MFMA, fp32 masters)
+    train, train_bf16 = None, None
     if args.train_steps > 0:
         from fastdepth_hip.train import TrainEngine
         import models
-        torch.manual_seed(0)
-        tm = models.MobileNetSkipAdd((224, 224), pretrained=False)
-        tm.decode_conv6[1].bias.data.fill_(2.8)
-        tm = tm.to(dev).train()
-        teng = TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
-                           force_buckets=os.environ.get("FD_BENCH_FORCE_DIST") == "1")
-        tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=g)).to(dev)     # synthetic depth, U[0.7, 10) m
-        for _ in range(3):
-            loss = teng.step(x, tgt)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.train_steps):
-            loss = teng.step(x, tgt)
-        torch.cuda.synchronize()
-        t_el = time.perf_counter() - t1
-        barrier()
-        tt = torch.tensor([t_el], dtype=torch.float64, device=dev)
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_el = float(tt.item())
-        assert torch.isfinite(loss).all()
-        train = {"metric": "frames/sec (224x224) train step: fwd + L1 loss + bwd + gradient all-reduce + SGD(momentum, wd)",
-                 "value": round(world * args.batch * args.train_steps / t_el, 1), "unit": "frames/s", "steps": args.train_steps, "warmup": 3,
-                 "ms_per_step": round(t_el / args.train_steps * 1e3, 4), "dtype": "f32", "batch_per_gpu": args.batch,
-                 "parallelism": "dp%d (RCCL all-reduce of the 15.84 MB gradient vector, %d buckets overlapped with backward)" % (world, len(teng.buckets))
-                                if world > 1 else "single GPU", "final_loss": round(float(loss), 5)}
-        del teng, tm
+
+        def time_train(dtype, tag):
+            torch.manual_seed(0)
+            tm = models.MobileNetSkipAdd((224, 224), pretrained=False)
+            tm.decode_conv6[1].bias.data.fill_(2.8)
+            tm = tm.to(dev).train()
+            teng = TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
+                               force_buckets=os.environ.get("FD_BENCH_FORCE_DIST") == "1", dtype=dtype)
+            gt = torch.Generator().manual_seed(1)
+            tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=gt)).to(dev)     # synthetic depth, U[0.7, 10) m
+            for _ in range(3):
+                loss = teng.step(x, tgt)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.train_steps):
+                loss = teng.step(x, tgt)
+            torch.cuda.synchronize()
+            t_el = time.perf_counter() - t1
+            barrier()
+            tt = torch.tensor([t_el], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_el = float(tt.item())
+            assert torch.isfinite(loss).all()
+            return {"metric": "frames/sec (224x224) train step: fwd + L1 loss + bwd + gradient all-reduce + SGD(momentum, wd)",
+                    "value": round(world * args.batch * args.train_steps / t_el, 1), "unit": "frames/s", "steps": args.train_steps, "warmup": 3,
+                    "ms_per_step": round(t_el / args.train_steps * 1e3, 4), "dtype": tag, "batch_per_gpu": args.batch,
+                    "parallelism": "dp%d (RCCL all-reduce of the 15.84 MB fp32 gradient vector, %d buckets overlapped with backward)" % (world, len(teng.buckets))
+                                   if world > 1 else "single GPU", "final_loss": round(float(loss), 5)}
+
+        train = time_train(torch.float32, "f32")
+        train_bf16 = time_train(torch.bfloat16, "bf16 storage + bf16 MFMA, fp32 accumulate / master weights / statistics")
 
     # ---- other BASELINE.json configurations, measured briefly on rank 0 only (N=1): parity for them is in tests/test_gpu_parity.py
     extras = []
@@ -257,6 +263,7 @@ def main():
                            "roofline_bound_ms": None},
             "kernels": kernels,
             "train_step": train,
+            "train_step_bf16": train_bf16,
             "other_configs": extras,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -18,6 +18,7 @@
 inline void fd_glds16(const float *g, float *lds_wave_base) { memcpy((char *)lds_wave_base + hipemu::lane_id() * 16, g, 16); }
 template <int N> inline void fd_wait_vmcnt() {}
 #define FD_SCHED_FENCE() ((void)0)
+#define FD_OPAQUE(x) ((void)0)
 inline void fd_block_barrier_lds() { __syncthreads(); }
 inline void fd_block_barrier() { __syncthreads(); }
 #else
@@ -30,6 +31,9 @@ __device__ __forceinline__ void fd_glds16(const float *g, float *lds_wave_base)
 template <int N> __device__ __forceinline__ void fd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // keeps the compiler's scheduler from moving instructions across this point (source order = issue order)
 #define FD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// makes the compiler forget what it knows about the integer x: loads addressed through it are not hoisted out of the enclosing loop
+// (used to keep per-channel tables out of registers while they are not needed)
+#define FD_OPAQUE(x) asm volatile("" : "+v"(x))
 // raw s_barrier: unlike __syncthreads() it does not drain vmcnt, so LDS-DMA loads stay in flight across it
 __device__ __forceinline__ void fd_block_barrier() { __builtin_amdgcn_s_barrier(); }
 // the same, after this wave's own LDS writes/reads have completed (lgkmcnt) -- still without draining vector-memory loads
@@ -99,6 +103,22 @@ __device__ __forceinline__ void fd_st4(fd_bf16 *p, fd_f32x4 v)
 {
     fd_u16x4 h = {fd_f32_to_bf16(v.x), fd_f32_to_bf16(v.y), fd_f32_to_bf16(v.z), fd_f32_to_bf16(v.w)};
     *reinterpret_cast<fd_u16x4 *>(p) = h;
+}
+// raw (unconverted) 4-channel loads: lets a kernel keep prefetched 16-bit data in half the registers until it is used
+__device__ __forceinline__ fd_f32x4 fd_ldraw4(const float *p) { return *reinterpret_cast<const fd_f32x4 *>(p); }
+__device__ __forceinline__ fd_u16x4 fd_ldraw4(const fd_half *p) { return *reinterpret_cast<const fd_u16x4 *>(p); }
+__device__ __forceinline__ fd_u16x4 fd_ldraw4(const fd_bf16 *p) { return *reinterpret_cast<const fd_u16x4 *>(p); }
+__device__ __forceinline__ fd_f32x4 fd_cvt4(float, fd_f32x4 r) { return r; }
+__device__ __forceinline__ fd_f32x4 fd_cvt4(fd_half, fd_u16x4 r)
+{
+    const fd_f16x4 h = __builtin_bit_cast(fd_f16x4, r);
+    fd_f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return v;
+}
+__device__ __forceinline__ fd_f32x4 fd_cvt4(fd_bf16, fd_u16x4 r)
+{
+    fd_f32x4 v = {fd_bf16_to_f32(r.x), fd_bf16_to_f32(r.y), fd_bf16_to_f32(r.z), fd_bf16_to_f32(r.w)};
+    return v;
 }
 __device__ __forceinline__ float fd_ld1(const float *p) { return *p; }
 __device__ __forceinline__ float fd_ld1(const fd_half *p) { return (float)*p; }

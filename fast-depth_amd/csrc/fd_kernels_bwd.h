@@ -595,7 +595,32 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
             const int ly = p / TW2, lx = p - ly * TW2;
             const int gy = iy0 + 2 * ly, gx = ix0 + 2 * lx;     // top-left full-res position of the 2x2 block
             if (!c_ok || gy >= Hin || gx >= Win) continue;
-            fd_f32x4 d00 = din_at(2 * ly, 2 * lx), d01 = din_at(2 * ly, 2 * lx + 1), d10 = din_at(2 * ly + 1, 2 * lx), d11 = din_at(2 * ly + 1, 2 * lx + 1);
+            fd_f32x4 d00, d01, d10, d11;
+            if (S == 1) {
+                // the four positions of the block read a (K+1) x (K+1) window of the dz patch: walk it row by row, every row feeds
+                // the block's upper row with tap row ky = K-1-r and its lower row with ky = K-r (one pass over LDS, few registers)
+                d00 = fd_zero4(); d01 = fd_zero4(); d10 = fd_zero4(); d11 = fd_zero4();
+                const int pyb = gy + P - (K - 1) - oyb, pxb = gx + P - (K - 1) - oxb;
+#pragma unroll 1
+                for (int r = 0; r <= K; ++r) {
+                    fd_f32x4 v[K + 1];
+                    const float *row = s_dz + ((pyb + r) * PW + pxb) * PSTR + c4 * 4;
+#pragma unroll
+                    for (int c = 0; c <= K; ++c) v[c] = fd_ld4(row + c * PSTR);
+                    if (r < K) {
+                        const float *wr = s_w + (K - 1 - r) * K * CB + c4 * 4;
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d00 += v[K - 1 - kx] * wv; d01 += v[K - kx] * wv; }
+                    }
+                    if (r > 0) {
+                        const float *wr = s_w + (K - r) * K * CB + c4 * 4;
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d10 += v[K - 1 - kx] * wv; d11 += v[K - kx] * wv; }
+                    }
+                }
+            } else {
+                d00 = din_at(2 * ly, 2 * lx); d01 = din_at(2 * ly, 2 * lx + 1); d10 = din_at(2 * ly + 1, 2 * lx); d11 = din_at(2 * ly + 1, 2 * lx + 1);
+            }
             if (MODE == 2) {
                 const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
                 fd_st4(SGout + o, d00); fd_st4(SGout + o + C, d01);
@@ -636,7 +661,7 @@ __global__ void __launch_bounds__(256)
 fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
-                int cbq, int TH, int TW, int tiles_x)
+                int cbq, int TH, int TW, int tiles_x, int tpw)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
@@ -645,22 +670,47 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
     float *s_in = smem;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    // a workgroup walks `tpw` horizontally adjacent tiles and keeps its tap sums in registers across them: one workgroup
+    // reduction and one partial row per `tpw` tiles
+    const int groups_x = (tiles_x + tpw - 1) / tpw;
+    const int ty = blockIdx.x / groups_x, tgx = blockIdx.x - ty * groups_x;
     const int c0 = blockIdx.y * CB, n = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
+    const int oy0 = ty * TH;
+    const int iy0 = oy0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
     const int cg = c0 + c4 * 4;
     const bool c_ok = cg < C;
-    fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
-    fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
-    if (c_ok) {
-        s1 = fd_ld4(st1 + FD_ST_SCALE * C + cg); t1 = fd_ld4(st1 + FD_ST_SHIFT * C + cg);
-        if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + cg); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + cg); }
-        cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg);
+    int tab_c = c_ok ? cg : 0;                             // channel offset of this work-item's table entries (re-read per tile, see FD_OPAQUE)
+    fd_f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = fd_zero4();
+#pragma unroll 1
+    for (int ti = 0; ti < tpw; ++ti) {
+    const int tx = tgx * tpw + ti;
+    if (tx >= tiles_x) break;
+    const int ox0 = tx * TW, ix0 = ox0 * S - P;
+    if (ti > 0) __syncthreads();                           // the previous tile's patch reads are done
+    // the BN-backward operands (G, z) of this work-item's FIRST output strip are requested before the input patch is staged,
+    // so that their latency overlaps the staging loads instead of following the barrier
+    const int TWS = TW >> 2, nstrips = TH * TWS;
+    constexpr bool PREFETCH = K == 5;                      // 3x3: the extra live registers cost more (occupancy) than the overlap gains
+    decltype(fd_ldraw4(G)) g0[4], z0[4];
+    {
+        const int oy = pt / TWS, ox = (pt - oy * TWS) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = oy0 + oy, gx = ox0 + ox + j;
+            if (PREFETCH && pt < nstrips && c_ok && gy < Ho && gx < Wo) {
+                const long o = (((long)n * Ho + gy) * Wo + gx) * C + cg;
+                g0[j] = fd_ldraw4(G + o); z0[j] = fd_ldraw4(Z + o);
+            }
+        }
     }
+    FD_OPAQUE(tab_c);
+    fd_f32x4 s1 = fd_ld4(st1 + FD_ST_SCALE * C + tab_c), t1 = fd_ld4(st1 + FD_ST_SHIFT * C + tab_c), s2 = fd_zero4(), t2 = fd_zero4();
+    if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + tab_c); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
-    constexpr int U = 8;
+    constexpr int U = 4;
     for (int base = pt; base < npx_in; base += npt * U) {
         fd_f32x4 v[U], sk[U];
         bool ok[U];
@@ -695,10 +745,8 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
         }
     }
     __syncthreads();
-    fd_f32x4 acc[K * K];
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = fd_zero4();
-    const int TWS = TW >> 2, nstrips = TH * TWS;
+    FD_OPAQUE(tab_c);
+    const fd_f32x4 cA = fd_ld4(coef + FD_CF_A * C + tab_c), c1 = fd_ld4(coef + FD_CF_C1 * C + tab_c), cM = fd_ld4(coef + FD_CF_MU * C + tab_c), c2 = fd_ld4(coef + FD_CF_C2 * C + tab_c);
     for (int s = pt; s < nstrips; s += npt) {
         const int oy = s / TWS, ox = (s - oy * TWS) * 4;
         const int gy = oy0 + oy;
@@ -708,8 +756,12 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
             const int gx = ox0 + ox + j;
             dz[j] = fd_zero4();
             if (c_ok && gy < Ho && gx < Wo) {
-                const long o = (((long)n * Ho + gy) * Wo + gx) * C + cg;
-                dz[j] = fd_dz4(fd_ld4(G + o), fd_ld4(Z + o), cA, c1, cM, c2);
+                if (PREFETCH && s == pt) {
+                    dz[j] = fd_dz4(fd_cvt4(T{}, g0[j]), fd_cvt4(T{}, z0[j]), cA, c1, cM, c2);
+                } else {
+                    const long o = (((long)n * Ho + gy) * Wo + gx) * C + cg;
+                    dz[j] = fd_dz4(fd_ld4(G + o), fd_ld4(Z + o), cA, c1, cM, c2);
+                }
             }
         }
 #pragma unroll
@@ -722,8 +774,10 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
             for (int kx = 0; kx < K; ++kx)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[ky * K + kx] += r[j * S + kx] * dz[j];
+            FD_SCHED_FENCE();                               // keep the next row's LDS reads from being hoisted above these FMAs (registers)
         }
     }
+    }   // tile loop
     // workgroup reduction over the pixel-threads (fixed order): lanes of a wave that share a channel group are combined with
     // xor-shuffles (lane = c4 + lanes_c * pixel-thread), the waves' results meet in LDS
     __syncthreads();
@@ -750,41 +804,80 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps; workgroup = 256 pixels.
-// wpart[blk][Cout*27].
+// Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps -- a [Cout x P] x [P x 27] matrix
+// product over the P = B*Ho*Wo output pixels.  A workgroup walks blocks of 256 pixels (grid-stride), stages dz (formed from
+// G, z on load) and the 27-tap input patches in LDS and feeds them to v_mfma_f32_32x32x2_f32: A[i = co][k = pixel],
+// B[k = pixel][j = tap], each wave accumulating 64 pixels of every block.  wpart[blk][Cout*27], blk = blockIdx.x.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
 fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__restrict__ Z,
-                  const float *__restrict__ coef, float *__restrict__ wpart, int B, int H, int W, int Cout)
+              const float *__restrict__ coef, float *__restrict__ wpart, int B, int H, int W, int Cout, int nblocks)
 {
     FD_DYN_SMEM(smem_raw);
-    float *s_in = reinterpret_cast<float *>(smem_raw);     // [256][28]
-    float *s_dz = s_in + 256 * 28;                          // [256][Cout + 1]
+    float *s_in = reinterpret_cast<float *>(smem_raw);     // [256][33]: taps 0..26, zeros in 27..31
+    float *s_dz = s_in + 256 * 33;                          // [256][Cout + 1]
     const int Ho = H >> 1, Wo = W >> 1;
     const long npix = (long)B * Ho * Wo;
-    const int tid = threadIdx.x;
-    const long p = (long)blockIdx.x * 256 + tid;
-    const bool valid = p < npix;
-    int n = 0, oy = 0, ox = 0;
-    if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
-    for (int c = 0; c < 3; ++c)
-        for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-                const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                s_in[tid * 28 + (c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
-            }
-    for (int co = 0; co < Cout; ++co) {
-        float dz = 0.0f;
-        if (valid) dz = fd_dz(fd_ld1(G + p * Cout + co), fd_ld1(Z + p * Cout + co), coef[FD_CF_A * Cout + co], coef[FD_CF_C1 * Cout + co], coef[FD_CF_MU * Cout + co], coef[FD_CF_C2 * Cout + co]);
-        s_dz[tid * (Cout + 1) + co] = dz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int DP = Cout + 1;
+    const int cgroups = (Cout + 31) / 32;                   // 32-channel column groups of the A operand (<= 2 supported)
+    fd_f32x16 acc[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+    for (int t = 27; t < 32; ++t) s_in[tid * 33 + t] = 0.0f;
+    for (int pb = blockIdx.x; pb < nblocks; pb += gridDim.x) {
+        const long p = (long)pb * 256 + tid;
+        const bool valid = p < npix;
+        int n = 0, oy = 0, ox = 0;
+        if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
+        __syncthreads();                                    // the previous block's fragment reads are done
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                    const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    s_in[tid * 33 + (c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
+                }
+        for (int c = 0; c < Cout; c += 4) {
+            fd_f32x4 dz = fd_zero4();
+            if (valid) dz = fd_dz4(fd_ld4(G + p * Cout + c), fd_ld4(Z + p * Cout + c), fd_ld4(coef + FD_CF_A * Cout + c), fd_ld4(coef + FD_CF_C1 * Cout + c),
+                                   fd_ld4(coef + FD_CF_MU * Cout + c), fd_ld4(coef + FD_CF_C2 * Cout + c));
+            s_dz[tid * DP + c] = dz.x; s_dz[tid * DP + c + 1] = dz.y; s_dz[tid * DP + c + 2] = dz.z; s_dz[tid * DP + c + 3] = dz.w;
+        }
+        __syncthreads();
+        const int i = lane & 31, kk = lane >> 5;
+#pragma unroll 4
+        for (int q = 0; q < 32; ++q) {
+            const int px = wave * 64 + 2 * q + kk;
+            const float b = s_in[px * 33 + i];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (g < cgroups) {
+                    const int co = g * 32 + i;
+                    const float a = co < Cout ? s_dz[px * DP + co] : 0.0f;
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+                }
+        }
     }
+    // cross-wave reduction through LDS: red[wave][32 co][33]
     __syncthreads();
-    for (int o = tid; o < Cout * 27; o += 256) {
-        const int co = o / 27, t = o - co * 27;
-        float s = 0.0f;
-        for (int px = 0; px < 256; ++px) s = fmaf(s_dz[px * (Cout + 1) + co], s_in[px * 28 + t], s);
-        wpart[(long)blockIdx.x * Cout * 27 + o] = s;
+    float *red = s_in;                                      // 4 * 32 * 33 floats <= 256 * 33
+    for (int g = 0; g < cgroups; ++g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[g][r];
+        __syncthreads();
+        for (int o = tid; o < 32 * 27; o += 256) {
+            const int co = o / 27, t = o - co * 27;
+            if (g * 32 + co < Cout)
+                wpart[(long)blockIdx.x * Cout * 27 + (g * 32 + co) * 27 + t] =
+                    (red[(0 * 32 + co) * 33 + t] + red[(1 * 32 + co) * 33 + t]) + (red[(2 * 32 + co) * 33 + t] + red[(3 * 32 + co) * 33 + t]);
+        }
+        __syncthreads();
     }
 }

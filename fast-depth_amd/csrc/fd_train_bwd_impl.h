@@ -66,12 +66,19 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     float *wpart = tws(c.p, c.p->wpart_off);
+    // tiles per workgroup (along x): as many as keep >= ~1536 workgroups in flight
+    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.grid.x * L.grid.y * L.grid.z / 1536)));
+    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
+    const int groups_x = ceil_div(L.tiles_x, tpw);
+    tpw = ceil_div(L.tiles_x, groups_x);
+    const dim3 wgrid(groups_x * L.tiles_y, L.grid.y, L.grid.z);
+    const int wblk = groups_x * L.tiles_y * c.p->B;
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
-        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
+        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), L.lds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
-                  L.cbq, L.th, L.tw, L.tiles_x);                                                                                   \
+                  L.cbq, L.th, L.tw, L.tiles_x, tpw);                                                                              \
         break;
     switch (key) {
         FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2)
@@ -82,7 +89,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     if (rc) return rc;
     const int kk = L.d.ksize * L.d.ksize;
     int rows = 0;
-    const float *pr = slice_rows(c.p, wpart, L.nblk, kk * L.d.cin, c.s, &rows, &rc);
+    const float *pr = slice_rows(c.p, wpart, wblk, kk * L.d.cin, c.s, &rows, &rc);
     if (rc) return rc;
     FD_LAUNCH(fd_reduce_partials_tapmajor_f32, dim3(ceil_div((long)kk * L.d.cin, 64)), dim3(1024), 0, c.s, pr, rows, kk, L.d.cin, c.grads[i].conv_weight);
     return check_launch("fd_reduce_partials_tapmajor_f32");
@@ -239,17 +246,20 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         const fd_layer_desc &d = L.d;
         int nblk = 0;
         switch (d.op) {
-        case FD_OP_STEM:
-            FD_LAUNCH((fd_stem_wgrad<T>), L.grid, dim3(256), (size_t)(256 * 28 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout);
+        case FD_OP_STEM: {
+            const int nb_w = std::min(L.nblk, 512);          // workgroups walk the 256-pixel blocks grid-stride
+            if (d.cout > 64) return fail(FD_ERR_INVALID, "stem weight gradient supports at most 64 output channels");
+            FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), (size_t)(256 * 33 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout, L.nblk);
             if ((rc = check_launch("fd_stem_wgrad"))) return rc;
             {
                 int rows = 0;
-                const float *pr = slice_rows(plan, wpart, L.nblk, 27 * d.cout, s, &rows, &rc);
+                const float *pr = slice_rows(plan, wpart, nb_w, 27 * d.cout, s, &rows, &rc);
                 if (rc) return rc;
                 FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, pr, rows, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
             }
             if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
             break;
+        }
         case FD_OP_DW: {
             if ((rc = launch_dw_wgrad<T>(c, i))) return rc;
             const TLayer &P = plan->layers[d.src];

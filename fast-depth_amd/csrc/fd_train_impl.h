@@ -47,6 +47,7 @@ struct TLayer {
 struct fd_train_plan {
     std::vector<TLayer> layers;
     int B = 0, H = 0, W = 0, dtype = FD_F32;
+    uint32_t flags = 0;
     size_t esz = 4;                  // bytes per stored activation / activation-gradient element
     size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0, part2_off = 0, part2_bytes = 0;
     unsigned char *ws = nullptr;
@@ -204,7 +205,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     if (dtype != FD_F32 && dtype != FD_BF16)
         return fail(FD_ERR_INVALID, "train plan: dtype %d not supported (fp32 or bf16; fp16 gradients would need loss scaling)", dtype);
     fd_train_plan *p = new fd_train_plan();
-    p->B = batch; p->H = height; p->W = width; p->dtype = dtype;
+    p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
     const bool h16 = dtype != FD_F32;
     const size_t esz = h16 ? 2 : 4;
     p->esz = esz;

@@ -21,6 +21,7 @@ FD_OP_STEM, FD_OP_DW, FD_OP_PW = 0, 1, 2
 FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
 FD_PLAN_KEEP_ACTIVATIONS = 1
 FD_PLAN_FUSE_SEPARABLE = 4
+FD_PLAN_WGRAD_TILE_ROWS = 8
 
 
 class LayerDesc(ctypes.Structure):

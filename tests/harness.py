@@ -118,7 +118,7 @@ def compare_with_oracle(kind, model, x, device, dtype=torch.float32):
 class CTrainPlan:
     """fd_train_plan + workspace; parameters are private fp32 copies on the plan's device (running stats get updated in place)."""
 
-    def __init__(self, kind, model, x, keep=False, dtype=torch.float32):
+    def __init__(self, kind, model, x, keep=False, dtype=torch.float32, flags=0):
         self.lib = L = get_lib(kind)
         self.dtype = dtype
         self.dev = x.device
@@ -127,7 +127,7 @@ class CTrainPlan:
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         self.h = ctypes.c_void_p()
         b, _, hh, ww = x.shape
-        capi.check(L, L.fd_train_plan_create(descs, n, b, hh, ww, capi.DTYPE_OF[dtype], capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0, ctypes.byref(self.h)), "fd_train_plan_create")
+        capi.check(L, L.fd_train_plan_create(descs, n, b, hh, ww, capi.DTYPE_OF[dtype], (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | flags, ctypes.byref(self.h)), "fd_train_plan_create")
         nbytes = L.fd_train_plan_workspace_bytes(self.h)
         self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.dev)
         base = (self.ws.data_ptr() + 255) // 256 * 256
@@ -248,7 +248,7 @@ def assert_train_parity(rep, tol=1e-3):
     assert not bad, "gradient tensors out of tolerance (abs err, norm): %s" % bad
 
 
-def local_train_parity(kind, model, x, target, device, dtype=torch.float32):
+def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flags=0):
     """Layer-LOCAL parity of one train step (forward + backward) through the C ABI, valid for fp32 and bf16 plans.
 
     The end-to-end comparison of train_parity_report is meaningless once activations are stored in bfloat16 on a tiny network
@@ -265,7 +265,7 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32):
     h16 = dtype != torch.float32
     rnd = (lambda t: t.float().to(dtype).double()) if h16 else (lambda t: t)
     run0 = [(l.bn.running_mean.detach().double().clone(), l.bn.running_var.detach().double().clone()) for l in layers_of(model)]
-    tp = CTrainPlan(kind, model, x.to(device), keep=True, dtype=dtype)
+    tp = CTrainPlan(kind, model, x.to(device), keep=True, dtype=dtype, flags=flags)
     y = tp.forward(x.to(device)).cpu()
     dpred = torch.sign(y - target) / y.numel()
     grads = tp.backward(dpred)

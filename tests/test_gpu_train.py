@@ -106,7 +106,8 @@ def test_train_step_layer_local_parity_full_size(pruned, dtype):
     from test_emu_train import assert_local_parity
     m = _model(pruned=pruned)
     x, tgt = _batch(2)
-    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
+    from fastdepth_hip import capi
+    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype, flags=capi.FD_PLAN_WGRAD_TILE_ROWS if pruned else 0)
     assert_local_parity(rep, dtype)
 
 
