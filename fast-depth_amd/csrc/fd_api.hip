@@ -6,6 +6,7 @@
 // fixed grids, tile shapes and buffer addresses, so a forward is ~38 back-to-back launches on the
 // caller's stream with no host-side decisions, allocations or synchronisation in between.
 #include "fd_kernels_f32.h"
+#include "fd_kernels_sk_f32.h"
 #include "fd_kernels_h16.h"
 #include "fd_kernels_fused_f32.h"
 #include "../../include/fastdepth_hip.h"
@@ -79,6 +80,8 @@ struct Layer {
     // pw
     PwCfg pw{};
     int m_tiles = 0, n_tiles = 0, w_pitch = 0;
+    bool sk = false;             // data-parallel rounds + stream-K remainder (fd_pw_gemm_sk_f32)
+    int sk_dp_rounds = 0, sk_base = 0, sk_rem = 0;
     size_t lds = 0;
     dim3 grid;
     std::string info, sym;
@@ -92,6 +95,7 @@ struct fd_plan {
     int B = 0, H = 0, W = 0, dtype = 0;
     uint32_t flags = 0;
     size_t ws_bytes = 0, weights_bytes = 0;
+    size_t sk_scratch_off = 0, sk_scratch_bytes = 0, sk_counter_off = 0, sk_counter_bytes = 0;   // stream-K partial tiles / per-tile arrival counters
     unsigned char *ws = nullptr;
     bool packed = false;
     double alg_bytes = 0, alg_flops = 0;
@@ -209,10 +213,26 @@ int launch_dw(const Layer &L, const T *in, const T *skip, const float *wp, const
 }
 
 template <int ACT>
-int launch_pw(const Layer &L, const float *A, const float *wp, const float *bias, float *out, long M, hipStream_t s)
+int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *wp, const float *bias, float *out, long M, hipStream_t s)
 {
     const int N = L.d.cout, K = L.d.cin;
     const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
+    if (L.sk) {
+        float *scratch = reinterpret_cast<float *>(plan->ws + plan->sk_scratch_off);
+        int *counters = reinterpret_cast<int *>(plan->ws + plan->sk_counter_off);
+#define FD_SK_CASE(a, b, c, d) \
+    case a * 1000 + b * 100 + c * 10 + d: \
+        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_sk_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        FD_LAUNCH((fd_pw_gemm_sk_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.m_tiles, L.n_tiles, \
+                  L.sk_dp_rounds, L.sk_base, L.sk_rem, scratch, counters); break;
+        switch (key) {
+            FD_SK_CASE(2, 2, 2, 1)
+            FD_SK_CASE(2, 2, 1, 1)
+        default: return fail(FD_ERR_INVALID, "no stream-K pointwise tile %d", key);
+        }
+#undef FD_SK_CASE
+        return check_launch("fd_pw_gemm_sk_f32");
+    }
 #define FD_PW_CASE(a, b, c, d) \
     case a * 1000 + b * 100 + c * 10 + d: \
         if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_pw_gemm_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
@@ -248,12 +268,12 @@ int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *
 }
 
 template <int ACT>
-int launch_pw_t(const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
+int launch_pw_t(const fd_plan *plan, const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
 {
-    return launch_pw<ACT>(L, A, static_cast<const float *>(wp), bias, out, M, s);
+    return launch_pw<ACT>(plan, L, A, static_cast<const float *>(wp), bias, out, M, s);
 }
 template <int ACT, typename T>
-int launch_pw_t(const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s)
+int launch_pw_t(const fd_plan *, const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s)
 {
     const int K = L.d.cin;
     FD_LAUNCH((fd_pw_gemm_h16<T, ACT>), L.grid, dim3(256), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, (K + 63) / 64 * 64,
@@ -291,7 +311,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
                 return fail(FD_ERR_INVALID, "fused units are fp32 only");
             }
         }
-        return launch_pw_t<ACT>(L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
+        return launch_pw_t<ACT>(p, L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
     }
     return fail(FD_ERR_INVALID, "bad op");
 }
@@ -333,7 +353,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
     p->layers.resize(n_layers);
     const size_t esz = dtype == FD_F32 ? 4 : 2;   // activation / pointwise-weight element size
-    size_t woff = 0;
+    size_t woff = 0, sk_scratch = 0, sk_counters = 0;
     for (int i = 0; i < n_layers; ++i) {
         Layer &L = p->layers[i];
         L.d = layers[i];
@@ -416,6 +436,26 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
                 L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));   // 1-D, XCD-aware mapping inside the kernel
+                // EXPERIMENTAL, opt-in (FD_PLAN_STREAMK): measured on MI355X at batch 32 the balanced decomposition takes exactly as long as
+                // the plain launch (conv7.3: 40.2 vs 40.0 us, conv13.3: 40.3 vs 39.9 us) -- see fd_kernels_sk_f32.h
+                if (dtype == FD_F32 && (flags & FD_PLAN_STREAMK) && L.pw.wgm == 2 && L.pw.wgn == 2 && L.pw.tn == 1) {
+                    // resident capacity: 256 CUs x (160 KiB LDS / ring size); one workgroup per slot
+                    const int per_cu = std::min(4, (int)(160 * 1024 / (L.lds + 256)));
+                    const int P = 256 * per_cu;
+                    const long tiles = (long)L.m_tiles * L.n_tiles;
+                    const int T = L.w_pitch / 32;
+                    const double eff = (double)tiles / ((double)ceil_div(tiles, P) * P);      // last-round occupancy of the plain launch
+                    (void)eff;
+                    if (T >= 2) {
+                        L.sk = true;
+                        L.sk_dp_rounds = (int)(tiles / P);
+                        const long units = (tiles % P) * T;
+                        L.sk_base = (int)(units / P); L.sk_rem = (int)(units % P);
+                        L.grid = dim3((unsigned)P);
+                        sk_scratch = std::max(sk_scratch, (size_t)P * 2 * (L.pw.wgm * L.pw.tm * 32) * (L.pw.wgn * L.pw.tn * 32) * 4);
+                        sk_counters = std::max(sk_counters, (size_t)P * 4);
+                    }
+                }
             }
             break;
         default: FD_BAD("layer %d: unknown op %d", i, d.op);
@@ -476,6 +516,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         L.out_off = woff + fl.alloc(L.out_bytes);
     }
     p->ws_bytes = woff + fl.top;
+    if (sk_scratch) {
+        p->sk_scratch_off = align_up(p->ws_bytes, 256); p->sk_scratch_bytes = sk_scratch;
+        p->sk_counter_off = p->sk_scratch_off + align_up(sk_scratch, 256); p->sk_counter_bytes = sk_counters;
+        p->ws_bytes = p->sk_counter_off + align_up(sk_counters, 256);
+    }
 
     // bookkeeping: algorithmic traffic and descriptions (SURVEY.md 8(d) convention)
     for (int i = 0; i < n_layers; ++i) {
@@ -508,6 +553,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (L.head)
             snprintf(buf, sizeof buf, "head_pw1 up=%d grid=%u", d.upsample, L.grid.x);
         else
+            if (L.sk)
+                snprintf(buf, sizeof buf, "pw_gemm_sk<%dx%d> M=%ld N=%d K=%d tiles=%dx%d on %u workgroups: %d full round(s) + stream-K %d.%03d K-tiles each, lds=%zu",
+                         L.pw.wgm * L.pw.tm * 32, L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.grid.x,
+                         L.sk_dp_rounds, L.sk_base, (int)(1000L * L.sk_rem / L.grid.x), L.lds);
+            else
             snprintf(buf, sizeof buf, "pw_gemm<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
                      L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         L.info = buf;
@@ -518,7 +568,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
-        else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
+        else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_%sf32<%d, %d, %d, %d, %d>", L.sk ? "sk_" : "", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);
         L.sym = buf;
     }
@@ -566,6 +616,9 @@ int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n
                                reinterpret_cast<float *>(plan->ws + L.w_off), bptr, L.d.cout, inner, transpose, pitch);
         int rc = check_launch("fd_pack_fold");
         if (rc) return rc;
+    }
+    if (plan->sk_counter_bytes) {   // stream-K arrival counters start at 0 (the kernels return them to 0)
+        if (hipMemsetAsync(plan->ws + plan->sk_counter_off, 0, plan->sk_counter_bytes, s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync(stream-K counters) failed");
     }
     plan->packed = true;
     return FD_OK;

@@ -22,6 +22,7 @@ FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
 FD_PLAN_KEEP_ACTIVATIONS = 1
 FD_PLAN_FUSE_SEPARABLE = 4
 FD_PLAN_WGRAD_TILE_ROWS = 8
+FD_PLAN_STREAMK = 32
 
 
 class LayerDesc(ctypes.Structure):

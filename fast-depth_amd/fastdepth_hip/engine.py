@@ -5,6 +5,7 @@ PyTorch is used for what the boundary leaves to the host: device memory (`torch.
 stream, parameter storage.  All arithmetic happens in libfastdepth_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -32,7 +33,7 @@ class _Plan:
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         handle = ctypes.c_void_p()
         capi.check(L, L.fd_plan_create(descs, n, batch, height, width, _DTYPES[engine.dtype],
-                                       capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0, ctypes.byref(handle)), "fd_plan_create")
+                                       (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | engine.plan_flags, ctypes.byref(handle)), "fd_plan_create")
         self.dtype = engine.dtype
         self.handle = handle
         self.shape = (batch, height, width)
@@ -58,6 +59,7 @@ class Engine:
         self.model = model
         self.layers = layers_of(model)
         self.keep = keep_activations
+        self.plan_flags = int(os.environ.get("FD_PLAN_FLAGS", "0"), 0)     # extra fd_plan_create flags (tuning experiments: FD_PLAN_STREAMK = 32, FD_PLAN_FUSE_SEPARABLE = 4)
         self.plans = {}
         self.set_dtype(dtype)
 

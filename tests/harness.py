@@ -100,14 +100,16 @@ def randomize_bn(model, seed):
     return model
 
 
-def compare_with_oracle(kind, model, x, device, dtype=torch.float32):
+def compare_with_oracle(kind, model, x, device, dtype=torch.float32, flags=0):
     """Runs the C ABI path and the C oracle on the same weights/input; returns (rel err of the output,
     [rel err per fused layer], plan info)."""
     from oracle import oracle
     model = model.eval()
     y_ref, taps_ref = oracle.forward(model.state_dict(), x.numpy(), taps=True)
-    plan = CPlan(kind, model, x.to(device), dtype=dtype)
+    plan = CPlan(kind, model, x.to(device), dtype=dtype, flags=flags)
     y = plan.forward(x.to(device)).cpu().numpy()
+    y2 = plan.forward(x.to(device)).cpu().numpy()          # a second pass over the same plan (stream-K counters must have returned to 0)
+    assert np.array_equal(y, y2), "forward is not reproducible run to run"
     errs = [rel_err(plan.tap(i).numpy(), taps_ref[i]) for i in range(len(taps_ref) - 1)]
     errs.append(rel_err(y, y_ref))
     info = plan.info()

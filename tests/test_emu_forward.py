@@ -34,6 +34,19 @@ def test_emulated_forward_matches_oracle(name, plan, b, hw):
     assert err < TOL
 
 
+def test_emulated_stream_k_gemm_matches_oracle():
+    """fd_pw_gemm_sk_f32 (opt-in: data-parallel rounds + stream-K remainder, partial tiles reduced by the last arriver) on every
+    pointwise layer with >= 2 K tiles of the ragged plan -- tiles << workgroups here, so every tile is split across several
+    workgroups and goes through the scratch / counter path."""
+    m = small_model(RAGGED[0], RAGGED[1], seed=11)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(1, 3, 32, 32, generator=g)
+    err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), flags=harness.capi.FD_PLAN_STREAMK)
+    assert sum("pw_gemm_sk" in s for s in info) >= 10, info
+    bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
+    assert not bad and err < TOL, bad
+
+
 def test_plan_rejects_bad_shapes():
     m = small_model(*TINY, seed=1)
     with pytest.raises(harness.capi.FastDepthError):
