@@ -153,8 +153,12 @@ PwCfg choose_pw(long M, int N)
     // Exception (same measurements): the 14x14 layers (M = 6272 at batch 32, N, K >= 256) run 13 % faster on 128x64 --
     // both shapes are bound by the same wave quantisation (3.06 32x32 tiles per SIMD), the larger tile halves the
     // L2 -> LDS bytes per flop.
-    (void)blocks; (void)waste; (void)c128x128; (void)c64x128;
-    if (M > 4096 && M <= 16384 && N >= 256) return c128x64;
+    // Re-measured with the final kernel (scratch/gemm sweep over all 18 shapes of the network, batch 32): 6272x512x{256,512}
+    // run fastest on 64x128 (37.9 us vs 39.6 on 128x64 vs 42.5 on 64x64), 25088x128x256 on 128x64 (23.2 vs 25.7); everything
+    // else on 64x64.
+    (void)blocks; (void)waste; (void)c128x128;
+    if (M > 4096 && M <= 16384 && N >= 512) return c64x128;
+    if (M > 16384 && M <= 32768 && N > 32 && N <= 128) return c128x64;
     return c64x64;
 }
 
@@ -380,7 +384,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 FD_BAD("layer %d: stem must be 3->8k channels, 3x3 stride 2 on the network input", i);
             L.out_h = L.in_h / 2; L.out_w = L.in_w / 2;
             L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
-            L.lds = 256 * (L.chunk + 4) * 4;
+            L.lds = 0;                                   // the MFMA stem needs no LDS (fd_kernels_f32.h)
             L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
             L.w_bytes = (size_t)27 * d.cout * 4; L.w_elems = (size_t)27 * d.cout;
             break;
@@ -544,7 +548,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
                      L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         else if (d.op == FD_OP_STEM)
-            snprintf(buf, sizeof buf, "stem3x3s2<chunk %d> grid=%u lds=%zu", L.chunk, L.grid.x, L.lds);
+            snprintf(buf, sizeof buf, "stem3x3s2<mfma 32x32x2, 64 px per wave> grid=%u", L.grid.x);
         else if (d.op == FD_OP_DW && L.dw_rows)
             snprintf(buf, sizeof buf, "dw3_rows<s%d> rows/item %d grid=%ux%ux%u", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW)

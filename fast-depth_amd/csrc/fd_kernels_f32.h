@@ -7,7 +7,7 @@
 //
 // Kernels (reference statement each one replaces):
 //   fd_pack_fold_f32    BN(eval) algebra: gamma*(x-mean)/sqrt(var+eps)+beta  == conv(w*s) + (beta-mean*s)
-//   fd_stem3x3s2_f32    conv_bn(3,32,2)                      imagenet/mobilenet.py:22-27,41
+//   fd_stem3x3s2        conv_bn(3,32,2) as an MFMA product   imagenet/mobilenet.py:22-27,41
 //   fd_dwconv_f32       depthwise 3x3 s1/s2 (+BN+ReLU6)      imagenet/mobilenet.py:31-33
 //                       depthwise 5x5 (+BN+ReLU) with the nearest-x2 upsample and the additive skip
 //                       of the PREVIOUS decoder stage folded into the tile read   models.py:61-68,723-729
@@ -43,58 +43,71 @@ fd_pack_fold(const float *__restrict__ w, const float *__restrict__ gamma, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem: dense 3x3 stride-2 conv, 3 -> Cout channels.  x is NCHW-planar (as the dataloader hands it
-// over), y is NHWC.  One work-item = one output pixel; the 27 taps live in registers, the folded
-// weights wp[27][Cout] are wave-uniform (scalar loads).  The per-pixel channel vector is transposed
-// through LDS so that the global store is dense.
+// Stem: dense 3x3 stride-2 conv, 3 -> Cout channels, as a [pixels x 27] x [27 x Cout] matrix product on
+// v_mfma_f32_32x32x2_f32.  x is NCHW-planar (as the dataloader hands it over), y is NHWC.
+// A wave owns 64 consecutive output pixels (two 32-row tiles): lane l supplies A[pixel l%32][tap 2s + l/32] for the 14 K steps
+// (tap 27 is zero padding) straight from global memory -- 14 gathers per tile instead of 27 per pixel -- and B[tap][channel
+// l%32] from the folded weights wp[27][Cout].  The D layout (lane = channel, register = pixel row) makes every store a
+// 128-byte run of one pixel's channels: no LDS transposition, no LDS at all.  Accumulators start at the folded-BN bias.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ACT, int CHUNK>
 __global__ void __launch_bounds__(256)
 fd_stem3x3s2(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
              T *__restrict__ y, int B, int H, int W, int Cout)
 {
-    FD_DYN_SMEM(smem_raw);
-    float *tile = reinterpret_cast<float *>(smem_raw);       // [256][CHUNK + 4]
-    constexpr int TS = CHUNK + 4;
+    (void)CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
     const long npix = (long)B * Ho * Wo;
-    const int tid = threadIdx.x;
-    const long p = (long)blockIdx.x * 256 + tid;
-    const bool valid = p < npix;
-    int n = 0, oy = 0, ox = 0;
-    if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
-    float in[27];
+    const long p0 = ((long)blockIdx.x * 4 + wave) * 64;
+    if (p0 >= npix) return;
+    float a[2][14];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int m = 0; m < 2; ++m) {
+        const long p = p0 + 32 * m + i;
+        const bool valid = p < npix;
+        int n = 0, oy = 0, ox = 0;
+        if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
+        const float *xn = x + (long)n * 3 * H * W;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-                const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                in[(c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
-            }
-    for (int c0 = 0; c0 < Cout; c0 += CHUNK) {
-        float acc[CHUNK];
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) acc[j] = bias[c0 + j];
-#pragma unroll
-        for (int t = 0; t < 27; ++t)
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) acc[j] = fmaf(in[t], wp[t * Cout + c0 + j], acc[j]);
-#pragma unroll
-        for (int j = 0; j < CHUNK; j += 4) {
-            fd_f32x4 v = {fd_act<ACT>(acc[j]), fd_act<ACT>(acc[j + 1]), fd_act<ACT>(acc[j + 2]), fd_act<ACT>(acc[j + 3])};
-            fd_st4(tile + tid * TS + j, v);
+        for (int s = 0; s < 14; ++s) {
+            // tap index 2s + h: both alternatives are compile-time, the lane half selects
+            const int t0 = 2 * s, t1 = 2 * s + 1;
+            const int c = h ? t1 / 9 : t0 / 9, ky = h ? (t1 % 9) / 3 : (t0 % 9) / 3, kx = h ? t1 % 3 : t0 % 3;
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            const bool ok = valid && (2 * s + h) < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            a[m][s] = ok ? xn[((long)c * H + iy) * W + ix] : 0.0f;
         }
-        __syncthreads();
-        constexpr int Q = CHUNK / 4;                          // float4 per pixel in this chunk
-        for (int f = tid; f < 256 * Q; f += 256) {
-            const int px = f / Q, c4 = f - px * Q;
-            const long gp = (long)blockIdx.x * 256 + px;
-            if (gp < npix) fd_st4(y + gp * Cout + c0 + c4 * 4, fd_ld4(tile + px * TS + c4 * 4));
+    }
+    for (int n0 = 0; n0 < Cout; n0 += 32) {
+        const int col = n0 + i;
+        const bool col_ok = col < Cout;
+        float b[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int t = 2 * s + h;
+            b[s] = (col_ok && t < 27) ? wp[t * Cout + col] : 0.0f;
         }
-        __syncthreads();
+        const float bv = col_ok ? bias[col] : 0.0f;
+        fd_f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = bv;
+#pragma unroll
+        for (int s = 0; s < 14; ++s)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[s], acc[m], 0, 0, 0);
+        if (col_ok) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long p = p0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (p < npix) fd_st1(y + p * Cout + col, fd_act<ACT>(acc[m][r]));
+                }
+        }
     }
 }
 

@@ -64,8 +64,29 @@ class Layer:
                                    upsample, skip, 0)
 
 
+def _layers_of_plain(model):
+    """MobileNet(decoder='nnconv*dw')-shaped module (reference models.py:420-460 + NNConv.forward :244-270): encoder
+    `mobilenet.0..13`, decoder `decoder.conv1..6` with a nearest x2 after conv1..conv5 and no skips."""
+    layers, src = [], -1
+    for i in range(14):
+        for j, (conv, bn, act) in enumerate(_units(model.mobilenet[i])):
+            layers.append(Layer("mobilenet.%d.%d" % (i, 3 * j), conv, bn, act, src))
+            src = len(layers) - 1
+    pending_up = 0
+    for j in range(1, 7):
+        for q, (conv, bn, act) in enumerate(_units(getattr(model.decoder, "conv%d" % j))):
+            layers.append(Layer("decoder.conv%d.%d" % (j, q), conv, bn, act, src, pending_up, -1))
+            pending_up = 0
+            src = len(layers) - 1
+        pending_up = 1 if j <= 5 else 0
+    return layers
+
+
 def layers_of(model):
-    """MobileNetSkipAdd-shaped module -> [Layer].  Skip sources follow models.py:714-719, 724-729."""
+    """MobileNetSkipAdd-shaped module -> [Layer].  Skip sources follow models.py:714-719, 724-729.
+    A module with `.mobilenet` / `.decoder` (the no-skip sibling) takes the plain walk above."""
+    if hasattr(model, "mobilenet") and hasattr(model, "decoder"):
+        return _layers_of_plain(model)
     layers, skips = [], {}
     src = -1
     for i in range(14):

@@ -25,7 +25,7 @@ import torch.nn as nn
 
 import imagenet.mobilenet as _mobilenet
 
-__all__ = ["MobileNetSkipAdd", "depthwise", "pointwise", "weights_init", "PRUNED_CHANNELS"]
+__all__ = ["MobileNetSkipAdd", "MobileNet", "NNConv", "choose_decoder", "depthwise", "pointwise", "weights_init", "PRUNED_CHANNELS"]
 
 # Channel plan of `mobilenet-nnconv5dw-skipadd-pruned`, reconstructed from the reference's TVM tuning
 # log (tvm_compile/tuning/tx2-gpu.mobilenet-nnconv5dw-skipadd-pruned.trials=2000.stop=600.log:1-38,
@@ -67,7 +67,96 @@ def pointwise(in_channels, out_channels):
     return nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, 1, 0, bias=False), *_bn_relu(out_channels))
 
 
-class MobileNetSkipAdd(nn.Module):
+class _HipForward(nn.Module):
+    """Shared HIP-engine plumbing of the drop-in model classes: `forward` hands the whole network to the hand-written engine;
+    there is no CPU / eager path."""
+
+    def _engine(self):
+        eng = self.__dict__.get('_fd_engine')
+        if eng is None:
+            from fastdepth_hip.engine import Engine  # raises loudly if libfastdepth_hip.so is absent
+            eng = Engine(self)
+            self.__dict__['_fd_engine'] = eng          # not a Module attribute: never pickled/state_dict'd
+        return eng
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop('_fd_engine', None)
+        return state
+
+    def set_compute_dtype(self, dtype):
+        """MI355X extension (not in the reference): storage type of the activations / pointwise weights inside the HIP
+        engine -- torch.float32 (default), torch.float16 or torch.bfloat16.  The module's parameters, its input and its
+        output stay float32; accumulation is fp32."""
+        self._engine().set_dtype(dtype)
+        return self
+
+    def repack(self):
+        """Drop cached packed weights (call after in-place edits the version counters cannot see)."""
+        eng = self.__dict__.get('_fd_engine')
+        if eng is not None:
+            eng.invalidate()
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("fast-depth_amd: {}.forward runs on an MI355X (HIP) device only; got a {} tensor. "
+                               "There is no CPU fallback in this package.".format(type(self).__name__, x.device))
+        return self._engine().forward(x)
+
+
+class NNConv(nn.Module):
+    """Nearest-neighbour-upsampling decoder, depthwise-separable form (reference models.py:224-270 with dw=True):
+    conv1..conv5 = Sequential(depthwise(C, k), pointwise(C, C/2)) for C = 1024..64, conv6 = pointwise(32, 1); the reference's
+    forward interleaves a nearest x2 after conv1..conv5.  Parameter container only (the HIP engine executes it as part of
+    `MobileNet`).  The dense variant (dw=False: k x k full convolutions) is outside this package's kernels."""
+
+    def __init__(self, kernel_size, dw):
+        super().__init__()
+        if not dw:
+            raise NotImplementedError("fast-depth_amd implements the depthwise-separable decoders ('nnconv5dw', 'nnconv3dw'); "
+                                      "the dense NNConv decoder is not on the accelerated path")
+        width = 1024
+        for j in range(1, 6):
+            setattr(self, 'conv{}'.format(j), nn.Sequential(depthwise(width, kernel_size), pointwise(width, width // 2)))
+            width //= 2
+        self.conv6 = pointwise(width, 1)
+
+
+def choose_decoder(decoder):
+    """Reference models.py:335-360, restricted to the decoders whose layers are on the accelerated path."""
+    if decoder in ('nnconv5dw', 'nnconv3dw'):
+        model = NNConv(int(decoder[6]), True)
+    else:
+        raise NotImplementedError("decoder {!r}: only 'nnconv5dw' / 'nnconv3dw' are built by fast-depth_amd "
+                                  "(SURVEY.md 8(f) row f-3)".format(decoder))
+    model.apply(weights_init)
+    return model
+
+
+class MobileNet(_HipForward):
+    """MobileNet-v1 encoder + decoder WITHOUT skip connections -- `MobileNet(decoder, output_size, in_channels=3,
+    pretrained=True)` as in reference models.py:420-460 (runs on the same kernels as
+    MobileNetSkipAdd, with `skip = -1` everywhere).  Attribute tree and state_dict keys follow the reference:
+    `mobilenet.0 .. mobilenet.13`, `decoder.conv1 .. decoder.conv6`."""
+
+    def __init__(self, decoder, output_size, in_channels=3, pretrained=True):
+        super().__init__()
+        self.output_size = output_size
+        if in_channels != 3:
+            raise NotImplementedError("the stem kernel reads 3-channel RGB (the only modality of the reference's main.py)")
+        mobilenet = _mobilenet.MobileNet()
+        if pretrained:
+            import os
+            path = os.path.join('imagenet', 'results', 'imagenet.arch=mobilenet.lr=0.1.bs=256', 'model_best.pth.tar')
+            state = torch.load(path, weights_only=False)['state_dict']
+            mobilenet.load_state_dict({k[len('module.'):] if k.startswith('module.') else k: v for k, v in state.items()})
+        else:
+            mobilenet.apply(weights_init)
+        self.mobilenet = nn.Sequential(*(mobilenet.model[i] for i in range(14)))
+        self.decoder = choose_decoder(decoder)
+
+
+class MobileNetSkipAdd(_HipForward):
     """MobileNet-v1 encoder + NNConv5 depthwise-separable decoder + 3 additive skips.
 
     ``MobileNetSkipAdd(output_size, pretrained=True)`` as in reference models.py:655.  Extra,
@@ -104,36 +193,3 @@ class MobileNetSkipAdd(nn.Module):
         # NB: the reference calls weights_init(self.decode_convN) directly on the Sequential
         # (models.py:699-704), which matches none of the isinstance tests -> the decoder keeps
         # torch's default initialisation.  Nothing to do here; stated so nobody "fixes" it.
-
-    # ---- HIP engine plumbing -------------------------------------------------------------------
-    def _engine(self):
-        eng = self.__dict__.get('_fd_engine')
-        if eng is None:
-            from fastdepth_hip.engine import Engine  # raises loudly if libfastdepth_hip.so is absent
-            eng = Engine(self)
-            self.__dict__['_fd_engine'] = eng          # not a Module attribute: never pickled/state_dict'd
-        return eng
-
-    def __getstate__(self):
-        state = self.__dict__.copy()
-        state.pop('_fd_engine', None)
-        return state
-
-    def set_compute_dtype(self, dtype):
-        """MI355X extension (not in the reference): storage type of the activations / pointwise weights inside the HIP
-        engine -- torch.float32 (default), torch.float16 or torch.bfloat16.  The module's parameters, its input and its
-        output stay float32; accumulation is fp32."""
-        self._engine().set_dtype(dtype)
-        return self
-
-    def repack(self):
-        """Drop cached packed weights (call after in-place edits the version counters cannot see)."""
-        eng = self.__dict__.get('_fd_engine')
-        if eng is not None:
-            eng.invalidate()
-
-    def forward(self, x):
-        if not x.is_cuda:
-            raise RuntimeError("fast-depth_amd: MobileNetSkipAdd.forward runs on an MI355X (HIP) device only; "
-                               "got a {} tensor. There is no CPU fallback in this package.".format(x.device))
-        return self._engine().forward(x)

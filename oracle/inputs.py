@@ -72,3 +72,25 @@ def golden_case(name):
     x = batch_variants(load_sample()[0], meta["batch"], meta["seed"])
     y = torch.from_numpy(np.load(os.path.join(GOLD, name + "_out.npy")))
     return m, x, y, meta
+
+
+def golden_sibling_case(name):
+    """Same as golden_case for the no-skip sibling `MobileNet(decoder, ...)` (tests/golden/siblings.json,
+    oracle/make_golden_siblings.py)."""
+    with open(os.path.join(GOLD, "siblings.json")) as f:
+        meta = json.load(f)[name]
+    models = product_models()
+    torch.manual_seed(meta["seed"])
+    m = models.MobileNet(meta["decoder"], (224, 224), pretrained=False)
+    sd = m.state_dict()
+    if len(sd) != meta["keys"]:
+        raise AssertionError("state_dict has %d keys, the reference has %d" % (len(sd), meta["keys"]))
+    for k, h in meta["conv_weight_sha"].items():
+        if _sha(sd[k]) != h:
+            raise AssertionError("seeded constructor no longer reproduces reference weights: " + k)
+    bn = np.load(os.path.join(GOLD, name + "_bn.npz"))
+    m.load_state_dict({k: torch.from_numpy(bn[k]) for k in bn.files}, strict=False)
+    m.eval()
+    x = batch_variants(load_sample()[0], meta["batch"], meta["seed"])
+    y = torch.from_numpy(np.load(os.path.join(GOLD, name + "_out.npy")))
+    return m, x, y, meta

@@ -82,3 +82,37 @@ def test_emulated_fused_separable_units(name, plan, hw):
     cp.close()
     assert sum("sep_unit" in i for i in info) == 10 and sum("fused into" in i for i in info) == 10
     assert float(np.abs(y - yo).max()) / float(yo.max() - yo.min()) < 1e-4
+
+
+def test_emulated_no_skip_sibling_forward():
+    """Row f-3: the no-skip `MobileNet('nnconv5dw')` runs on the same kernels (plan walk `mobilenet.*` / `decoder.*`, nearest x2
+    folded into the next unit's read, skip = -1).  Full widths, 32x32 input, against a torch-functional restatement of the
+    reference's forward (models.py:244-270, 455-458) built from the product module's own tensors."""
+    import torch.nn.functional as F
+    models = inputs.product_models()
+    torch.manual_seed(21)
+    m = harness.randomize_bn(models.MobileNet("nnconv5dw", (32, 32), pretrained=False), 22).eval()
+    x = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(23))
+
+    def unit(t, seq):
+        mods = list(seq)
+        for i in range(0, len(mods), 3):
+            conv, bn, act = mods[i:i + 3]
+            t = F.conv2d(t.double(), conv.weight.double(), None, conv.stride, conv.padding, 1, conv.groups)
+            t = F.batch_norm(t, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(), False, 0.1, bn.eps)
+            t = t.clamp(0, 6) if isinstance(act, torch.nn.ReLU6) else t.clamp(min=0)
+        return t
+
+    with torch.no_grad():
+        t = x
+        for blk in m.mobilenet:
+            t = unit(t, blk)
+        for j in range(1, 6):
+            blk = getattr(m.decoder, "conv%d" % j)
+            t = unit(unit(t, blk[0]), blk[1])
+            t = F.interpolate(t, scale_factor=2, mode="nearest")
+        ref = unit(t, m.decoder.conv6)
+    plan = harness.CPlan("emu", m, x, keep=False)
+    y = plan.forward(x)
+    plan.close()
+    assert harness.rel_err(y.numpy(), ref.numpy()) < TOL

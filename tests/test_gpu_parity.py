@@ -164,3 +164,17 @@ def test_on_device_metrics_and_eval_harness(tmp_path):
     avg = fd_eval.main(["--evaluate", ck, "--batch-size", "4", "--repeat", "8", "-p", "1"])
     want = meta["metrics_vs_sample_depth"]
     assert avg.rmse == pytest.approx(want["rmse"], rel=1e-4) and avg.delta1 == pytest.approx(want["delta1"], rel=1e-4)
+
+
+def test_no_skip_sibling_matches_reference_output():
+    """Row f-3: `MobileNet('nnconv5dw')` against the reference's own output on the same seeded weights / inputs
+    (tests/golden/nnconv5dw_s4_*, generated by oracle/make_golden_siblings.py from /root/reference)."""
+    m, x, y_ref, meta = inputs.golden_sibling_case("nnconv5dw_s4")
+    m = m.cuda()
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+    assert harness.rel_err(y.numpy(), y_ref.numpy()) < 1e-3
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        yb = m(x.cuda()).cpu()
+    assert harness.rel_err(yb.numpy(), y_ref.numpy()) < 3e-2

@@ -90,3 +90,20 @@ def test_seeded_constructor_is_bit_identical_to_reference():
     torch.manual_seed(7); m = models.MobileNetSkipAdd((224, 224), pretrained=False)
     a, b = r.state_dict(), m.state_dict()
     assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_no_skip_sibling_matches_reference_surface():
+    """`MobileNet('nnconv5dw', ...)` (reference models.py:420-460) -- same state_dict keys, and for the same
+    seed bit-identical conv weights (sha of every conv weight of the reference is stored in tests/golden/siblings.json; the
+    reference's choose_decoder applies weights_init to the decoder, unlike MobileNetSkipAdd)."""
+    import pytest
+    from oracle import inputs
+    m, x, y, meta = inputs.golden_sibling_case("nnconv5dw_s4")
+    keys = list(m.state_dict())
+    assert len(keys) == 228 and keys[0] == "mobilenet.0.0.weight" and "decoder.conv6.1.running_var" in keys
+    assert [n for n, _ in m.named_children()] == ["mobilenet", "decoder"]
+    models = inputs.product_models()
+    with pytest.raises(NotImplementedError):
+        models.MobileNet("deconv3", (224, 224), pretrained=False)        # decoders outside the accelerated path say so
+    with pytest.raises(RuntimeError):
+        m(x)                                                              # CPU tensor: no fallback
