@@ -344,7 +344,7 @@ int run_layer(fd_plan *plan, const Layer &L, const float *x, float *out, hipStre
 extern "C" {
 
 const char *fd_last_error(void) { return g_err.c_str(); }
-const char *fd_version(void) { return "fastdepth_hip 0.2 (gfx950; inference f32/f16/bf16, train step f32)"; }
+const char *fd_version(void) { return "fastdepth_hip 0.3 (gfx950; inference f32/f16/bf16, train step f32/bf16)"; }
 
 int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
                    int32_t dtype, uint32_t flags, fd_plan **out_plan)

@@ -23,7 +23,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/rocprof_bench.json 2> $OUT/rocprof.err; echo "rc=$?"
 find $OUT/prof -name "*stats*" | head; f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -30 "$f"
 echo "== rocprofv3 PMC passes (HBM traffic)"
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 > /dev/null 2> $OUT/pmc_fetch.err; echo "rc=$?"
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 > /dev/null 2> $OUT/pmc_write.err; echo "rc=$?"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 --train-steps 0 --extra-steps 0 > /dev/null 2> $OUT/pmc_fetch.err; echo "rc=$?"
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 --train-steps 0 --extra-steps 0 > /dev/null 2> $OUT/pmc_write.err; echo "rc=$?"
 cd $ROOT; python tools/summarize_profiles.py $OUT > $OUT/profile_summary.txt 2>&1; tail -40 $OUT/profile_summary.txt
 du -sh $OUT
