@@ -127,3 +127,30 @@ __device__ __forceinline__ void fd_st1(float *p, float v) { *p = v; }
 __device__ __forceinline__ void fd_st1(fd_half *p, float v) { *p = (_Float16)v; }
 __device__ __forceinline__ void fd_st1(fd_bf16 *p, float v) { p->v = fd_f32_to_bf16(v); }
 __device__ __forceinline__ fd_f32x4 fd_zero4() { fd_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// ---- device-coherent accesses ("last arriver" reductions: stream-K partial tiles, fused two-level reductions of the train step) ----
+// Device-coherent accesses for partial results and their arrival counters.  MI355X has one L2 per XCD and the L2s are not coherent
+// with each other inside a kernel; an agent-scope FENCE would make them so by writing back / invalidating the whole L2
+// (buffer_wbl2 / buffer_inv: measured +100 us per launch here, the L2 is full of freshly written activations).  Instead every
+// access to the scratch slots and counters is itself agent-scope (sc1: performed at the device coherence point, bypassing the
+// non-coherent L2 lines), and the only ordering needed -- partial stores complete before the counter moves -- is a
+// workgroup-scope release (s_waitcnt vmcnt(0), no cache maintenance) followed by the workgroup barrier.
+#ifdef FD_EMU
+inline int fd_atomic_inc(int *p) { int o = *p; *p = o + 1; return o; }
+inline void fd_store_dev(float *p, float v) { *p = v; }
+inline float fd_load_dev(const float *p) { return *p; }
+inline void fd_store_dev(int *p, int v) { *p = v; }
+inline void fd_store_dev(double *p, double v) { *p = v; }
+inline double fd_load_dev(const double *p) { return *p; }
+inline void fd_release_wg() {}
+inline void fd_acquire_wg() {}
+#else
+__device__ __forceinline__ int fd_atomic_inc(int *p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fd_store_dev(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float fd_load_dev(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fd_store_dev(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fd_store_dev(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double fd_load_dev(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fd_release_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void fd_acquire_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#endif

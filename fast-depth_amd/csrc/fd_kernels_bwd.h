@@ -44,40 +44,58 @@ __device__ __forceinline__ fd_f32x4 fd_actmask4(fd_f32x4 y)
     return r;
 }
 
-// ---- generic deterministic partial reduction: out[j] = sum_b part[b*stride + j], j < n -------------------------------
+// ---- generic deterministic partial reduction: out[j] = sum_b part[b*stride + j], j < n  (grid (ceil(n/64), slices), see
+// fd_two_level_tail) ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-fd_reduce_partials_f32(const float *__restrict__ part, int nblk, long stride, int n, float *__restrict__ out)
+fd_reduce_partials_f32(const float *__restrict__ part, int nblk, int rps, long stride, int n, float *__restrict__ out,
+                       double *__restrict__ slices, int *__restrict__ counters)
 {
-    __shared__ double sh[16][64];
+    __shared__ double sh[16][64][2];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
-    double s = 0.0;
+    const int r0 = blockIdx.y * rps;
+    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
+    double s = 0.0, unused = 0.0;
     if (j < n)
-        for (int b = wave; b < nblk; b += 16) s += (double)part[(long)b * stride + j];
-    sh[wave][lane] = s;
+#pragma unroll 4
+        for (int b = r0 + wave; b < r1; b += 16) s += (double)part[(long)b * stride + j];
+    sh[wave][lane][0] = s;
     __syncthreads();
-    if (wave == 0 && j < n) {
+    if (wave == 0) {
         s = 0.0;
-        for (int w = 0; w < 16; ++w) s += sh[w][lane];
-        out[j] = (float)s;
+        for (int w = 0; w < 16; ++w) s += sh[w][lane][0];
     }
+    __syncthreads();
+    if (!fd_two_level_tail(s, unused, false, j < n, j, 2 * n, slices, counters, &s_last, sh)) return;
+    if (wave == 0 && j < n) out[j] = (float)s;
 }
 
 // out[c*KK + t] = sum_b part[(b*KK + t)*C + c]   (depthwise weight gradient: tap-major partials -> torch's [C][1][k][k])
 __global__ void __launch_bounds__(1024)
-fd_reduce_partials_tapmajor_f32(const float *__restrict__ part, int nblk, int KK, int C, float *__restrict__ out)
+fd_reduce_partials_tapmajor_f32(const float *__restrict__ part, int nblk, int rps, int KK, int C, float *__restrict__ out,
+                                double *__restrict__ slices, int *__restrict__ counters)
 {
-    __shared__ double sh[16][64];
+    __shared__ double sh[16][64][2];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;                      // j = t*C + c
-    double s = 0.0;
-    if (j < KK * C)
-        for (int b = wave; b < nblk; b += 16) s += (double)part[(long)b * KK * C + j];
-    sh[wave][lane] = s;
+    const int n = KK * C;
+    const int r0 = blockIdx.y * rps;
+    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
+    double s = 0.0, unused = 0.0;
+    if (j < n)
+#pragma unroll 4
+        for (int b = r0 + wave; b < r1; b += 16) s += (double)part[(long)b * n + j];
+    sh[wave][lane][0] = s;
     __syncthreads();
-    if (wave == 0 && j < KK * C) {
+    if (wave == 0) {
         s = 0.0;
-        for (int w = 0; w < 16; ++w) s += sh[w][lane];
+        for (int w = 0; w < 16; ++w) s += sh[w][lane][0];
+    }
+    __syncthreads();
+    if (!fd_two_level_tail(s, unused, false, j < n, j, 2 * n, slices, counters, &s_last, sh)) return;
+    if (wave == 0 && j < n) {
         const int t = j / C, c = j - t * C;
         out[(long)c * KK + t] = (float)s;
     }
@@ -85,20 +103,29 @@ fd_reduce_partials_tapmajor_f32(const float *__restrict__ part, int nblk, int KK
 
 // ---- BatchNorm backward finalize -----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int C, double n, const float *__restrict__ st,
-                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef)
+fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
+                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
+                       double *__restrict__ slices, int *__restrict__ counters)
 {
     __shared__ double sh[16][64][2];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rps;
+    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int b = wave; b < nblk; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+#pragma unroll 4
+        for (int b = r0 + wave; b < r1; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
     sh[wave][lane][0] = s; sh[wave][lane][1] = q;
     __syncthreads();
-    if (wave == 0 && c < C) {
+    if (wave == 0) {
         s = 0.0; q = 0.0;
         for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
+    }
+    __syncthreads();
+    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, &s_last, sh)) return;
+    if (wave == 0 && c < C) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         const double sc = st[FD_ST_SCALE * C + c], mean = st[FD_ST_MEAN * C + c], invstd = st[FD_ST_INVSTD * C + c];

@@ -27,27 +27,7 @@
 #pragma once
 #include "fd_kernels_f32.h"
 
-// Device-coherent accesses for the partial tiles and their counters.  MI355X has one L2 per XCD and the L2s are not coherent
-// with each other inside a kernel; an agent-scope FENCE would make them so by writing back / invalidating the whole L2
-// (buffer_wbl2 / buffer_inv: measured +100 us per launch here, the L2 is full of freshly written activations).  Instead every
-// access to the scratch slots and counters is itself agent-scope (sc1: performed at the device coherence point, bypassing the
-// non-coherent L2 lines), and the only ordering needed -- partial stores complete before the counter moves -- is a
-// workgroup-scope release (s_waitcnt vmcnt(0), no cache maintenance) followed by the workgroup barrier.
-#ifdef FD_EMU
-inline int fd_atomic_inc(int *p) { int o = *p; *p = o + 1; return o; }
-inline void fd_store_dev(float *p, float v) { *p = v; }
-inline float fd_load_dev(const float *p) { return *p; }
-inline void fd_store_dev(int *p, int v) { *p = v; }
-inline void fd_release_wg() {}
-inline void fd_acquire_wg() {}
-#else
-__device__ __forceinline__ int fd_atomic_inc(int *p) { return __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fd_store_dev(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float fd_load_dev(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fd_store_dev(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fd_release_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void fd_acquire_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-#endif
+// (device-coherent access helpers fd_store_dev / fd_load_dev / fd_atomic_inc / fd_release_wg / fd_acquire_wg: fd_device.h)
 
 template <int WGM, int WGN, int TM, int TN, int ACT>
 __global__ void __launch_bounds__(256)

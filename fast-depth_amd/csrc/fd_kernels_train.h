@@ -11,7 +11,8 @@
 //   * the CONSUMER applies  a = act(z*s + t)  while it loads its input ("normalise on read"), so the
 //     normalised / activated tensor is never written to HBM.  Nearest-x2 upsampling and the additive skips stay
 //     fused into the consumer's read exactly as in the inference kernels (models.py:723-729).
-// Reductions are two-stage and deterministic (per-workgroup partials in a fixed layout, summed in fixed order).
+// Reductions are two-level and deterministic (per-workgroup partials in a fixed layout, summed in fixed order by the
+// "last arriver" of the finalisation kernel: fd_two_level_tail).
 #pragma once
 #include "fd_device.h"
 
@@ -369,59 +370,88 @@ fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stage A of the two-level deterministic reductions: slice y of the partial rows is summed into one row.
-//   out[y*width + j] = sum_{b in slice y} part[b*width + j]        slice y = rows [y*rows_per_slice, (y+1)*rows_per_slice)
-// 16 waves per workgroup split the rows of the slice, 4 independent loads in flight per lane; the partial buffers of
-// the large layers (up to 6272 workgroups) are cut into <= 64 slices, so that every finalize kernel sees <= 64 rows.
+// Two-level deterministic reduction in ONE launch ("last arriver").  The rows of a partial buffer (up to 6272 workgroups of
+// the producer) are cut into gridDim.y slices of `rps` rows; workgroup (x, y) sums slice y for the 64 columns of block x (16
+// waves split the rows, fixed order) and, when there is more than one slice, publishes its sums with device-scope stores and
+// bumps counter[x]; the workgroup that finds the counter complete adds the slice sums IN SLICE ORDER (independent of who
+// arrives last) and runs the finalisation for its 64 columns.  No workgroup waits; the counters return to 0.
+// fd_tail_begin returns true in the workgroup that owns the final result of column block x; s/q then hold the full sums for
+// wave 0's lanes.  (A separate slice-sum launch per reduction cost ~5 us x 71 launches per train step.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-fd_slice_sum_f32(const float *__restrict__ part, int nrows, int rows_per_slice, int width, float *__restrict__ out)
+__device__ __forceinline__ bool fd_two_level_tail(double &s, double &q, bool has_q, bool col_ok, int col, int width2,
+                                                  double *__restrict__ slices, int *__restrict__ counters, int *s_last,
+                                                  double (*sh)[64][2])
 {
-    __shared__ float sh[16][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rows_per_slice;
-    int r1 = r0 + rows_per_slice; if (r1 > nrows) r1 = nrows;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    if (j < width) {
-        int b = r0 + wave;
-        for (; b + 48 < r1; b += 64) {
-            a0 += part[(long)b * width + j]; a1 += part[(long)(b + 16) * width + j];
-            a2 += part[(long)(b + 32) * width + j]; a3 += part[(long)(b + 48) * width + j];
-        }
-        for (; b < r1; b += 16) a0 += part[(long)b * width + j];
+    // called by all 1024 work-items after wave 0 holds the slice sums (s, q) of its lanes' columns
+    const int ny = gridDim.y;
+    if (ny == 1) return true;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0 && col_ok) {
+        fd_store_dev(slices + (long)blockIdx.y * width2 + col, s);
+        if (has_q) fd_store_dev(slices + (long)blockIdx.y * width2 + (width2 >> 1) + col, q);
     }
-    sh[wave][lane] = (a0 + a1) + (a2 + a3);
+    fd_release_wg();
     __syncthreads();
-    if (wave == 0 && j < width) {
-        float s = 0.0f;
-        for (int w = 0; w < 16; ++w) s += sh[w][lane];
-        out[(long)blockIdx.y * width + j] = s;
+    if (threadIdx.x == 0) {
+        const int old = fd_atomic_inc(counters + blockIdx.x);
+        *s_last = old == ny - 1;
+        if (*s_last) fd_store_dev(counters + blockIdx.x, 0);
     }
+    __syncthreads();
+    if (!*s_last) return false;
+    fd_acquire_wg();
+    // the slice sums are added in a fixed order: wave w takes slices w, w+16, ... (all its loads in flight at once), then the 16
+    // per-wave sums are added in wave order
+    constexpr int MAXK = 8;                                  // ny <= 128 (fd_train_impl.h red_geom)
+    double vs[MAXK], vq[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const int y = wave + 16 * k;
+        const bool ok = col_ok && y < ny;
+        vs[k] = ok ? fd_load_dev(slices + (long)y * width2 + col) : 0.0;
+        vq[k] = (ok && has_q) ? fd_load_dev(slices + (long)y * width2 + (width2 >> 1) + col) : 0.0;
+    }
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) { a += vs[k]; b += vq[k]; }
+    sh[wave][lane][0] = a; sh[wave][lane][1] = b;
+    __syncthreads();
+    if (wave == 0) {
+        s = 0.0; q = 0.0;
+        for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm finalize: partial sums -> per-channel (scale, shift, mean, invstd) + running-statistics update.
 //   mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), running_var uses var_b * n_u/(n_u-1).
-// One workgroup of 1024 (16 waves) per 64 channels: lane = channel, wave w sums partial blocks b = w, w+16, ...
-// in double, fixed order -> deterministic.
+// Grid (ceil(C/64), slices): lane = channel, wave w sums partial rows w, w+16, ... of its slice in double, fixed order.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int C, double n, double n_unbiased, float eps, float momentum,
+fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, double n_unbiased, float eps, float momentum,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ run_mean,
-                   float *__restrict__ run_var, float *__restrict__ st)
+                   float *__restrict__ run_var, float *__restrict__ st, double *__restrict__ slices, int *__restrict__ counters)
 {
     __shared__ double sh[16][64][2];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rps;
+    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int b = wave; b < nblk; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+#pragma unroll 4
+        for (int b = r0 + wave; b < r1; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
     sh[wave][lane][0] = s; sh[wave][lane][1] = q;
     __syncthreads();
-    if (wave == 0 && c < C) {
+    if (wave == 0) {
         s = 0.0; q = 0.0;
         for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
+    }
+    __syncthreads();
+    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, &s_last, sh)) return;
+    if (wave == 0 && c < C) {
         const double mean = s / n;
         double var = q / n - mean * mean;
         if (var < 0.0) var = 0.0;

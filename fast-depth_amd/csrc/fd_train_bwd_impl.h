@@ -15,11 +15,9 @@ inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
     TLayer &L = c.p->layers[i];
-    int rows = 0, rc = FD_OK;
-    const float *pr = slice_rows(c.p, tws(c.p, c.p->part_off), nblk, 2 * L.d.cout, c.s, &rows, &rc);
-    if (rc) return rc;
-    FD_LAUNCH(fd_bn_bwd_finalize_f32, dim3(ceil_div(L.d.cout, 64)), dim3(1024), 0, c.s, pr, rows, L.d.cout, L.n_stat,
-              tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off));
+    const RedGeom rg = red_geom(nblk, L.d.cout);
+    FD_LAUNCH(fd_bn_bwd_finalize_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat,
+              tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off), red_slices(c.p), red_counters(c.p));
     return check_launch("fd_bn_bwd_finalize_f32");
 }
 
@@ -88,10 +86,8 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     int rc = check_launch("fd_dw_wgrad");
     if (rc) return rc;
     const int kk = L.d.ksize * L.d.ksize;
-    int rows = 0;
-    const float *pr = slice_rows(c.p, wpart, wblk, kk * L.d.cin, c.s, &rows, &rc);
-    if (rc) return rc;
-    FD_LAUNCH(fd_reduce_partials_tapmajor_f32, dim3(ceil_div((long)kk * L.d.cin, 64)), dim3(1024), 0, c.s, pr, rows, kk, L.d.cin, c.grads[i].conv_weight);
+    const RedGeom rg = red_geom(wblk, (long)kk * L.d.cin);
+    FD_LAUNCH(fd_reduce_partials_tapmajor_f32, rg.grid, dim3(1024), 0, c.s, wpart, wblk, rg.rps, kk, L.d.cin, c.grads[i].conv_weight, red_slices(c.p), red_counters(c.p));
     return check_launch("fd_reduce_partials_tapmajor_f32");
 }
 
@@ -123,7 +119,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     }
     {
         const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
-        int splits = std::max(1, std::min(ceil_div(2048, (long)n_tiles * k_tiles), ceil_div(M, 256)));
+        int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_H16, (long)n_tiles * k_tiles), ceil_div(M, 256)));
         int rows = ceil_div(ceil_div(M, splits), 64) * 64;
         splits = ceil_div(M, rows);
         const size_t need = (size_t)splits * N * K * 4;
@@ -131,10 +127,8 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.s, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
-        int srows = 0;
-        const float *pr = slice_rows(c.p, tws(c.p, c.p->wpart_off), splits, N * K, c.s, &srows, &rc);
-        if (rc) return rc;
-        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div((long)N * K, 64)), dim3(1024), 0, c.s, pr, srows, (long)N * K, N * K, c.grads[i].conv_weight);
+        const RedGeom rg = red_geom(splits, (long)N * K);
+        FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->wpart_off), splits, rg.rps, (long)N * K, N * K, c.grads[i].conv_weight, red_slices(c.p), red_counters(c.p));
         if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
     }
     {
@@ -166,7 +160,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     // --- weights: dW[N][K], reduction over M split across workgroups
     {
         const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
-        int splits = std::max(1, std::min(ceil_div(2048, (long)n_tiles * k_tiles), ceil_div(M, 256)));
+        int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_F32, (long)n_tiles * k_tiles), ceil_div(M, 256)));
         int rows = ceil_div(ceil_div(M, splits), 64) * 64;
         splits = ceil_div(M, rows);
         const size_t need = (size_t)splits * N * K * 4;
@@ -177,10 +171,8 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         int rc = check_launch("fd_pw_wgrad_f32");
         if (rc) return rc;
-        int srows = 0;
-        const float *pr = slice_rows(c.p, tws(c.p, c.p->wpart_off), splits, N * K, c.s, &srows, &rc);
-        if (rc) return rc;
-        FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div((long)N * K, 64)), dim3(1024), 0, c.s, pr, srows, (long)N * K, N * K, c.grads[i].conv_weight);
+        const RedGeom rg = red_geom(splits, (long)N * K);
+        FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->wpart_off), splits, rg.rps, (long)N * K, N * K, c.grads[i].conv_weight, red_slices(c.p), red_counters(c.p));
         if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
     }
     // --- data: G_src[M][K]
@@ -231,10 +223,8 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
         if ((rc = check_launch("fd_head_bwd"))) return rc;
         {
-            int rows = 0;
-            const float *pr = slice_rows(plan, wpart, nb2, Hd.d.cin, s, &rows, &rc);
-            if (rc) return rc;
-            FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(Hd.d.cin, 64)), dim3(1024), 0, s, pr, rows, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight);
+            const RedGeom rg = red_geom(nb2, Hd.d.cin);
+            FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, s, wpart, nb2, rg.rps, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight, red_slices(plan), red_counters(plan));
         }
         if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
         // the BN partials of the head's producer are now in `part` (nb2 workgroups)
@@ -252,10 +242,8 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), (size_t)(256 * 33 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout, L.nblk);
             if ((rc = check_launch("fd_stem_wgrad"))) return rc;
             {
-                int rows = 0;
-                const float *pr = slice_rows(plan, wpart, nb_w, 27 * d.cout, s, &rows, &rc);
-                if (rc) return rc;
-                FD_LAUNCH(fd_reduce_partials_f32, dim3(ceil_div(27 * d.cout, 64)), dim3(1024), 0, s, pr, rows, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight);
+                const RedGeom rg = red_geom(nb_w, 27 * d.cout);
+                FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, s, wpart, nb_w, rg.rps, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight, red_slices(plan), red_counters(plan));
             }
             if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
             break;

@@ -14,6 +14,12 @@
 #include "fd_kernels_bwd.h"
 #include "fd_kernels_train_h16.h"
 
+// workgroups the pointwise weight-gradient GEMM aims for (output tiles x pixel splits); every split writes a private fp32 partial
+// tile that fd_reduce_partials_f32 sums afterwards, so more splits = more parallelism but more partial traffic
+// (measured at batch 32: 2048 is best for the fp32 kernel, 1024 for the bf16 one whose MFMA part is 16x shorter)
+#define FD_WGRAD_TARGET_WGS_F32 2048
+#define FD_WGRAD_TARGET_WGS_H16 1024
+
 namespace {
 
 struct TLayer {
@@ -49,7 +55,7 @@ struct fd_train_plan {
     int B = 0, H = 0, W = 0, dtype = FD_F32;
     uint32_t flags = 0;
     size_t esz = 4;                  // bytes per stored activation / activation-gradient element
-    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0, part2_off = 0, part2_bytes = 0;
+    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
     unsigned char *ws = nullptr;
     bool forward_done = false;
     float eps = 1e-5f;
@@ -61,21 +67,17 @@ namespace {
 inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
 template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reinterpret_cast<T *>(p->ws + off); }
 
-// Two-level deterministic reduction, stage A: more than 64 partial rows are first summed into <= 64 slice rows.
-// Returns the buffer / row count the finalize kernel should read.
-const float *slice_rows(fd_train_plan *p, const float *part, int nrows, int width, hipStream_t s, int *rows_out, int *rc)
+// Launch geometry of the fused two-level reductions (fd_two_level_tail): up to 64 partial rows are finalised by a single
+// workgroup per 64 columns; more rows are cut into slices of 64 that the grid's y dimension sums first.
+struct RedGeom { int rps; dim3 grid; };
+inline RedGeom red_geom(int nrows, long width)
 {
-    *rc = FD_OK;
-    if (nrows <= 64) { *rows_out = nrows; return part; }
-    const int slices = std::min(64, ceil_div(nrows, 16));
-    const int rps = ceil_div(nrows, slices);
-    const int ns = ceil_div(nrows, rps);
-    float *out = tws(p, p->part2_off);
-    FD_LAUNCH(fd_slice_sum_f32, dim3(ceil_div(width, 64), ns), dim3(1024), 0, s, part, nrows, rps, width, out);
-    *rc = check_launch("fd_slice_sum_f32");
-    *rows_out = ns;
-    return out;
+    if (nrows <= 64) return RedGeom{nrows, dim3((unsigned)ceil_div(width, 64), 1)};
+    const int rps = std::max(64, ceil_div(nrows, 128));       // at most 128 slices (fd_two_level_tail: 8 per wave)
+    return RedGeom{rps, dim3((unsigned)ceil_div(width, 64), (unsigned)ceil_div(nrows, rps))};
 }
+inline double *red_slices(fd_train_plan *p) { return reinterpret_cast<double *>(p->ws + p->part2_off); }
+inline int *red_counters(fd_train_plan *p) { return reinterpret_cast<int *>(p->ws + p->cnt_off); }
 
 template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
@@ -174,11 +176,9 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
             break;
         }
         if (rc) return rc;
-        int rows = 0;
-        const float *pr = slice_rows(plan, part, L.nblk, 2 * d.cout, s, &rows, &rc);
-        if (rc) return rc;
-        FD_LAUNCH(fd_bn_finalize_f32, dim3(ceil_div(d.cout, 64)), dim3(1024), 0, s, pr, rows, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
-                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off));
+        const RedGeom rg = red_geom(L.nblk, d.cout);
+        FD_LAUNCH(fd_bn_finalize_f32, rg.grid, dim3(1024), 0, s, part, L.nblk, rg.rps, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
+                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off), red_slices(plan), red_counters(plan));
         if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
     }
     const TLayer &Hd = plan->layers.back();
@@ -280,7 +280,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.nblk = L.m_tiles;
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
                     const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
-                    int splits = std::max(1, std::min(ceil_div(2048, (long)nt * kt), ceil_div(M, 256)));
+                    int splits = std::max(1, std::min(ceil_div(h16 ? FD_WGRAD_TARGET_WGS_H16 : FD_WGRAD_TARGET_WGS_F32, (long)nt * kt), ceil_div(M, 256)));
                     const int rows = ceil_div(ceil_div(M, splits), 64) * 64;
                     splits = ceil_div(M, rows);
                     max_wpart = std::max(max_wpart, (size_t)splits * d.cout * d.cin);
@@ -328,7 +328,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
     p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
     p->wpart_off = off; p->wpart_bytes = align_up(std::max(max_wpart, (size_t)1) * 4, 256); off += p->wpart_bytes;
-    p->part2_off = off; p->part2_bytes = align_up(64 * std::max(max_width, (size_t)1) * 4, 256); off += p->part2_bytes;   // stage-A slices of the two-level reductions
+    // slice sums (double) of the fused two-level reductions: ceil(rows / 64) x 2 x width, bounded through rows x width <= the partial buffers
+    p->part2_off = off; p->part2_bytes = align_up((std::max(2 * max_part, max_wpart) / 16 + 4 * std::max(max_width, (size_t)1) + 64) * 8, 256); off += p->part2_bytes;
+    p->cnt_off = off; p->cnt_bytes = align_up((ceil_div((long)std::max(max_width, (size_t)1), 64) + 1) * 4, 256); off += p->cnt_bytes;   // arrival counters, one per 64 columns
     p->ws_bytes = off;
     *out_plan = p;
     return FD_OK;
@@ -344,6 +346,8 @@ int fd_train_plan_bind_workspace(fd_train_plan *plan, void *device_ptr, size_t b
     if (reinterpret_cast<uintptr_t>(device_ptr) % 256) return fail(FD_ERR_INVALID, "workspace must be 256-byte aligned");
     plan->ws = static_cast<unsigned char *>(device_ptr);
     plan->forward_done = false;
+    // arrival counters of the two-level reductions start at 0 (the kernels return them to 0)
+    if (hipMemset(plan->ws + plan->cnt_off, 0, plan->cnt_bytes) != hipSuccess) return fail(FD_ERR_HIP, "hipMemset(reduction counters) failed");
     return FD_OK;
 }
 
