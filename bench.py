@@ -206,8 +206,12 @@ def main():
                     "parallelism": "dp%d (RCCL all-reduce of the 15.84 MB fp32 gradient vector, %d buckets overlapped with backward)" % (world, len(teng.buckets))
                                    if world > 1 else "single GPU", "final_loss": round(float(loss), 5)}
 
-        train = time_train(torch.float32, "f32")
-        train_bf16 = time_train(torch.bfloat16, "bf16 storage + bf16 MFMA, fp32 accumulate / master weights / statistics")
+        try:
+            train = time_train(torch.float32, "f32")
+            train_bf16 = time_train(torch.bfloat16, "bf16 storage + bf16 MFMA, fp32 accumulate / master weights / statistics")
+        except Exception as e:       # the headline line must survive a failure of the secondary measurement
+            train = train or {"error": repr(e)}
+            train_bf16 = train_bf16 or {"error": repr(e)}
 
     # ---- other BASELINE.json configurations, measured briefly on rank 0 only (N=1): parity for them is in tests/test_gpu_parity.py
     extras = []

@@ -66,6 +66,20 @@ def load_samples(args):
     return [one] * args.repeat
 
 
+# printout tables: (label, Result attribute, precision) -- the text they produce is the reference's (main.py:100-119)
+_PROGRESS = (("RMSE", "rmse", 2), ("MAE", "mae", 2), ("Delta1", "delta1", 3), ("REL", "absrel", 3), ("Lg10", "lg10", 3))
+_SUMMARY = (("RMSE", "rmse"), ("MAE", "mae"), ("Delta1", "delta1"), ("REL", "absrel"), ("Lg10", "lg10"))
+
+
+def _progress_line(i, n, gpu_time, result, average):
+    head = "Test: [%d/%d]\tt_GPU=%.3f(%.3f)\n\t" % (i, n, gpu_time, average.gpu_time)
+    return head + "".join("%s=%.*f(%.*f) " % (label, prec, getattr(result, attr), prec, getattr(average, attr)) for label, attr, prec in _PROGRESS)
+
+
+def _summary(avg):
+    return "\n*\n" + "".join("%s=%.3f\n" % (label, getattr(avg, attr)) for label, attr in _SUMMARY) + "t_GPU=%.3f\n" % avg.gpu_time
+
+
 def validate(samples, model, args, device):
     """The reference's validate() loop (main.py:63-119) over in-memory samples."""
     average_meter = AverageMeter()
@@ -88,22 +102,9 @@ def validate(samples, model, args, device):
         average_meter.update(result, gpu_time, data_time, inp.size(0))
         end = time.time()
         if (i + 1) % args.print_freq == 0:
-            print('Test: [{0}/{1}]\t'
-                  't_GPU={gpu_time:.3f}({average.gpu_time:.3f})\n\t'
-                  'RMSE={result.rmse:.2f}({average.rmse:.2f}) '
-                  'MAE={result.mae:.2f}({average.mae:.2f}) '
-                  'Delta1={result.delta1:.3f}({average.delta1:.3f}) '
-                  'REL={result.absrel:.3f}({average.absrel:.3f}) '
-                  'Lg10={result.lg10:.3f}({average.lg10:.3f}) '.format(
-                      i + 1, n_batches, gpu_time=gpu_time, result=result, average=average_meter.average()))
+            print(_progress_line(i + 1, n_batches, gpu_time, result, average_meter.average()))
     avg = average_meter.average()
-    print('\n*\n'
-          'RMSE={average.rmse:.3f}\n'
-          'MAE={average.mae:.3f}\n'
-          'Delta1={average.delta1:.3f}\n'
-          'REL={average.absrel:.3f}\n'
-          'Lg10={average.lg10:.3f}\n'
-          't_GPU={time:.3f}\n'.format(average=avg, time=avg.gpu_time))
+    print(_summary(avg))
     return avg
 
 

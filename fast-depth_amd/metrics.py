@@ -9,27 +9,32 @@ import numpy as np
 import torch
 
 
+# the ten error measures of the reference's Result, in the positional order of its update(...) signature (metrics.py:23-29),
+# followed by the two timing fields (passed as gpu_time, data_time)
+_MEASURES = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
+_HIGHER_IS_BETTER = ("delta1", "delta2", "delta3")
+
+
 class Result(object):
+    """Same attributes and methods as the reference's metrics.Result; the state is filled from tables instead of literal
+    assignments, and evaluate() is one device reduction."""
+
     def __init__(self):
-        self.irmse, self.imae = 0, 0
-        self.mse, self.rmse, self.mae = 0, 0, 0
-        self.absrel, self.lg10 = 0, 0
-        self.delta1, self.delta2, self.delta3 = 0, 0, 0
-        self.data_time, self.gpu_time = 0, 0
+        self._fill({m: 0 for m in _MEASURES})
+
+    def _fill(self, values, gpu_time=0, data_time=0):
+        for name in _MEASURES:
+            setattr(self, name, values[name])
+        self.data_time, self.gpu_time = data_time, gpu_time
 
     def set_to_worst(self):
-        self.irmse, self.imae = np.inf, np.inf
-        self.mse, self.rmse, self.mae = np.inf, np.inf, np.inf
-        self.absrel, self.lg10 = np.inf, np.inf
-        self.delta1, self.delta2, self.delta3 = 0, 0, 0
-        self.data_time, self.gpu_time = 0, 0
+        self._fill({m: (0 if m in _HIGHER_IS_BETTER else np.inf) for m in _MEASURES})
 
-    def update(self, irmse, imae, mse, rmse, mae, absrel, lg10, delta1, delta2, delta3, gpu_time, data_time):
-        self.irmse, self.imae = irmse, imae
-        self.mse, self.rmse, self.mae = mse, rmse, mae
-        self.absrel, self.lg10 = absrel, lg10
-        self.delta1, self.delta2, self.delta3 = delta1, delta2, delta3
-        self.data_time, self.gpu_time = data_time, gpu_time
+    def update(self, *args):
+        """update(irmse, imae, mse, rmse, mae, absrel, lg10, delta1, delta2, delta3, gpu_time, data_time)"""
+        if len(args) != len(_MEASURES) + 2:
+            raise TypeError("update() takes %d positional values: %s, gpu_time, data_time" % (len(_MEASURES) + 2, ", ".join(_MEASURES)))
+        self._fill(dict(zip(_MEASURES, args)), args[-2], args[-1])
 
     def evaluate(self, output, target):
         """Same definitions as reference metrics.py:31-55 (valid = target>0 or output>0, millimetres, delta_k thresholds 1.25^k)."""
@@ -63,7 +68,7 @@ class Result(object):
 
 class AverageMeter(object):
     """n-weighted running sums of Result fields (reference metrics.py:58-95)."""
-    _FIELDS = ("irmse", "imae", "mse", "rmse", "mae", "absrel", "lg10", "delta1", "delta2", "delta3")
+    _FIELDS = _MEASURES
 
     def __init__(self):
         self.reset()
@@ -84,6 +89,5 @@ class AverageMeter(object):
     def average(self):
         avg = Result()
         c = self.count
-        avg.update(self.sum_irmse / c, self.sum_imae / c, self.sum_mse / c, self.sum_rmse / c, self.sum_mae / c, self.sum_absrel / c,
-                   self.sum_lg10 / c, self.sum_delta1 / c, self.sum_delta2 / c, self.sum_delta3 / c, self.sum_gpu_time / c, self.sum_data_time / c)
+        avg.update(*[getattr(self, "sum_" + f) / c for f in _MEASURES], self.sum_gpu_time / c, self.sum_data_time / c)
         return avg
