@@ -71,6 +71,7 @@ struct Layer {
     bool pw_packed_t = false;    // packed weights are 16-bit (pointwise layers of a 16-bit plan)
     // dw tiling
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0;
+    int csplit = 0;              // concatenating consumer: channels [0, csplit) come from src, the rest from skip
     bool skipped = false;        // depthwise layer executed inside the following pointwise layer's fused kernel
     int fused_dw = -1;           // pointwise layer: index of the depthwise layer fused into it
     int np = 0, flat = 0, gpw = 0;   // fused kernel: patch pixels, tile mapping, LDS-DMA instructions per wave per chunk
@@ -189,7 +190,7 @@ template <typename T, int K, int S, int MODE, int ACT>
 int launch_dw_inst(const Layer &L, const T *in, const T *skip, const float *wp, const float *bias, T *out, hipStream_t s)
 {
     FD_LAUNCH((fd_dwconv<T, K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
-                       L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);
+                       L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit);
     return check_launch("fd_dwconv");
 }
 
@@ -212,6 +213,7 @@ int launch_dw(const Layer &L, const T *in, const T *skip, const float *wp, const
     case 512: return launch_dw_inst<T, 5, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
     case 311: return launch_dw_inst<T, 3, 1, 1, ACT>(L, in, skip, wp, bias, out, s);
     case 312: return launch_dw_inst<T, 3, 1, 2, ACT>(L, in, skip, wp, bias, out, s);
+    case 513: return launch_dw_inst<T, 5, 1, 3, ACT>(L, in, skip, wp, bias, out, s);
     }
     return fail(FD_ERR_INVALID, "depthwise k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
 }
@@ -369,13 +371,18 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         int src_h, src_w, src_c;
         if (d.src < 0) { src_h = height; src_w = width; src_c = 3; }
         else { const Layer &S = p->layers[d.src]; src_h = S.out_h; src_w = S.out_w; src_c = S.d.cout; }
-        if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
+        const bool concat = d.concat != 0;
+        if (concat && (d.skip < 0 || d.op != FD_OP_DW || !d.upsample)) FD_BAD("layer %d: concat needs an upsampled depthwise consumer with a skip tensor", i);
+        if (concat) {
+            L.csplit = src_c;
+            if (src_c + p->layers[d.skip].d.cout != d.cin || src_c % 4) FD_BAD("layer %d: concat of %d + %d channels does not give cin %d", i, src_c, p->layers[d.skip].d.cout, d.cin);
+        } else if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
         L.in_h = d.upsample ? 2 * src_h : src_h;
         L.in_w = d.upsample ? 2 * src_w : src_w;
         if (d.skip >= 0) {
             const Layer &S = p->layers[d.skip];
             if (!d.upsample) FD_BAD("layer %d: skip without upsample is not part of this path", i);
-            if (S.out_h != L.in_h || S.out_w != L.in_w || S.d.cout != d.cin)
+            if (S.out_h != L.in_h || S.out_w != L.in_w || (!concat && S.d.cout != d.cin))
                 FD_BAD("layer %d: skip tensor %dx%dx%d does not match input %dx%dx%d", i, S.out_h, S.out_w, S.d.cout, L.in_h, L.in_w, d.cin);
         }
         switch (d.op) {
@@ -392,7 +399,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4)
                 FD_BAD("layer %d: depthwise needs cin==cout (multiple of 4), k in {3,5}, stride in {1,2}", i);
             if (d.stride == 2 && (L.in_h % 2 || L.in_w % 2)) FD_BAD("layer %d: stride-2 depthwise on odd input", i);
-            L.mode = d.upsample ? (d.skip >= 0 ? 2 : 1) : 0;
+            L.mode = d.upsample ? (d.skip >= 0 ? (concat ? 3 : 2) : 1) : 0;
             L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
             if (d.ksize == 3 && L.mode == 0) {
                 // register-window kernel: pick the row-strip height so that the grid has >= ~4 workgroups per CU when it can
@@ -530,8 +537,9 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     for (int i = 0; i < n_layers; ++i) {
         Layer &L = p->layers[i];
         const fd_layer_desc &d = L.d;
-        const double src_elems = (double)batch * (d.upsample ? (L.in_h / 2) * (L.in_w / 2) : L.in_h * L.in_w) * d.cin;
-        const double skip_elems = d.skip >= 0 ? (double)batch * L.in_h * L.in_w * d.cin : 0.0;
+        const int c_src = L.csplit ? L.csplit : d.cin, c_skip = L.csplit ? d.cin - L.csplit : d.cin;
+        const double src_elems = (double)batch * (d.upsample ? (L.in_h / 2) * (L.in_w / 2) : L.in_h * L.in_w) * c_src;
+        const double skip_elems = d.skip >= 0 ? (double)batch * L.in_h * L.in_w * c_skip : 0.0;
         const double out_elems = (double)batch * L.out_h * L.out_w * d.cout;
         const double w_elems = (double)L.w_elems + 2.0 * d.cout;
         const double in_esz = d.src < 0 ? 4.0 : (double)esz, out_esz = L.to_output ? 4.0 : (double)esz;   // network input / output stay fp32

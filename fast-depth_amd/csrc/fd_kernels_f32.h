@@ -126,7 +126,7 @@ template <typename T, int K, int S, int MODE, int ACT>
 __global__ void __launch_bounds__(256)
 fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ wp,
           const float *__restrict__ bias, T *__restrict__ out, int Hin, int Win, int Ho, int Wo, int C,
-          int cbq, int TH, int TW, int tiles_x)
+          int cbq, int TH, int TW, int tiles_x, int csplit)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;                       // input columns feeding 4 adjacent outputs
@@ -169,8 +169,15 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
                     v[u] = fd_ld4(in + (((long)n * Hin + gy) * Win + gx) * C + cg);
                 } else {
                     const int Hs = Hin >> 1, Ws = Win >> 1;
-                    v[u] = fd_ld4(in + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
-                    if (MODE == 2) sk[u] = fd_ld4(skip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                    if (MODE == 3) {
+                        // channel concatenation cat(up2(in), skip): channels [0, csplit) come from the low-resolution tensor (pitch
+                        // csplit), the rest from the skip tensor (pitch C - csplit); a lane's 4 channels never straddle (csplit % 4 == 0)
+                        if (cg < csplit) v[u] = fd_ld4(in + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * csplit + cg);
+                        else v[u] = fd_ld4(skip + (((long)n * Hin + gy) * Win + gx) * (C - csplit) + (cg - csplit));
+                    } else {
+                        v[u] = fd_ld4(in + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                        if (MODE == 2) sk[u] = fd_ld4(skip + (((long)n * Hin + gy) * Win + gx) * C + cg);
+                    }
                 }
             }
         }

@@ -217,6 +217,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.d = layers[i];
         const fd_layer_desc &d = L.d;
         if (d.src >= i || d.skip >= i) FD_BAD("layer %d: src/skip must reference earlier layers", i);
+        if (d.concat) FD_BAD("layer %d: the train step of concatenating skips (MobileNetSkipConcat) is not built", i);
         if (d.act != FD_ACT_RELU && d.act != FD_ACT_RELU6) FD_BAD("layer %d: train mode needs ReLU or ReLU6", i);
         int src_h, src_w, src_c;
         if (d.src < 0) { src_h = height; src_w = width; src_c = 3; }

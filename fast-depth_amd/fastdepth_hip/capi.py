@@ -27,7 +27,7 @@ FD_PLAN_STREAMK = 32
 
 class LayerDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("op", "cin", "cout", "ksize", "stride", "act", "src", "upsample", "skip", "reserved")]
+                ("op", "cin", "cout", "ksize", "stride", "act", "src", "upsample", "skip", "concat")]
 
 
 class LayerParams(ctypes.Structure):

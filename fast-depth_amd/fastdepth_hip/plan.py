@@ -49,7 +49,7 @@ def _units(seq):
 class Layer:
     __slots__ = ("conv", "bn", "desc", "name")
 
-    def __init__(self, name, conv, bn, act, src, upsample=0, skip=-1):
+    def __init__(self, name, conv, bn, act, src, upsample=0, skip=-1, concat=0):
         k = conv.kernel_size[0]
         if conv.groups == 1 and k == 3:
             op = capi.FD_OP_STEM
@@ -61,7 +61,7 @@ class Layer:
             raise capi.FastDepthError("%s: conv %r has no fused kernel on this path" % (name, conv))
         self.name, self.conv, self.bn = name, conv, bn
         self.desc = capi.LayerDesc(op, conv.in_channels, conv.out_channels, k, conv.stride[0], act, src,
-                                   upsample, skip, 0)
+                                   upsample, skip, concat)
 
 
 def _layers_of_plain(model):
@@ -96,10 +96,11 @@ def layers_of(model):
         if i in (1, 3, 5):
             skips[i] = src
     skip_after = {2: 5, 3: 3, 4: 1}        # decode stage -> encoder block whose output is added after its upsample
+    concat = 1 if getattr(type(model), "_fd_skip", "add") == "concat" else 0      # MobileNetSkipConcat: torch.cat instead of + (models.py:803-808)
     pending_up, pending_skip = 0, -1
     for j in range(1, 7):
         for q, (conv, bn, act) in enumerate(_units(getattr(model, "decode_conv%d" % j))):
-            layers.append(Layer("decode_conv%d.%d" % (j, q), conv, bn, act, src, pending_up, pending_skip))
+            layers.append(Layer("decode_conv%d.%d" % (j, q), conv, bn, act, src, pending_up, pending_skip, concat if pending_skip >= 0 else 0))
             pending_up, pending_skip = 0, -1
             src = len(layers) - 1
         if j <= 5:

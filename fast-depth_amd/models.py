@@ -25,7 +25,7 @@ import torch.nn as nn
 
 import imagenet.mobilenet as _mobilenet
 
-__all__ = ["MobileNetSkipAdd", "MobileNet", "NNConv", "choose_decoder", "depthwise", "pointwise", "weights_init", "PRUNED_CHANNELS"]
+__all__ = ["MobileNetSkipAdd", "MobileNetSkipConcat", "MobileNet", "NNConv", "choose_decoder", "depthwise", "pointwise", "weights_init", "PRUNED_CHANNELS"]
 
 # Channel plan of `mobilenet-nnconv5dw-skipadd-pruned`, reconstructed from the reference's TVM tuning
 # log (tvm_compile/tuning/tx2-gpu.mobilenet-nnconv5dw-skipadd-pruned.trials=2000.stop=600.log:1-38,
@@ -193,3 +193,32 @@ class MobileNetSkipAdd(_HipForward):
         # NB: the reference calls weights_init(self.decode_convN) directly on the Sequential
         # (models.py:699-704), which matches none of the isinstance tests -> the decoder keeps
         # torch's default initialisation.  Nothing to do here; stated so nobody "fixes" it.
+
+
+class MobileNetSkipConcat(_HipForward):
+    """MobileNet-v1 encoder + NNConv5 depthwise-separable decoder whose three skips are CONCATENATED along the channel axis
+    (reference models.py:734-814).  Same attribute names as MobileNetSkipAdd; decode_conv3/4/5 consume
+    cat(up(x), skip) and are therefore twice as wide (512 / 256 / 128 channels).  Inference path only: the depthwise kernel
+    reads the two channel ranges from their two tensors (`fd_layer_desc.concat`), nothing is concatenated in memory."""
+
+    _fd_skip = "concat"                      # class attribute: survives unpickling of reference-format checkpoints
+
+    def __init__(self, output_size, pretrained=True):
+        super().__init__()
+        self.output_size = output_size
+        mobilenet = _mobilenet.MobileNet()
+        if pretrained:
+            import os
+            path = os.path.join('imagenet', 'results', 'imagenet.arch=mobilenet.lr=0.1.bs=256', 'model_best.pth.tar')
+            state = torch.load(path, weights_only=False)['state_dict']
+            mobilenet.load_state_dict({k[len('module.'):] if k.startswith('module.') else k: v for k, v in state.items()})
+        else:
+            mobilenet.apply(weights_init)
+        for i in range(14):
+            setattr(self, 'conv{}'.format(i), mobilenet.model[i])
+        # (decoder input width, output width): the skip tensors conv5 / conv3 / conv1 (256 / 128 / 64 channels) double the
+        # inputs of stages 3, 4, 5
+        for j, (cin, cout) in enumerate(((1024, 512), (512, 256), (512, 128), (256, 64), (128, 32)), start=1):
+            setattr(self, 'decode_conv{}'.format(j), nn.Sequential(depthwise(cin, 5), pointwise(cin, cout)))
+        self.decode_conv6 = pointwise(32, 1)
+        # as in MobileNetSkipAdd the reference's weights_init(self.decode_convN) calls are no-ops on Sequentials

@@ -81,7 +81,7 @@ def golden_sibling_case(name):
         meta = json.load(f)[name]
     models = product_models()
     torch.manual_seed(meta["seed"])
-    m = models.MobileNet(meta["decoder"], (224, 224), pretrained=False)
+    m = models.MobileNetSkipConcat((224, 224), pretrained=False) if meta["decoder"] == "skipconcat" else models.MobileNet(meta["decoder"], (224, 224), pretrained=False)
     sd = m.state_dict()
     if len(sd) != meta["keys"]:
         raise AssertionError("state_dict has %d keys, the reference has %d" % (len(sd), meta["keys"]))

@@ -116,3 +116,44 @@ def test_emulated_no_skip_sibling_forward():
     y = plan.forward(x)
     plan.close()
     assert harness.rel_err(y.numpy(), ref.numpy()) < TOL
+
+
+def test_emulated_skip_concat_sibling_forward():
+    """Row f-3: `MobileNetSkipConcat` -- the depthwise kernel reads cat(up2(x), skip) as two channel ranges of two tensors
+    (fd_layer_desc.concat, MODE 3).  Full widths, 32x32 input, against a torch-functional restatement of the reference's
+    forward (models.py:786-813) built from the product module's own tensors."""
+    import torch.nn.functional as F
+    models = inputs.product_models()
+    torch.manual_seed(31)
+    m = harness.randomize_bn(models.MobileNetSkipConcat((32, 32), pretrained=False), 32).eval()
+    x = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(33))
+
+    def unit(t, seq):
+        mods = []
+        for c in seq:
+            mods += list(c) if isinstance(c, torch.nn.Sequential) else [c]
+        for i in range(0, len(mods), 3):
+            conv, bn, act = mods[i:i + 3]
+            t = F.conv2d(t.double(), conv.weight.double(), None, conv.stride, conv.padding, 1, conv.groups)
+            t = F.batch_norm(t, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(), False, 0.1, bn.eps)
+            t = t.clamp(0, 6) if isinstance(act, torch.nn.ReLU6) else t.clamp(min=0)
+        return t
+
+    with torch.no_grad():
+        t, skips = x, {}
+        for i in range(14):
+            t = unit(t, getattr(m, "conv%d" % i))
+            if i in (1, 3, 5):
+                skips[i] = t
+        for j in range(1, 6):
+            t = unit(t, getattr(m, "decode_conv%d" % j))
+            t = F.interpolate(t, scale_factor=2, mode="nearest")
+            if j in (2, 3, 4):
+                t = torch.cat((t, skips[{2: 5, 3: 3, 4: 1}[j]]), 1)
+        ref = unit(t, m.decode_conv6)
+    plan = harness.CPlan("emu", m, x, keep=False)
+    y = plan.forward(x)
+    plan.close()
+    assert harness.rel_err(y.numpy(), ref.numpy()) < TOL
+    with pytest.raises(harness.capi.FastDepthError):
+        harness.CTrainPlan("emu", m, x)                    # the train step of the concatenating variant is not built

@@ -178,3 +178,16 @@ def test_no_skip_sibling_matches_reference_output():
     with torch.no_grad():
         yb = m(x.cuda()).cpu()
     assert harness.rel_err(yb.numpy(), y_ref.numpy()) < 3e-2
+
+
+def test_skip_concat_sibling_matches_reference_output():
+    """Row f-3: `MobileNetSkipConcat` against the reference's own output (tests/golden/skipconcat_s6_*), fp32 and fp16 storage."""
+    m, x, y_ref, meta = inputs.golden_sibling_case("skipconcat_s6")
+    m = m.cuda()
+    with torch.no_grad():
+        y = m(x.cuda()).cpu()
+    assert harness.rel_err(y.numpy(), y_ref.numpy()) < 1e-3
+    m.set_compute_dtype(torch.float16)
+    with torch.no_grad():
+        yh = m(x.cuda()).cpu()
+    assert harness.rel_err(yh.numpy(), y_ref.numpy()) < 2e-2

@@ -107,3 +107,14 @@ def test_no_skip_sibling_matches_reference_surface():
         models.MobileNet("deconv3", (224, 224), pretrained=False)        # decoders outside the accelerated path say so
     with pytest.raises(RuntimeError):
         m(x)                                                              # CPU tensor: no fallback
+
+
+def test_skip_concat_sibling_matches_reference_surface():
+    """Row f-3, second sibling: `MobileNetSkipConcat` (reference models.py:734-814) -- same keys, bit-identical seeded weights."""
+    from oracle import inputs
+    from fastdepth_hip.plan import layers_of
+    m, x, y, meta = inputs.golden_sibling_case("skipconcat_s6")
+    assert m.decode_conv3[0][0].in_channels == 512 and m.decode_conv5[1][0].in_channels == 128
+    descs = [l.desc for l in layers_of(m)]
+    cat = [(d.cin, d.concat, d.skip) for d in descs if d.concat]
+    assert [c[0] for c in cat] == [512, 256, 128] and all(c[2] >= 0 for c in cat)
