@@ -294,6 +294,18 @@ int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, 
                                   : train_backward_t<float>(plan, params, grads, n_layers, dy, from_layer, to_layer, stream);
 }
 
+int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t height, int32_t width, int32_t out_h, int32_t out_w,
+                     const int32_t *ymap_device, const int32_t *xmap_device, float *x_out, float *depth_out, void *stream)
+{
+    if (!rgb_u8 || !ymap_device || !xmap_device || !x_out || n <= 0 || height <= 0 || width <= 0 || out_h <= 0 || out_w <= 0)
+        return fail(FD_ERR_INVALID, "fd_val_transform: null/empty argument");
+    if ((depth == nullptr) != (depth_out == nullptr)) return fail(FD_ERR_INVALID, "fd_val_transform: depth and depth_out go together");
+    const long total = (long)n * out_h * out_w;
+    FD_LAUNCH(fd_val_transform_u8, dim3((unsigned)std::min<long>(4096, ceil_div(total, 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+              static_cast<const unsigned char *>(rgb_u8), depth, ymap_device, xmap_device, x_out, depth_out, n, height, width, out_h, out_w);
+    return check_launch("fd_val_transform_u8");
+}
+
 size_t fd_depth_metrics_scratch_bytes(void) { return (size_t)1024 * 10 * sizeof(double); }
 
 int fd_depth_metrics(const void *output, const void *target, int64_t numel, double *sums_device, void *scratch, void *stream)

@@ -13,6 +13,7 @@
 #include "fd_kernels_train.h"
 #include "fd_kernels_bwd.h"
 #include "fd_kernels_train_h16.h"
+#include "fd_kernels_io.h"
 
 // workgroups the pointwise weight-gradient GEMM aims for (output tiles x pixel splits); every split writes a private fp32 partial
 // tile that fd_reduce_partials_f32 sums afterwards, so more splits = more parallelism but more partial traffic

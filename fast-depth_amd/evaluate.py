@@ -9,8 +9,10 @@ Differences from the reference, all deliberate:
   * any batch size (the reference validates with batch 1, main.py:40-41);
   * metrics come from ONE fused device reduction per batch (metrics.py of this package) instead of ~12 host syncs;
   * the NYU-Depth-v2 HDF5 loader is not rebuilt (dataset absent, h5py absent; dataloaders/ depends on removed SciPy/NumPy
-    APIs): samples are `.npz` files holding `rgb` ([H,W,3] uint8 or float in [0,1]) and `depth` ([H,W] float32 metres) already at
-    the network resolution, or -- by default -- the reference's own shipped sample (deploy/data) replicated.
+    APIs): samples are `.npz` files holding `rgb` and `depth` -- either RAW frames ([480,640,3] uint8 + [480,640] float32
+    metres), which go through the reference's val_transform as ONE device gather (dataloaders/nyu.py, pinned against PIL), or
+    frames already at the network resolution ([H,W,3] uint8 or float in [0,1]) -- or, by default, the reference's own shipped
+    sample (deploy/data) replicated.
 A checkpoint is the reference's pickle ({'epoch','best_result','model'} or a bare module, main.py:49-57); without one, a seeded
 random-weight model is evaluated (useful only as a smoke test of the loop).
 """
@@ -54,6 +56,10 @@ def load_samples(args):
         out = []
         for f in files:
             z = np.load(f)
+            if z['rgb'].dtype == np.uint8 and z['rgb'].shape[:2] == (480, 640):
+                # raw NYU frame: kept as uint8 HWC; validate() runs the reference's val_transform on the GPU (dataloaders/nyu.py)
+                out.append((torch.from_numpy(z['rgb']), torch.from_numpy(z['depth'].astype(np.float32))))
+                continue
             rgb = z['rgb'].astype(np.float32)
             if rgb.max() > 1.5:
                 rgb = rgb / 255.0
@@ -90,6 +96,10 @@ def validate(samples, model, args, device):
         chunk = samples[i * args.batch_size:(i + 1) * args.batch_size]
         inp = torch.stack([c[0] for c in chunk]).to(device, non_blocking=True)
         target = torch.stack([c[1] for c in chunk]).to(device, non_blocking=True)
+        if inp.dtype == torch.uint8:                     # raw 480 x 640 frames: val_transform (nyu.py:48-59) as one device gather
+            from dataloaders.nyu import GpuValTransform
+            tf = validate.__dict__.setdefault("_tf", GpuValTransform((224, 224), device))
+            inp, target = tf(inp, target)
         torch.cuda.synchronize(device)
         data_time = time.time() - end
         end = time.time()

@@ -106,6 +106,8 @@ def load(path=None):
         lib.fd_l1_loss.restype = ctypes.c_int
         lib.fd_sgd_step.argtypes = [vp, i32, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i32, vp]
         lib.fd_sgd_step.restype = ctypes.c_int
+    lib.fd_val_transform.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.fd_val_transform.restype = ctypes.c_int
     lib.fd_depth_metrics_scratch_bytes.argtypes = []
     lib.fd_depth_metrics_scratch_bytes.restype = ctypes.c_size_t
     lib.fd_depth_metrics.argtypes = [vp, vp, ctypes.c_int64, vp, vp, vp]
@@ -120,7 +122,7 @@ EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_p
            "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats",
            "fd_train_plan_create", "fd_train_plan_destroy", "fd_train_plan_workspace_bytes", "fd_train_plan_bind_workspace",
            "fd_train_forward", "fd_train_backward", "fd_train_backward_range", "fd_train_layer_tensor", "fd_l1_loss_scratch_bytes",
-           "fd_l1_loss", "fd_sgd_step", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics", "fd_last_error", "fd_version")
+           "fd_l1_loss", "fd_sgd_step", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics", "fd_last_error", "fd_version")
 
 
 def check(lib, rc, what):

@@ -193,6 +193,14 @@ int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t to
  *   [8] sum (1/o-1/t)^2, [9] sum |1/o-1/t|      with valid = (target>0)|(output>0), o = 1e3*output, t = 1e3*target.
  * `sums_device` = 10 doubles on the device; `scratch` needs fd_depth_metrics_scratch_bytes() bytes.  The reference issues ~12
  * device->host synchronisations per sample for the same numbers (one float() per metric). */
+/* Input preparation (reference dataloaders/nyu.py:48-59 val_transform: Resize(250/480) -> CenterCrop(228,304)
+ * -> Resize(output_size), nearest-neighbour, then /255): gathers n raw frames rgb[n][H][W][3] (uint8) and, if depth != NULL,
+ * depth[n][H][W] (fp32) through a row table ymap[out_h] and a column table xmap[out_w] (device int32 arrays holding source
+ * indices; the host composes the three steps, fast-depth_amd/dataloaders/nyu.py) into the network input x[n][3][out_h][out_w]
+ * (fp32, value/255 computed in double as the reference does) and depth_out[n][1][out_h][out_w]. */
+int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t height, int32_t width, int32_t out_h, int32_t out_w,
+                     const int32_t *ymap_device, const int32_t *xmap_device, float *x_out, float *depth_out, void *stream);
+
 size_t fd_depth_metrics_scratch_bytes(void);
 int fd_depth_metrics(const void *output, const void *target, int64_t numel, double *sums_device, void *scratch, void *stream);
 

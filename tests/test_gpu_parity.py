@@ -191,3 +191,25 @@ def test_skip_concat_sibling_matches_reference_output():
     with torch.no_grad():
         yh = m(x.cuda()).cpu()
     assert harness.rel_err(yh.numpy(), y_ref.numpy()) < 2e-2
+
+
+def test_gpu_val_transform_and_raw_frame_evaluation(tmp_path):
+    """Row f-1: raw 480x640 uint8 frames -> GpuValTransform -> network, against the PIL restatement of the reference's
+    val_transform; and the evaluation harness on raw-size .npz samples."""
+    import sys
+    sys.path.insert(0, inputs.PKG)
+    from dataloaders.nyu import GpuValTransform
+    from oracle import val_transform as ovt
+    import evaluate as fd_eval
+    g = np.random.default_rng(2)
+    rgb = g.integers(0, 256, (3, 480, 640, 3), dtype=np.uint8)
+    depth = (g.random((3, 480, 640), dtype=np.float32) * 9 + 0.7).astype(np.float32)
+    x, d = GpuValTransform((224, 224))(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda())
+    for f in range(3):
+        want_rgb, want_d = ovt.val_transform(rgb[f], depth[f])
+        assert np.array_equal(x[f].permute(1, 2, 0).cpu().numpy(), want_rgb.astype(np.float32))
+        assert np.array_equal(d[f, 0].cpu().numpy(), want_d)
+    for f in range(3):
+        np.savez(str(tmp_path / ("%05d.npz" % f)), rgb=rgb[f], depth=depth[f])
+    avg = fd_eval.main(["--samples", str(tmp_path), "--batch-size", "2", "-p", "1"])
+    assert np.isfinite(avg.rmse) and avg.rmse > 0
