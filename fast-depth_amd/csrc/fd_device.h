@@ -126,6 +126,14 @@ __device__ __forceinline__ float fd_ld1(const fd_bf16 *p) { return fd_bf16_to_f3
 __device__ __forceinline__ void fd_st1(float *p, float v) { *p = v; }
 __device__ __forceinline__ void fd_st1(fd_half *p, float v) { *p = (_Float16)v; }
 __device__ __forceinline__ void fd_st1(fd_bf16 *p, float v) { p->v = fd_f32_to_bf16(v); }
+// Walks a row-major index space of width w in steps of `step` without a division per visit: the staging loops of the LDS-tiled
+// depthwise kernels visit patch pixel start, start+step, start+2*step, ... (their integer address arithmetic, not the FMAs, was
+// the largest VALU consumer: PMC).
+struct fd_px_walk {
+    int iy, ix, dy, dx, w;
+    __device__ __forceinline__ fd_px_walk(int start, int step, int w_) : w(w_) { iy = start / w_; ix = start - iy * w_; dy = step / w_; dx = step - dy * w_; }
+    __device__ __forceinline__ void next() { ix += dx; iy += dy; if (ix >= w) { ix -= w; ++iy; } }
+};
 __device__ __forceinline__ fd_f32x4 fd_zero4() { fd_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 // ---- device-coherent accesses ("last arriver" reductions: stream-K partial tiles, fused two-level reductions of the train step) ----

@@ -558,13 +558,15 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
     if (c_ok) { cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = 8;
+    fd_px_walk wk(pt, npt, PW);
     for (int base = pt; base < npx; base += npt * U) {
         fd_f32x4 g[U], z[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            const int py = px / PW, pxx = px - py * PW;
+            const int py = wk.iy, pxx = wk.ix;
+            wk.next();
             const int oy = oyb + py, ox = oxb + pxx;
             ok[u] = px < npx && c_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
             g[u] = fd_zero4(); z[u] = fd_zero4();
@@ -738,13 +740,15 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + tab_c); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
     constexpr int U = 4;
+    fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
         fd_f32x4 v[U], sk[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            const int iy = px / TW_in, ix = px - iy * TW_in;
+            const int iy = wk.iy, ix = wk.ix;
+            wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
             v[u] = fd_zero4(); sk[u] = fd_zero4();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;

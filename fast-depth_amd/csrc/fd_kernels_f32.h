@@ -156,12 +156,14 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
     // chain per pixel would serialise ~12 HBM round trips per workgroup.
     const int npx_in = TH_in * TW_in;
     constexpr int U = 8;
+    fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
         fd_f32x4 v[U], sk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            const int iy = px / TW_in, ix = px - iy * TW_in;
+            const int iy = wk.iy, ix = wk.ix;
+            wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
             v[u] = fd_zero4(); sk[u] = fd_zero4();
             if (px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {

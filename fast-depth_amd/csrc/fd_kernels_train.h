@@ -153,13 +153,15 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     }
     const int npx_in = TH_in * TW_in;
     constexpr int U = 8;
+    fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
         fd_f32x4 v[U], sk[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            const int iy = px / TW_in, ix = px - iy * TW_in;
+            const int iy = wk.iy, ix = wk.ix;
+            wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
             v[u] = fd_zero4(); sk[u] = fd_zero4();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
