@@ -111,6 +111,21 @@ def test_train_step_layer_local_parity_full_size(pruned, dtype):
     assert_local_parity(rep, dtype)
 
 
+def test_no_skip_sibling_train_step_layer_local():
+    """Row f-3: the train step of `MobileNet('nnconv5dw')` (upsampled depthwise inputs without skips: dw MODE 1 forward / dgrad /
+    wgrad) through the same layer-local check, fp32 and bf16 plans."""
+    from test_emu_train import assert_local_parity
+    models = inputs.product_models()
+    torch.manual_seed(13)
+    m = models.MobileNet("nnconv5dw", (224, 224), pretrained=False)
+    m.decoder.conv6[1].bias.data.fill_(2.8)
+    x, tgt = _batch(2, seed=6)
+    for dtype in (torch.float32, torch.bfloat16):
+        rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
+        rep.setdefault("skip_grad", (0.0, "none"))                       # no skip tensors in this model
+        assert_local_parity(rep, dtype)
+
+
 def test_bf16_train_step_end_to_end():
     """SURVEY.md 8(d) config 3, end to end (the rigorous statement is the layer-local test above).  This randomly initialised
     train-mode network amplifies relative perturbations ~300x from input to prediction (fp32 rounding, 6e-8, arrives as 2e-5:
