@@ -213,3 +213,19 @@ def test_gpu_val_transform_and_raw_frame_evaluation(tmp_path):
         np.savez(str(tmp_path / ("%05d.npz" % f)), rgb=rgb[f], depth=depth[f])
     avg = fd_eval.main(["--samples", str(tmp_path), "--batch-size", "2", "-p", "1"])
     assert np.isfinite(avg.rmse) and avg.rmse > 0
+
+
+def test_large_batch_matches_small_batches_bitwise():
+    """Maximum-size edge: B = 160 frames in one plan (5x the headline batch; > 2^31 bytes of intermediate activations are never
+    indexed with 32-bit offsets) equals the same frames run as B = 32 batches, bit for bit (frames are independent and the
+    plain kernels keep a frame's arithmetic order independent of its position), fp32 and fp16 storage."""
+    m, x, _, _ = inputs.golden_case("base_s0")
+    x = inputs.batch_variants(inputs.load_sample()[0], 160, 9).cuda()
+    m = m.cuda()
+    for dt in (torch.float32, torch.float16):
+        m.set_compute_dtype(dt)
+        with torch.no_grad():
+            big = m(x)
+            small = torch.cat([m(x[i:i + 32]) for i in range(0, 160, 32)])
+        assert torch.equal(big, small), dt
+        assert bool(torch.isfinite(big).all())
