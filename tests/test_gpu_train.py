@@ -156,3 +156,22 @@ def test_bf16_train_step_end_to_end():
     assert mb.conv7[3].weight.grad is not None and bool(torch.isfinite(mb.conv7[3].weight.grad).all())
     with pytest.raises(RuntimeError):
         copy.deepcopy(base).cuda().train().set_compute_dtype(torch.float16)(x.cuda())       # fp16 training is not offered
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_train_step_is_bit_reproducible_at_batch32(dtype):
+    """Headline-size determinism: at B=32 every reduction runs its sliced 'last arriver' path (up to 98 slices, arrival order
+    differs from run to run); two steps from identical state must produce bit-identical gradients, loss and running statistics."""
+    from fastdepth_hip.train import TrainEngine
+    x, tgt = _batch(32, seed=8)
+    base = _model(seed=17)
+    out = []
+    for _ in range(2):
+        m = copy.deepcopy(base).cuda().train()
+        eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=1e-4, dtype=dtype)
+        loss = eng.step(x.cuda(), tgt.cuda()).clone()
+        out.append((loss, eng.flat_grad.clone(), {k: v.clone() for k, v in m.state_dict().items()}))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert bool(torch.isfinite(out[0][1]).all()) and float(out[0][1].abs().max()) > 0
+    for k in out[0][2]:
+        assert torch.equal(out[0][2][k], out[1][2][k]), k
