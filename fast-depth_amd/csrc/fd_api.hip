@@ -541,7 +541,6 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         const double src_elems = (double)batch * (d.upsample ? (L.in_h / 2) * (L.in_w / 2) : L.in_h * L.in_w) * c_src;
         const double skip_elems = d.skip >= 0 ? (double)batch * L.in_h * L.in_w * c_skip : 0.0;
         const double out_elems = (double)batch * L.out_h * L.out_w * d.cout;
-        const double w_elems = (double)L.w_elems + 2.0 * d.cout;
         const double in_esz = d.src < 0 ? 4.0 : (double)esz, out_esz = L.to_output ? 4.0 : (double)esz;   // network input / output stay fp32
         L.alg_bytes = (src_elems + skip_elems) * in_esz + out_elems * out_esz + (double)L.w_elems * (L.pw_packed_t ? esz : 4) + 2.0 * d.cout * 4;
         p->alg_bytes += L.alg_bytes;
