@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(256)
 fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
 {
     constexpr int P = K / 2;
     FD_DYN_SMEM(smem_raw);
@@ -583,9 +583,13 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
     }
     __syncthreads();
 
-    // producer's tables
+    // producer's tables.  MODE 3 (concatenating consumer): channels [0, csplit) belong to the low-resolution producer (pitch
+    // csplit: 2x2 sum, mask, BN partials as in MODE 1), the rest to the skip tensor (pitch C - csplit: full-resolution gradient
+    // into its skip-gradient buffer, masked later by the skip source's own consumer)
+    const bool to_skip = MODE == 3 && cg >= csplit;
+    const int Cp = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = to_skip ? cg - csplit : cg;
     fd_f32x4 sc = fd_zero4(), sh = fd_zero4(), mu = fd_zero4(), is = fd_zero4();
-    if (c_ok) { sc = fd_ld4(st_in + FD_ST_SCALE * C + cg); sh = fd_ld4(st_in + FD_ST_SHIFT * C + cg); mu = fd_ld4(st_in + FD_ST_MEAN * C + cg); is = fd_ld4(st_in + FD_ST_INVSTD * C + cg); }
+    if (c_ok && !to_skip) { sc = fd_ld4(st_in + FD_ST_SCALE * Cp + cg); sh = fd_ld4(st_in + FD_ST_SHIFT * Cp + cg); mu = fd_ld4(st_in + FD_ST_MEAN * Cp + cg); is = fd_ld4(st_in + FD_ST_INVSTD * Cp + cg); }
     fd_f32x4 ssum = fd_zero4(), ssx = fd_zero4();
     auto din_at = [&](int iy, int ix) {                    // gradient w.r.t. the conv input at tile-local (iy, ix)
         fd_f32x4 acc = fd_zero4();
@@ -650,13 +654,14 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
             } else {
                 d00 = din_at(2 * ly, 2 * lx); d01 = din_at(2 * ly, 2 * lx + 1); d10 = din_at(2 * ly + 1, 2 * lx); d11 = din_at(2 * ly + 1, 2 * lx + 1);
             }
-            if (MODE == 2) {
-                const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
-                fd_st4(SGout + o, d00); fd_st4(SGout + o + C, d01);
-                fd_st4(SGout + o + (long)Win * C, d10); fd_st4(SGout + o + (long)Win * C + C, d11);
+            if (MODE == 2 || to_skip) {
+                const long o = (((long)n * Hin + gy) * Win + gx) * C2 + cl;
+                fd_st4(SGout + o, d00); fd_st4(SGout + o + C2, d01);
+                fd_st4(SGout + o + (long)Win * C2, d10); fd_st4(SGout + o + (long)Win * C2 + C2, d11);
+                if (to_skip) continue;
             }
             fd_f32x4 v = (d00 + d01) + (d10 + d11);
-            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg;
+            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * Cp + cg;
             const fd_f32x4 z = fd_ld4(Zin + ol);
             v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
             fd_st4(Gin + ol, v);
@@ -672,9 +677,9 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
         fd_f32x4 a = fd_zero4(), b = fd_zero4();
         for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
         const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
-        if (c0 + tid * 4 < C) {
-            fd_st4(part + blk * 2 * C + c0 + tid * 4, a);
-            fd_st4(part + blk * 2 * C + C + c0 + tid * 4, b);
+        if (c0 + tid * 4 < Cp) {
+            fd_st4(part + blk * 2 * Cp + c0 + tid * 4, a);
+            fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, b);
         }
     }
 }
@@ -690,7 +695,7 @@ __global__ void __launch_bounds__(256)
 fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
-                int cbq, int TH, int TW, int tiles_x, int tpw)
+                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
@@ -710,6 +715,8 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     const int cg = c0 + c4 * 4;
     const bool c_ok = cg < C;
     int tab_c = c_ok ? cg : 0;                             // channel offset of this work-item's table entries (re-read per tile, see FD_OPAQUE)
+    const bool from_skip = MODE == 3 && cg >= csplit;      // MODE 3: cat(up2(a_in), a_skip), see fd_dwconv_train
+    const int C1 = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = from_skip ? cg - csplit : cg;
     fd_f32x4 acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = fd_zero4();
@@ -736,7 +743,11 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
         }
     }
     FD_OPAQUE(tab_c);
-    fd_f32x4 s1 = fd_ld4(st1 + FD_ST_SCALE * C + tab_c), t1 = fd_ld4(st1 + FD_ST_SHIFT * C + tab_c), s2 = fd_zero4(), t2 = fd_zero4();
+    int tab_l = c_ok ? cl : 0;
+    FD_OPAQUE(tab_l);
+    fd_f32x4 s1, t1, s2 = fd_zero4(), t2 = fd_zero4();
+    if (from_skip) { s1 = fd_ld4(st2 + FD_ST_SCALE * C2 + tab_l); t1 = fd_ld4(st2 + FD_ST_SHIFT * C2 + tab_l); }
+    else { s1 = fd_ld4(st1 + FD_ST_SCALE * C1 + tab_l); t1 = fd_ld4(st1 + FD_ST_SHIFT * C1 + tab_l); }
     if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + tab_c); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
     constexpr int U = 4;
@@ -757,7 +768,8 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
                     v[u] = fd_ld4(zin + (((long)n * Hin + gy) * Win + gx) * C + cg);
                 } else {
                     const int Hs = Hin >> 1, Ws = Win >> 1;
-                    v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                    if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C2 + cl);
+                    else v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C1 + cl);
                     if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C + cg);
                 }
             }
@@ -768,7 +780,7 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
             if (px < npx_in) {
                 fd_f32x4 a = fd_zero4();
                 if (ok[u]) {
-                    a = fd_bn_act4<ACT1>(v[u], s1, t1);
+                    a = from_skip ? fd_bn_act4<ACT2>(v[u], s1, t1) : fd_bn_act4<ACT1>(v[u], s1, t1);
                     if (MODE == 2) a += fd_bn_act4<ACT2>(sk[u], s2, t2);
                 }
                 fd_st4(s_in + px * PSTR + c4 * 4, a);

@@ -124,7 +124,7 @@ template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
 __global__ void __launch_bounds__(256)
 fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                     const float *__restrict__ st2, const float *__restrict__ w, T *__restrict__ zout,
-                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x)
+                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
@@ -146,9 +146,14 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
         const int t = i / CB, cc = i - t * CB;
         s_w[t * CB + cc] = (c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
+    // MODE 3 (channel concatenation cat(up2(a_in), a_skip), MobileNetSkipConcat): channels [0, csplit) come from the low-resolution
+    // producer (pitch csplit), the rest from the skip tensor (pitch C - csplit); a lane's 4 channels never straddle
+    const bool from_skip = MODE == 3 && cg >= csplit;
+    const int C1 = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = from_skip ? cg - csplit : cg;
     fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
     if (c_ok) {
-        s1 = fd_ld4(st1 + FD_ST_SCALE * C + cg); t1 = fd_ld4(st1 + FD_ST_SHIFT * C + cg);
+        if (from_skip) { s1 = fd_ld4(st2 + FD_ST_SCALE * C2 + cl); t1 = fd_ld4(st2 + FD_ST_SHIFT * C2 + cl); }
+        else { s1 = fd_ld4(st1 + FD_ST_SCALE * C1 + cl); t1 = fd_ld4(st1 + FD_ST_SHIFT * C1 + cl); }
         if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + cg); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + cg); }
     }
     const int npx_in = TH_in * TW_in;
@@ -170,7 +175,8 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
                     v[u] = fd_ld4(zin + (((long)n * Hin + gy) * Win + gx) * C + cg);
                 } else {
                     const int Hs = Hin >> 1, Ws = Win >> 1;
-                    v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C + cg);
+                    if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C2 + cl);
+                    else v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C1 + cl);
                     if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C + cg);
                 }
             }
@@ -181,7 +187,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
             if (px < npx_in) {
                 fd_f32x4 a = fd_zero4();                   // zero padding applies to the ACTIVATED tensor
                 if (ok[u]) {
-                    a = fd_bn_act4<ACT1>(v[u], s1, t1);
+                    a = from_skip ? fd_bn_act4<ACT2>(v[u], s1, t1) : fd_bn_act4<ACT1>(v[u], s1, t1);
                     if (MODE == 2) a += fd_bn_act4<ACT2>(sk[u], s2, t2);
                 }
                 fd_st4(s_in + px * PSTR + c4 * 4, a);

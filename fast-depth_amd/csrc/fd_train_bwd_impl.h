@@ -36,7 +36,7 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
     FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
               c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
               twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, tws(c.p, c.p->part_off),
-              L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x);
+              L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit);
     *nblk_out = tiles_x * tiles_y * c.p->B;
     return check_launch("fd_dw_dgrad");
 }
@@ -52,6 +52,7 @@ int dispatch_dw_dgrad(BwdCtx &c, int i, int *nblk)
     case 510: return launch_dw_dgrad<T, 5, 1, 0, ACT_IN, ADD_SG>(c, i, nblk);
     case 511: return launch_dw_dgrad<T, 5, 1, 1, ACT_IN, ADD_SG>(c, i, nblk);
     case 512: return launch_dw_dgrad<T, 5, 1, 2, ACT_IN, ADD_SG>(c, i, nblk);
+    case 513: return launch_dw_dgrad<T, 5, 1, 3, ACT_IN, ADD_SG>(c, i, nblk);
     }
     return fail(FD_ERR_INVALID, "train: depthwise backward k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
 }
@@ -76,10 +77,10 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
         FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), L.lds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
-                  L.cbq, L.th, L.tw, L.tiles_x, tpw);                                                                              \
+                  L.cbq, L.th, L.tw, L.tiles_x, tpw, L.csplit);                                                                    \
         break;
     switch (key) {
-        FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2)
+        FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2) FD_DWW(5, 1, 3)
     default: return fail(FD_ERR_INVALID, "train: depthwise wgrad has no kernel for this layer");
     }
 #undef FD_DWW

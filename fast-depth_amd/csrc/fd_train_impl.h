@@ -28,6 +28,7 @@ struct TLayer {
     int in_h = 0, in_w = 0, out_h = 0, out_w = 0;   // in_* = logical (post-upsample) input size; head: out_* = LOW-res size when upsample
     bool head = false;
     int mode = 0;
+    int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling
     int chunk = 0;                                            // stem
     int m_tiles = 0, n_tiles = 0;                             // pw
@@ -88,10 +89,10 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
 #define FD_DWT(K_, S_, M_)                                                                                                   \
     case K_ * 100 + S_ * 10 + M_:                                                                                            \
         FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
-                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x);                                  \
+                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit);                        \
         break;
     switch (key) {
-        FD_DWT(3, 1, 0) FD_DWT(3, 2, 0) FD_DWT(5, 1, 0) FD_DWT(5, 1, 1) FD_DWT(5, 1, 2)
+        FD_DWT(3, 1, 0) FD_DWT(3, 2, 0) FD_DWT(5, 1, 0) FD_DWT(5, 1, 1) FD_DWT(5, 1, 2) FD_DWT(5, 1, 3)
     default: return fail(FD_ERR_INVALID, "train: depthwise k=%d stride=%d mode=%d has no kernel", L.d.ksize, L.d.stride, L.mode);
     }
 #undef FD_DWT
@@ -218,12 +219,16 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.d = layers[i];
         const fd_layer_desc &d = L.d;
         if (d.src >= i || d.skip >= i) FD_BAD("layer %d: src/skip must reference earlier layers", i);
-        if (d.concat) FD_BAD("layer %d: the train step of concatenating skips (MobileNetSkipConcat) is not built", i);
         if (d.act != FD_ACT_RELU && d.act != FD_ACT_RELU6) FD_BAD("layer %d: train mode needs ReLU or ReLU6", i);
         int src_h, src_w, src_c;
         if (d.src < 0) { src_h = height; src_w = width; src_c = 3; }
         else { const TLayer &S = p->layers[d.src]; src_h = S.out_h; src_w = S.out_w; src_c = S.d.cout; }
-        if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
+        const bool concat = d.concat != 0;
+        if (concat) {
+            if (d.skip < 0 || d.op != FD_OP_DW || !d.upsample) FD_BAD("layer %d: concat needs an upsampled depthwise consumer with a skip tensor", i);
+            L.csplit = src_c;
+            if (src_c + p->layers[d.skip].d.cout != d.cin || src_c % 32) FD_BAD("layer %d: concat of %d + %d channels does not give cin %d (the first part must be a multiple of 32)", i, src_c, p->layers[d.skip].d.cout, d.cin);
+        } else if (src_c != d.cin) FD_BAD("layer %d: cin %d != producer channels %d", i, d.cin, src_c);
         if (h16 && (d.cout % 8 || (d.op != FD_OP_STEM && d.cin % 8)) && !(d.op == FD_OP_PW && d.cout == 1))
             FD_BAD("layer %d: the 16-bit train plan needs channel counts that are multiples of 8", i);
         L.in_h = d.upsample ? 2 * src_h : src_h;
@@ -231,7 +236,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         if (d.src >= 0) { if (p->layers[d.src].consumer >= 0) FD_BAD("layer %d: producer %d already has a consumer", i, d.src); p->layers[d.src].consumer = i; }
         if (d.skip >= 0) {
             const TLayer &S = p->layers[d.skip];
-            if (!d.upsample || S.out_h != L.in_h || S.out_w != L.in_w || S.d.cout != d.cin) FD_BAD("layer %d: bad skip", i);
+            if (!d.upsample || S.out_h != L.in_h || S.out_w != L.in_w || (!concat && S.d.cout != d.cin)) FD_BAD("layer %d: bad skip", i);
             if (p->layers[d.skip].skip_consumer >= 0) FD_BAD("layer %d: skip source %d used twice", i, d.skip);
             p->layers[d.skip].skip_consumer = i;
         }
@@ -247,7 +252,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             break;
         case FD_OP_DW: {
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);
-            L.mode = d.upsample ? (d.skip >= 0 ? 2 : 1) : 0;
+            L.mode = d.upsample ? (d.skip >= 0 ? (concat ? 3 : 2) : 1) : 0;
             L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
             const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);

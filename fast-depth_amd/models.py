@@ -198,15 +198,17 @@ class MobileNetSkipAdd(_HipForward):
 class MobileNetSkipConcat(_HipForward):
     """MobileNet-v1 encoder + NNConv5 depthwise-separable decoder whose three skips are CONCATENATED along the channel axis
     (reference models.py:734-814).  Same attribute names as MobileNetSkipAdd; decode_conv3/4/5 consume
-    cat(up(x), skip) and are therefore twice as wide (512 / 256 / 128 channels).  Inference path only: the depthwise kernel
-    reads the two channel ranges from their two tensors (`fd_layer_desc.concat`), nothing is concatenated in memory."""
+    cat(up(x), skip) and are therefore wider (512 / 256 / 128 channels).  The depthwise kernels read the two channel ranges
+    from their two tensors (`fd_layer_desc.concat`), forward and backward: nothing is concatenated in memory.
+    Optional, keyword-only: ``channels=(enc14, dec6)`` as in MobileNetSkipAdd (dec = the six decoder OUTPUT widths)."""
 
     _fd_skip = "concat"                      # class attribute: survives unpickling of reference-format checkpoints
 
-    def __init__(self, output_size, pretrained=True):
+    def __init__(self, output_size, pretrained=True, *, channels=None):
         super().__init__()
         self.output_size = output_size
-        mobilenet = _mobilenet.MobileNet()
+        enc, dec = (None, DEFAULT_DECODER) if channels is None else channels
+        mobilenet = _mobilenet.MobileNet(channels=enc)
         if pretrained:
             import os
             path = os.path.join('imagenet', 'results', 'imagenet.arch=mobilenet.lr=0.1.bs=256', 'model_best.pth.tar')
@@ -216,9 +218,12 @@ class MobileNetSkipConcat(_HipForward):
             mobilenet.apply(weights_init)
         for i in range(14):
             setattr(self, 'conv{}'.format(i), mobilenet.model[i])
-        # (decoder input width, output width): the skip tensors conv5 / conv3 / conv1 (256 / 128 / 64 channels) double the
-        # inputs of stages 3, 4, 5
-        for j, (cin, cout) in enumerate(((1024, 512), (512, 256), (512, 128), (256, 64), (128, 32)), start=1):
-            setattr(self, 'decode_conv{}'.format(j), nn.Sequential(depthwise(cin, 5), pointwise(cin, cout)))
-        self.decode_conv6 = pointwise(32, 1)
+        widths = [mobilenet.model[i][-3].out_channels for i in range(14)]           # encoder block outputs (skips: blocks 5, 3, 1)
+        width = widths[13]
+        skip_of = {3: widths[5], 4: widths[3], 5: widths[1]}                          # stage j consumes cat(up(stage j-1), skip)
+        for j, out in enumerate(dec[:5], start=1):
+            cin = width + skip_of.get(j, 0)
+            setattr(self, 'decode_conv{}'.format(j), nn.Sequential(depthwise(cin, 5), pointwise(cin, out)))
+            width = out
+        self.decode_conv6 = pointwise(width, dec[5])
         # as in MobileNetSkipAdd the reference's weights_init(self.decode_convN) calls are no-ops on Sequentials

@@ -68,7 +68,7 @@ typedef struct fd_layer_desc {
     int32_t upsample; /* 1: the input is the nearest-neighbour x2 upsampling of src's output (models.py:723) */
     int32_t skip;     /* >= 0: add that layer's output to the (upsampled) input before the conv (models.py:724-729); -1: none */
     int32_t concat;   /* 0: the skip tensor is ADDED (MobileNetSkipAdd); 1: it is CONCATENATED after the (upsampled) source along the channel
-                       * axis, cin = C_src + C_skip (MobileNetSkipConcat, reference models.py:796-811; depthwise consumers, inference plans) */
+                       * axis, cin = C_src + C_skip (MobileNetSkipConcat, reference models.py:796-811; depthwise consumers; train plans need C_src % 32 == 0) */
 } fd_layer_desc;
 
 /* device pointers to the live parameters of one layer (fp32, torch layouts) */

@@ -321,7 +321,7 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
             inp = F.interpolate(a, scale_factor=2, mode="nearest") if (d.upsample and not head) else a
             if d.skip >= 0:
                 ask = act(d.skip, pre(d.skip)).requires_grad_(True)
-                inp = inp + ask
+                inp = torch.cat((inp, ask), 1) if d.concat else inp + ask
         w = (rnd(w) if pw16 else w).requires_grad_(True)
         zr = F.conv2d(inp, w, None, d.stride, d.ksize // 2, 1, d.cout if d.op == FD_OP_DW else 1)
         note("z", relmax(Z[i], zr.detach()), i)

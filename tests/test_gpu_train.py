@@ -126,6 +126,24 @@ def test_no_skip_sibling_train_step_layer_local():
         assert_local_parity(rep, dtype)
 
 
+def test_skip_concat_sibling_train_step_layer_local():
+    """Row f-3: the train step of `MobileNetSkipConcat` at 224x224 (depthwise MODE 3 forward / backward-data / backward-weights),
+    fp32 and bf16 plans, layer-local fp64 check; plus one fused SGD step through TrainEngine."""
+    from test_emu_train import assert_local_parity
+    from fastdepth_hip.train import TrainEngine
+    models = inputs.product_models()
+    torch.manual_seed(14)
+    m = models.MobileNetSkipConcat((224, 224), pretrained=False)
+    m.decode_conv6[1].bias.data.fill_(2.8)
+    x, tgt = _batch(2, seed=7)
+    for dtype in (torch.float32, torch.bfloat16):
+        rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
+        assert_local_parity(rep, dtype)
+    eng = TrainEngine(copy.deepcopy(m).cuda().train(), lr=0.01)
+    l0 = float(eng.step(x.cuda(), tgt.cuda())); l1 = float(eng.step(x.cuda(), tgt.cuda()))
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0
+
+
 def test_bf16_train_step_end_to_end():
     """SURVEY.md 8(d) config 3, end to end (the rigorous statement is the layer-local test above).  This randomly initialised
     train-mode network amplifies relative perturbations ~300x from input to prediction (fp32 rounding, 6e-8, arrives as 2e-5:
