@@ -354,7 +354,9 @@ int fd_train_plan_bind_workspace(fd_train_plan *plan, void *device_ptr, size_t b
     plan->ws = static_cast<unsigned char *>(device_ptr);
     plan->forward_done = false;
     // arrival counters of the two-level reductions start at 0 (the kernels return them to 0)
-    if (hipMemset(plan->ws + plan->cnt_off, 0, plan->cnt_bytes) != hipSuccess) return fail(FD_ERR_HIP, "hipMemset(reduction counters) failed");
+    // (synchronous: the first launch may come on any stream)
+    if (hipMemset(plan->ws + plan->cnt_off, 0, plan->cnt_bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+        return fail(FD_ERR_HIP, "hipMemset(reduction counters) failed");
     return FD_OK;
 }
 

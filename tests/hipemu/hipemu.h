@@ -275,6 +275,7 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 
