@@ -569,9 +569,9 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
             wk.next();
             const int oy = oyb + py, ox = oxb + pxx;
             ok[u] = px < npx && c_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-            g[u] = fd_zero4(); z[u] = fd_zero4();
-            if (ok[u]) {
-                const long o = (((long)n * Ho + oy) * Wo + ox) * C + cg;
+            {   // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
+                const int qy = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), qx = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+                const long o = (((long)n * Ho + qy) * Wo + qx) * C + (c_ok ? cg : 0);
                 g[u] = fd_ld4(G + o); z[u] = fd_ld4(Z + o);
             }
         }
@@ -736,8 +736,9 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int gy = oy0 + oy, gx = ox0 + ox + j;
-            if (PREFETCH && pt < nstrips && c_ok && gy < Ho && gx < Wo) {
-                const long o = (((long)n * Ho + gy) * Wo + gx) * C + cg;
+            if (PREFETCH) {                                   // branch-free: clamped address, validity is re-checked where the value is used
+                const int qy = gy < Ho ? gy : Ho - 1, qx = gx < Wo ? gx : Wo - 1;
+                const long o = (((long)n * Ho + qy) * Wo + qx) * C + (c_ok ? cg : 0);
                 g0[j] = fd_ldraw4(G + o); z0[j] = fd_ldraw4(Z + o);
             }
         }
@@ -761,17 +762,18 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
             const int iy = wk.iy, ix = wk.ix;
             wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
-            v[u] = fd_zero4(); sk[u] = fd_zero4();
+            sk[u] = fd_zero4();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
-            if (ok[u]) {
-                if (MODE == 0) {
-                    v[u] = fd_ld4(zin + (((long)n * Hin + gy) * Win + gx) * C + cg);
-                } else {
-                    const int Hs = Hin >> 1, Ws = Win >> 1;
-                    if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C2 + cl);
-                    else v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C1 + cl);
-                    if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C + cg);
-                }
+            // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
+            const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
+            const int ql = c_ok ? cl : 0, qg = c_ok ? cg : 0;
+            if (MODE == 0) {
+                v[u] = fd_ld4(zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+            } else {
+                const int Hs = Hin >> 1, Ws = Win >> 1;
+                if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C2 + ql);
+                else v[u] = fd_ld4(zin + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C1 + ql);
+                if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C + qg);
             }
         }
 #pragma unroll
@@ -885,7 +887,9 @@ fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__r
                 for (int kx = 0; kx < 3; ++kx) {
                     const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
                     const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                    s_in[tid * 33 + (c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
+                    const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);   // branch-free: clamp, load, select
+                    const float v = x[(((long)n * 3 + c) * H + qy) * W + qx];
+                    s_in[tid * 33 + (c * 3 + ky) * 3 + kx] = ok ? v : 0.0f;
                 }
         for (int c = 0; c < Cout; c += 4) {
             fd_f32x4 dz = fd_zero4();

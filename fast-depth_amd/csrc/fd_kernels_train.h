@@ -69,7 +69,9 @@ fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__res
             for (int kx = 0; kx < 3; ++kx) {
                 const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
                 const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                in[(c * 3 + ky) * 3 + kx] = ok ? x[(((long)n * 3 + c) * H + iy) * W + ix] : 0.0f;
+                const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);   // branch-free: clamp, load, select
+                const float v = x[(((long)n * 3 + c) * H + qy) * W + qx];
+                in[(c * 3 + ky) * 3 + kx] = ok ? v : 0.0f;
             }
     for (int c0 = 0; c0 < Cout; c0 += CHUNK) {
         float acc[CHUNK];
@@ -168,17 +170,19 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
             const int iy = wk.iy, ix = wk.ix;
             wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
-            v[u] = fd_zero4(); sk[u] = fd_zero4();
+            sk[u] = fd_zero4();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
-            if (ok[u]) {
-                if (MODE == 0) {
-                    v[u] = fd_ld4(zin + (((long)n * Hin + gy) * Win + gx) * C + cg);
-                } else {
-                    const int Hs = Hin >> 1, Ws = Win >> 1;
-                    if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C2 + cl);
-                    else v[u] = fd_ld4(zin + (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * C1 + cl);
-                    if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + gy) * Win + gx) * C + cg);
-                }
+            // branch-free staging: the address is clamped into the image (and the channel group into the tensor) so that every
+            // lane issues its load unconditionally -- all U (x2) loads go out back to back; padding is applied when the value is used
+            const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
+            const int ql = c_ok ? cl : 0, qg = c_ok ? cg : 0;
+            if (MODE == 0) {
+                v[u] = fd_ld4(zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+            } else {
+                const int Hs = Hin >> 1, Ws = Win >> 1;
+                if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C2 + ql);
+                else v[u] = fd_ld4(zin + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C1 + ql);
+                if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C + qg);
             }
         }
 #pragma unroll

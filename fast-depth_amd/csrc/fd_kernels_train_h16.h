@@ -360,8 +360,10 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
         for (int i = 0; i < 2; ++i) {
             const long m = mbeg + (long)t * BR + lr + 32 * i;
             const bool ok = m < mend;
-            rdz[i] = (ok && n_ok) ? fd_ld8(DZ + m * N + ncol) : zero8;
-            rzi[i] = (ok && k_ok) ? fd_ld8(Zin + m * K + kcol) : zero8;
+            const long mq = ok ? m : mend - 1;                 // branch-free: clamped row / column, unconditional loads, select
+            const fd_u16x8 vdz = fd_ld8(DZ + mq * N + (n_ok ? ncol : 0)), vzi = fd_ld8(Zin + mq * K + (k_ok ? kcol : 0));
+            rdz[i] = (ok && n_ok) ? vdz : zero8;
+            rzi[i] = (ok && k_ok) ? vzi : zero8;
         }
     };
     auto stage = [&](int t) {
