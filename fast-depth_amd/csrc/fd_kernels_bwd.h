@@ -614,10 +614,12 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
             const int iy = p / TW, ix = p - iy * TW;
             const int gy = iy0 + iy, gx = ix0 + ix;
             if (!c_ok || gy >= Hin || gx >= Win) continue;
-            fd_f32x4 v = din_at(iy, ix);
             const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
-            if (ADD_SG) v += fd_ld4(SG + o);
-            const fd_f32x4 z = fd_ld4(Zin + o);
+            const fd_f32x4 z = fd_ld4(Zin + o);                 // requested before the tap loop: the latency hides behind the LDS work
+            fd_f32x4 sgv = fd_zero4();
+            if (ADD_SG) sgv = fd_ld4(SG + o);
+            fd_f32x4 v = din_at(iy, ix);
+            if (ADD_SG) v += sgv;
             v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
             fd_st4(Gin + o, v);
             ssum += v; ssx += v * ((z - mu) * is);
@@ -628,6 +630,8 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
             const int ly = p / TW2, lx = p - ly * TW2;
             const int gy = iy0 + 2 * ly, gx = ix0 + 2 * lx;     // top-left full-res position of the 2x2 block
             if (!c_ok || gy >= Hin || gx >= Win) continue;
+            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * Cp + (to_skip ? 0 : cg);
+            const fd_f32x4 z = fd_ld4(Zin + ol);                // requested before the tap loop (unused by the lanes that feed the skip tensor)
             fd_f32x4 d00, d01, d10, d11;
             if (S == 1) {
                 // the four positions of the block read a (K+1) x (K+1) window of the dz patch: walk it row by row, every row feeds
@@ -661,8 +665,6 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
                 if (to_skip) continue;
             }
             fd_f32x4 v = (d00 + d01) + (d10 + d11);
-            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * Cp + cg;
-            const fd_f32x4 z = fd_ld4(Zin + ol);
             v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
             fd_st4(Gin + ol, v);
             ssum += v; ssx += v * ((z - mu) * is);
