@@ -688,9 +688,9 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
 
 // ------------------------------------------------------------------------------------------------
 // Depthwise backward-weights: dW[c][ky][kx] = sum over (n, oy, ox) of dz[oy][ox][c] * in[oy*S-P+ky][ox*S-P+kx][c].
-// Same tiling and input staging as the forward kernel (the input a_in / up2 / +skip is re-created on load); each
-// work-item accumulates the K*K tap sums of its 4 channels over its output strips, the workgroup reduces them through
-// LDS and writes wpart[blk][K*K][C].
+// Same tiling and input staging as the forward kernel (the input a_in / up2 / +skip is re-created on load); dz of the tile's
+// outputs is staged next to it.  A work-item then owns ONE tap row of 4 channels and walks a share of the output strips; the
+// shares are summed through LDS once per workgroup, which writes wpart[blk][K*K][C].
 // ------------------------------------------------------------------------------------------------
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
 __global__ void __launch_bounds__(256)
@@ -705,7 +705,8 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
-    float *s_in = smem;
+    float *s_in = smem;                                    // [TH_in*TW_in][PSTR] activated input patch; reused for the final reduction
+    float *s_dz = smem + TH_in * TW_in * PSTR;             // [TH*TW][PSTR]       dz of the tile's outputs (0 outside the image)
     // a workgroup walks `tpw` horizontally adjacent tiles and keeps its tap sums in registers across them: one workgroup
     // reduction and one partial row per `tpw` tiles
     const int groups_x = (tiles_x + tpw - 1) / tpw;
@@ -719,9 +720,15 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     int tab_c = c_ok ? cg : 0;                             // channel offset of this work-item's table entries (re-read per tile, see FD_OPAQUE)
     const bool from_skip = MODE == 3 && cg >= csplit;      // MODE 3: cat(up2(a_in), a_skip), see fd_dwconv_train
     const int C1 = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = from_skip ? cg - csplit : cg;
-    fd_f32x4 acc[K * K];
+    // compute-phase mapping: work-item = (channel group c4, tap row ky, pixel group pg).  It owns only the K taps of row ky
+    // (K float4 accumulators instead of K*K: the 5x5 kernel needed 216+ VGPRs and a 25 x 3-step shuffle reduction per tile
+    // before) and walks the output strips pg, pg + ngroups, ... of every tile; the pixel groups meet once, through LDS, at the end.
+    const int ngroups = npt / K;
+    const int ky = pt % K, pg = pt / K;
+    const bool worker = pg < ngroups;
+    fd_f32x4 acc[K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = fd_zero4();
+    for (int t = 0; t < K; ++t) acc[t] = fd_zero4();
 #pragma unroll 1
     for (int ti = 0; ti < tpw; ++ti) {
     const int tx = tgx * tpw + ti;
@@ -731,7 +738,7 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     // the BN-backward operands (G, z) of this work-item's FIRST output strip are requested before the input patch is staged,
     // so that their latency overlaps the staging loads instead of following the barrier
     const int TWS = TW >> 2, nstrips = TH * TWS;
-    constexpr bool PREFETCH = K == 5;                      // 3x3: the extra live registers cost more (occupancy) than the overlap gains
+    constexpr bool PREFETCH = true;
     decltype(fd_ldraw4(G)) g0[4], z0[4];
     {
         const int oy = pt / TWS, ox = (pt - oy * TWS) * 4;
@@ -791,60 +798,52 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
             }
         }
     }
-    __syncthreads();
+    // dz of this work-item's output strip (pixel-thread pt stages strip pt: TH*TW/4 <= npt) -> s_dz
     FD_OPAQUE(tab_c);
-    const fd_f32x4 cA = fd_ld4(coef + FD_CF_A * C + tab_c), c1 = fd_ld4(coef + FD_CF_C1 * C + tab_c), cM = fd_ld4(coef + FD_CF_MU * C + tab_c), c2 = fd_ld4(coef + FD_CF_C2 * C + tab_c);
-    for (int s = pt; s < nstrips; s += npt) {
-        const int oy = s / TWS, ox = (s - oy * TWS) * 4;
-        const int gy = oy0 + oy;
-        fd_f32x4 dz[4];
+    {
+        const fd_f32x4 cA = fd_ld4(coef + FD_CF_A * C + tab_c), c1 = fd_ld4(coef + FD_CF_C1 * C + tab_c), cM = fd_ld4(coef + FD_CF_MU * C + tab_c), c2 = fd_ld4(coef + FD_CF_C2 * C + tab_c);
+        if (pt < nstrips) {
+            const int oy = pt / TWS, ox = (pt - oy * TWS) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gx = ox0 + ox + j;
-            dz[j] = fd_zero4();
-            if (c_ok && gy < Ho && gx < Wo) {
-                if (PREFETCH && s == pt) {
-                    dz[j] = fd_dz4(fd_cvt4(T{}, g0[j]), fd_cvt4(T{}, z0[j]), cA, c1, cM, c2);
-                } else {
-                    const long o = (((long)n * Ho + gy) * Wo + gx) * C + cg;
-                    dz[j] = fd_dz4(fd_ld4(G + o), fd_ld4(Z + o), cA, c1, cM, c2);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = c_ok && oy0 + oy < Ho && ox0 + ox + j < Wo;
+                const fd_f32x4 dz = fd_dz4(fd_cvt4(T{}, g0[j]), fd_cvt4(T{}, z0[j]), cA, c1, cM, c2);
+                fd_st4(s_dz + (oy * TW + ox + j) * PSTR + c4 * 4, ok ? dz : fd_zero4());
             }
         }
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
+    }
+    __syncthreads();
+    if (worker) {
+        for (int s = pg; s < nstrips; s += ngroups) {
+            const int oy = s / TWS, ox = (s - oy * TWS) * 4;
             const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
-            fd_f32x4 r[NIN];
+            const float *dzp = s_dz + (oy * TW + ox) * PSTR + c4 * 4;
+            fd_f32x4 r[NIN], dz[4];
 #pragma unroll
             for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
 #pragma unroll
+            for (int j = 0; j < 4; ++j) dz[j] = fd_ld4(dzp + j * PSTR);
+#pragma unroll
             for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ky * K + kx] += r[j * S + kx] * dz[j];
-            FD_SCHED_FENCE();                               // keep the next row's LDS reads from being hoisted above these FMAs (registers)
+                for (int j = 0; j < 4; ++j) acc[kx] += r[j * S + kx] * dz[j];
         }
     }
     }   // tile loop
-    // workgroup reduction over the pixel-threads (fixed order): lanes of a wave that share a channel group are combined with
-    // xor-shuffles (lane = c4 + lanes_c * pixel-thread), the waves' results meet in LDS
+    // the pixel groups' tap sums meet in LDS: red[pg][ky*K + kx][c4] (fixed order -> deterministic)
     __syncthreads();
-    float *red = smem;                                     // [K*K][4 waves][lanes_c] float4
-    const int wave = tid >> 6;
+    float *red = smem;
+    if (worker) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-        fd_f32x4 v = acc[t];
-        for (int m = lanes_c; m < 64; m <<= 1) {
-            v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); v.z += __shfl_xor(v.z, m); v.w += __shfl_xor(v.w, m);
-        }
-        if ((tid & 63) < lanes_c) fd_st4(red + ((t * 4 + wave) * lanes_c + c4) * 4, v);
+        for (int kx = 0; kx < K; ++kx) fd_st4(red + ((pg * K * K + ky * K + kx) * lanes_c + c4) * 4, acc[kx]);
     }
     __syncthreads();
     const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
     for (int i = tid; i < K * K * lanes_c; i += 256) {
         const int t = i >> cbq, cc = i & (lanes_c - 1);
         if (c0 + cc * 4 < C) {
-            const fd_f32x4 a = (fd_ld4(red + ((t * 4 + 0) * lanes_c + cc) * 4) + fd_ld4(red + ((t * 4 + 1) * lanes_c + cc) * 4)) +
-                               (fd_ld4(red + ((t * 4 + 2) * lanes_c + cc) * 4) + fd_ld4(red + ((t * 4 + 3) * lanes_c + cc) * 4));
+            fd_f32x4 a = fd_zero4();
+            for (int g = 0; g < ngroups; ++g) a += fd_ld4(red + ((g * K * K + t) * lanes_c + cc) * 4);
             fd_st4(wpart + (blk * K * K + t) * C + c0 + cc * 4, a);
         }
     }

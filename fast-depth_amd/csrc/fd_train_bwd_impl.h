@@ -71,10 +71,14 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const int groups_x = ceil_div(L.tiles_x, tpw);
     tpw = ceil_div(L.tiles_x, groups_x);
     const dim3 wgrid(groups_x * L.tiles_y, L.grid.y, L.grid.z);
+    // LDS: activated input patch + dz tile, both [pixels][cb + 4] floats; the final reduction (npt/K groups x K*K taps x cb) reuses it
+    const int cbw = 4 << L.cbq, th_in = (L.th - 1) * L.d.stride + L.d.ksize, tw_in = (L.tw - 1) * L.d.stride + L.d.ksize;
+    const size_t wlds = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
+    if (wlds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise wgrad: LDS request %zu exceeds 64 KiB", wlds);
     const int wblk = groups_x * L.tiles_y * c.p->B;
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
-        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), L.lds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
+        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
                   L.cbq, L.th, L.tw, L.tiles_x, tpw, L.csplit);                                                                    \
