@@ -50,10 +50,18 @@ __device__ __forceinline__ void fd_st8(void *p, fd_u16x8 v) { *reinterpret_cast<
 // Master weights W[N][K] (fp32, torch layout) -> wt[N][K64] and wtt[K][N64] in T, zero padded along the reduction index of
 // the GEMM that reads them (forward: k, backward-data: n).
 // ------------------------------------------------------------------------------------------------
+// One launch converts the weights of up to FD_PACK_MAX pointwise units (blockIdx.y = unit; the records travel as a kernel argument).
+#define FD_PACK_MAX 24
+template <typename T> struct fd_pack_rec { const float *w; T *wt; T *wtt; int N, K, K64, N64; };
+template <typename T> struct fd_pack_table { fd_pack_rec<T> rec[FD_PACK_MAX]; };
 template <typename T>
 __global__ void __launch_bounds__(256)
-fd_pack_train_w_h16(const float *__restrict__ w, T *__restrict__ wt, T *__restrict__ wtt, int N, int K, int K64, int N64)
+fd_pack_train_w_h16(const fd_pack_table<T> table)
 {
+    const fd_pack_rec<T> &R = table.rec[blockIdx.y];
+    const float *__restrict__ w = R.w;
+    T *__restrict__ wt = R.wt, *__restrict__ wtt = R.wtt;
+    const int N = R.N, K = R.K, K64 = R.K64, N64 = R.N64;
     const long a = (long)N * K64, total = a + (long)K * N64;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         if (i < a) {

@@ -122,6 +122,27 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
     float *part = tws(plan, plan->part_off);
     plan->eps = bn_eps;
     plan->x_saved = x_nchw;
+    if constexpr (!F32) {
+        // 16-bit operand copies (W as [N][K64], W^T as [K][N64]) of the live fp32 master weights of every pointwise unit, FD_PACK_MAX
+        // units per launch; read by this step's forward and backward
+        fd_pack_table<T> tab;
+        int cnt = 0;
+        auto flush = [&]() -> int {
+            if (!cnt) return FD_OK;
+            FD_LAUNCH((fd_pack_train_w_h16<T>), dim3(512, (unsigned)cnt), dim3(256), 0, s, tab);
+            cnt = 0;
+            return check_launch("fd_pack_train_w_h16");
+        };
+        for (int i = 0; i < n_layers; ++i) {
+            const TLayer &L = plan->layers[i];
+            if (L.d.op != FD_OP_PW || L.head) continue;
+            if (!params[i].conv_weight) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
+            tab.rec[cnt++] = fd_pack_rec<T>{params[i].conv_weight, twt<T>(plan, L.wt_off), twt<T>(plan, L.wtt_off), L.d.cout, L.d.cin, L.k64, L.n64};
+            if (cnt == FD_PACK_MAX) { int rc = flush(); if (rc) return rc; }
+        }
+        int rc = flush();
+        if (rc) return rc;
+    }
     for (int i = 0; i < n_layers; ++i) {
         const TLayer &L = plan->layers[i];
         const fd_layer_desc &d = L.d;
@@ -160,11 +181,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
                     else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
                     rc = check_launch("fd_pw_gemm_train_f32");
                 } else {
-                    // 16-bit operand copies of the live fp32 master weights (read again by this unit's backward)
-                    T *wt = twt<T>(plan, L.wt_off), *wtt = twt<T>(plan, L.wtt_off);
-                    const long tot = (long)d.cout * L.k64 + (long)d.cin * L.n64;
-                    FD_LAUNCH((fd_pack_train_w_h16<T>), dim3((unsigned)std::min<long>(1024, ceil_div(tot, 256))), dim3(256), 0, s, q.conv_weight, wt, wtt, d.cout, d.cin, L.k64, L.n64);
-                    if ((rc = check_launch("fd_pack_train_w_h16"))) return rc;
+                    T *wt = twt<T>(plan, L.wt_off);      // 16-bit operand copies of the master weights: made for all units at the start of the step
                     if (P->d.act == FD_ACT_RELU6) {
                         (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, FD_ACT_RELU6_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
                         FD_LAUNCH((fd_pw_gemm_train_h16<T, FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles);
