@@ -229,3 +229,16 @@ def test_large_batch_matches_small_batches_bitwise():
             small = torch.cat([m(x[i:i + 32]) for i in range(0, 160, 32)])
         assert torch.equal(big, small), dt
         assert bool(torch.isfinite(big).all())
+
+
+@pytest.mark.parametrize("b,h,w,pruned", [(1, 96, 160, False), (3, 192, 256, True), (5, 256, 224, False)])
+def test_other_input_shapes_layerwise(b, h, w, pruned):
+    """Ragged-shape edge cases (tile edges of the depthwise kernels, partial GEMM tiles, odd batch): non-square inputs, H and W any
+    multiples of 32, layer by layer against the C oracle."""
+    models = inputs.product_models()
+    torch.manual_seed(50 + b)
+    m = harness.randomize_bn(models.MobileNetSkipAdd((h, w), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None), 51 + b)
+    x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(52 + b))
+    err, per_layer, info = harness.compare_with_oracle("hip", m, x, torch.device("cuda"))
+    bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
+    assert not bad and err < TOL, bad

@@ -193,3 +193,18 @@ def test_train_step_is_bit_reproducible_at_batch32(dtype):
     assert bool(torch.isfinite(out[0][1]).all()) and float(out[0][1].abs().max()) > 0
     for k in out[0][2]:
         assert torch.equal(out[0][2][k], out[1][2][k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_train_step_layer_local_other_shape(dtype):
+    """Non-square input, odd batch (3 x 160 x 96), pruned widths: tile-edge paths of the train forward / backward kernels."""
+    from test_emu_train import assert_local_parity
+    models = inputs.product_models()
+    torch.manual_seed(61)
+    m = models.MobileNetSkipAdd((160, 96), pretrained=False, channels=models.PRUNED_CHANNELS)
+    m.decode_conv6[1].bias.data.fill_(2.8)
+    g = torch.Generator().manual_seed(62)
+    x = torch.rand(3, 3, 160, 96, generator=g)
+    tgt = 0.7 + 9 * torch.rand(3, 1, 160, 96, generator=g)
+    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
+    assert_local_parity(rep, dtype)
