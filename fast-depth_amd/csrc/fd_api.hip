@@ -148,13 +148,13 @@ PwCfg choose_pw(long M, int N)
     if (N <= 32) return c128x32;
     auto blocks = [&](const PwCfg &c) { return (long)ceil_div(M, c.wgm * c.tm * 32) * ceil_div(N, c.wgn * c.tn * 32); };
     auto waste = [&](const PwCfg &c) { int bn = c.wgn * c.tn * 32; return (double)(ceil_div(N, bn) * bn) / N; };
-    // Measured on MI355X (scratch/gemm, round 1): with the fp32 MFMA at 64 cycles per instruction the 64x64 tile
+    // Measured on MI355X (tools/microbench/gemm_tiles.hip, round 1): with the fp32 MFMA at 64 cycles per instruction the 64x64 tile
     // (one 32x32 accumulator per wave, 4+ workgroups per CU) beats the larger tiles on every shape of this
     // network -- latency hiding across workgroups matters more than operand reuse.
     // Exception (same measurements): the 14x14 layers (M = 6272 at batch 32, N, K >= 256) run 13 % faster on 128x64 --
     // both shapes are bound by the same wave quantisation (3.06 32x32 tiles per SIMD), the larger tile halves the
     // L2 -> LDS bytes per flop.
-    // Re-measured with the final kernel (scratch/gemm sweep over all 18 shapes of the network, batch 32): 6272x512x{256,512}
+    // Re-measured with the final kernel (tools/microbench/gemm_tiles.hip sweep over all 18 shapes of the network, batch 32): 6272x512x{256,512}
     // run fastest on 64x128 (37.9 us vs 39.6 on 128x64 vs 42.5 on 64x64), 25088x128x256 on 128x64 (23.2 vs 25.7); everything
     // else on 64x64.
     (void)blocks; (void)waste; (void)c128x128;
