@@ -609,7 +609,49 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
         }
         return acc;
     };
-    if (MODE == 0) {
+    if (MODE == 0 && S == 1) {
+        // stride 1: din = correlation of the dz patch with the FLIPPED taps -- same strip scheme as the forward kernel: 4 adjacent
+        // positions share K + 3 patch vectors per tap row (13 LDS reads per 20 FMAs instead of 40)
+        const int TWS = TW >> 2;
+        for (int st = pt; st < TH * TWS; st += npt) {
+            const int iy = st / TWS, ix = (st - iy * TWS) * 4;
+            const int gy = iy0 + iy;
+            if (!c_ok || gy >= Hin) continue;
+            fd_f32x4 z[4], sgv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                      // requested before the tap loop; clamped column, validity re-checked at the store
+                const int gx = ix0 + ix + j, qx = gx < Win ? gx : Win - 1;
+                const long o = (((long)n * Hin + gy) * Win + qx) * C + cg;
+                z[j] = fd_ld4(Zin + o);
+                sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
+            }
+            fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
+#pragma unroll 1
+            for (int a = 0; a < K; ++a) {
+                const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
+                fd_f32x4 r[K + 3];
+#pragma unroll
+                for (int i = 0; i < K + 3; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+                for (int b = 0; b < K; ++b) {
+                    const fd_f32x4 wv = fd_ld4(s_w + ((K - 1 - a) * K + (K - 1 - b)) * CB + c4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += r[j + b] * wv;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = ix0 + ix + j;
+                if (gx >= Win) continue;
+                const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
+                fd_f32x4 v = acc[j];
+                if (ADD_SG) v += sgv[j];
+                v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z[j] * sc + sh));
+                fd_st4(Gin + o, v);
+                ssum += v; ssx += v * ((z[j] - mu) * is);
+            }
+        }
+    } else if (MODE == 0) {
         for (int p = pt; p < TH * TW; p += npt) {
             const int iy = p / TW, ix = p - iy * TW;
             const int gy = iy0 + iy, gx = ix0 + ix;
