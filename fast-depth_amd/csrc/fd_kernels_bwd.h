@@ -44,44 +44,17 @@ __device__ __forceinline__ fd_f32x4 fd_actmask4(fd_f32x4 y)
     return r;
 }
 
-// ---- generic deterministic partial reduction: out[j] = sum_b part[b*stride + j], j < n  (grid (ceil(n/64), slices), see
-// fd_two_level_tail) ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-fd_reduce_partials_f32(const float *__restrict__ part, int nblk, int rps, long stride, int n, float *__restrict__ out,
-                       double *__restrict__ slices, int *__restrict__ counters)
+// ---- deterministic partial reductions of the backward pass (bodies shared by the single kernels and by
+// fd_bwd_reduce_pair_f32; (bx, by, ny) = column block, slice, slice count: see fd_two_level_tail) -------------------------------
+// weights:  out[j] = sum_b part[b*n + j]  (KK == 0), or the depthwise form  out[c*KK + t] = sum_b part[(b*KK + t)*C + c]
+// (tap-major partials -> torch's [C][1][k][k]) with n = KK*C
+__device__ __forceinline__ void fd_reduce_partials_dev(const float *__restrict__ part, int nblk, int rps, int n, int KK, int C, float *__restrict__ out,
+                                                       double *__restrict__ slices, int *__restrict__ counters, double (*sh)[64][2], int *s_last,
+                                                       int bx, int by, int ny)
 {
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rps;
-    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
-    double s = 0.0, unused = 0.0;
-    if (j < n)
-#pragma unroll 4
-        for (int b = r0 + wave; b < r1; b += 16) s += (double)part[(long)b * stride + j];
-    sh[wave][lane][0] = s;
-    __syncthreads();
-    if (wave == 0) {
-        s = 0.0;
-        for (int w = 0; w < 16; ++w) s += sh[w][lane][0];
-    }
-    __syncthreads();
-    if (!fd_two_level_tail(s, unused, false, j < n, j, 2 * n, slices, counters, &s_last, sh)) return;
-    if (wave == 0 && j < n) out[j] = (float)s;
-}
-
-// out[c*KK + t] = sum_b part[(b*KK + t)*C + c]   (depthwise weight gradient: tap-major partials -> torch's [C][1][k][k])
-__global__ void __launch_bounds__(1024)
-fd_reduce_partials_tapmajor_f32(const float *__restrict__ part, int nblk, int rps, int KK, int C, float *__restrict__ out,
-                                double *__restrict__ slices, int *__restrict__ counters)
-{
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + lane;                      // j = t*C + c
-    const int n = KK * C;
-    const int r0 = blockIdx.y * rps;
+    const int j = bx * 64 + lane;
+    const int r0 = by * rps;
     int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
     double s = 0.0, unused = 0.0;
     if (j < n)
@@ -94,24 +67,22 @@ fd_reduce_partials_tapmajor_f32(const float *__restrict__ part, int nblk, int rp
         for (int w = 0; w < 16; ++w) s += sh[w][lane][0];
     }
     __syncthreads();
-    if (!fd_two_level_tail(s, unused, false, j < n, j, 2 * n, slices, counters, &s_last, sh)) return;
+    if (!fd_two_level_tail(s, unused, false, j < n, j, 2 * n, slices, counters, s_last, sh, bx, by, ny)) return;
     if (wave == 0 && j < n) {
-        const int t = j / C, c = j - t * C;
-        out[(long)c * KK + t] = (float)s;
+        if (KK == 0) { out[j] = (float)s; }
+        else { const int t = j / C, c = j - t * C; out[(long)c * KK + t] = (float)s; }
     }
 }
 
-// ---- BatchNorm backward finalize -----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
-                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
-                       double *__restrict__ slices, int *__restrict__ counters)
+// BatchNorm backward finalize: partial sums of (G, G*xhat) -> dbeta, dgamma and the coefficient table of dz
+__device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
+                                                       double *__restrict__ slices, int *__restrict__ counters, double (*sh)[64][2], int *s_last,
+                                                       int bx, int by, int ny)
 {
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rps;
+    const int c = bx * 64 + lane;
+    const int r0 = by * rps;
     int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
     double s = 0.0, q = 0.0;
     if (c < C)
@@ -124,7 +95,7 @@ fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C,
         for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
     }
     __syncthreads();
-    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, &s_last, sh)) return;
+    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, s_last, sh, bx, by, ny)) return;
     if (wave == 0 && c < C) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
@@ -133,6 +104,45 @@ fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C,
         coef[FD_CF_C1 * C + c] = (float)(s / n);
         coef[FD_CF_MU * C + c] = (float)mean;
         coef[FD_CF_C2 * C + c] = (float)(invstd * q / n);
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+fd_reduce_partials_f32(const float *__restrict__ part, int nblk, int rps, int n, int KK, int C, float *__restrict__ out,
+                       double *__restrict__ slices, int *__restrict__ counters)
+{
+    __shared__ double sh[16][64][2];
+    __shared__ int s_last;
+    fd_reduce_partials_dev(part, nblk, rps, n, KK, C, out, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+__global__ void __launch_bounds__(1024)
+fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
+                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
+                       double *__restrict__ slices, int *__restrict__ counters)
+{
+    __shared__ double sh[16][64][2];
+    __shared__ int s_last;
+    fd_bn_bwd_finalize_dev(part, nblk, rps, C, n, st, dgamma, dbeta, coef, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// One launch for the two reductions that close a unit's backward: its weight-gradient partials (column blocks [0, nbx_w)) and
+// the BatchNorm-backward partials its backward-data kernel produced for the producer (column blocks [nbx_w, gridDim.x)).
+// gridDim.y = max of the two slice counts; the counters / slice areas of the second part start at cnt_off / slice_off.
+struct fd_wred_args { const float *part; int nblk, rps, n, KK, C; float *out; int ny; };
+struct fd_bred_args { const float *part; int nblk, rps, C; double n; const float *st; float *dgamma, *dbeta, *coef; int ny; };
+__global__ void __launch_bounds__(1024)
+fd_bwd_reduce_pair_f32(const fd_wred_args W, const fd_bred_args Bn, int nbx_w, double *__restrict__ slices, long slice_off, int *__restrict__ counters)
+{
+    __shared__ double sh[16][64][2];
+    __shared__ int s_last;
+    if ((int)blockIdx.x < nbx_w) {
+        if ((int)blockIdx.y >= W.ny) return;
+        fd_reduce_partials_dev(W.part, W.nblk, W.rps, W.n, W.KK, W.C, W.out, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, W.ny);
+    } else {
+        if ((int)blockIdx.y >= Bn.ny) return;
+        fd_bn_bwd_finalize_dev(Bn.part, Bn.nblk, Bn.rps, Bn.C, Bn.n, Bn.st, Bn.dgamma, Bn.dbeta, Bn.coef, slices + slice_off, counters + nbx_w, sh, &s_last,
+                               blockIdx.x - nbx_w, blockIdx.y, Bn.ny);
     }
 }
 

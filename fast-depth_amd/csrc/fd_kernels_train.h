@@ -392,22 +392,22 @@ fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const fl
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool fd_two_level_tail(double &s, double &q, bool has_q, bool col_ok, int col, int width2,
                                                   double *__restrict__ slices, int *__restrict__ counters, int *s_last,
-                                                  double (*sh)[64][2])
+                                                  double (*sh)[64][2], int bx, int by, int ny)
 {
-    // called by all 1024 work-items after wave 0 holds the slice sums (s, q) of its lanes' columns
-    const int ny = gridDim.y;
+    // called by all 1024 work-items after wave 0 holds the slice sums (s, q) of its lanes' columns; (bx, by) of ny slices: normally
+    // blockIdx / gridDim.y, explicit so that one launch can run two reductions side by side (fd_bwd_reduce_pair_f32)
     if (ny == 1) return true;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0 && col_ok) {
-        fd_store_dev(slices + (long)blockIdx.y * width2 + col, s);
-        if (has_q) fd_store_dev(slices + (long)blockIdx.y * width2 + (width2 >> 1) + col, q);
+        fd_store_dev(slices + (long)by * width2 + col, s);
+        if (has_q) fd_store_dev(slices + (long)by * width2 + (width2 >> 1) + col, q);
     }
     fd_release_wg();
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int old = fd_atomic_inc(counters + blockIdx.x);
+        const int old = fd_atomic_inc(counters + bx);
         *s_last = old == ny - 1;
-        if (*s_last) fd_store_dev(counters + blockIdx.x, 0);
+        if (*s_last) fd_store_dev(counters + bx, 0);
     }
     __syncthreads();
     if (!*s_last) return false;
@@ -462,7 +462,7 @@ fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, dou
         for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
     }
     __syncthreads();
-    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, &s_last, sh)) return;
+    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, &s_last, sh, blockIdx.x, blockIdx.y, gridDim.y)) return;
     if (wave == 0 && c < C) {
         const double mean = s / n;
         double var = q / n - mean * mean;

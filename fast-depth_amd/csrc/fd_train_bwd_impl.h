@@ -8,7 +8,25 @@ struct BwdCtx {
     const fd_layer_params *params;
     const fd_layer_grads *grads;
     hipStream_t s;
+    // weight-gradient partials of the unit being processed, waiting to be reduced together with the BatchNorm-backward partials
+    // its backward-data kernel produces (one launch: fd_bwd_reduce_pair_f32)
+    bool w_pending = false;
+    fd_wred_args w{};
 };
+
+// the generic single reduction (stem, head: units without a backward-data partner)
+int reduce_weights_now(BwdCtx &c, const float *part, int nrows, int n, int KK, int C, float *out)
+{
+    const RedGeom rg = red_geom(nrows, n);
+    FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, c.s, part, nrows, rg.rps, n, KK, C, out, red_slices(c.p), red_counters(c.p));
+    return check_launch("fd_reduce_partials_f32");
+}
+void defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C, float *out)
+{
+    const RedGeom rg = red_geom(nrows, n);
+    c.w = fd_wred_args{part, nrows, rg.rps, n, KK, C, out, (int)rg.grid.y};
+    c.w_pending = true;
+}
 
 inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size_t)ph * pw * (cb + 4), (size_t)2048) + (size_t)k * k * cb) * 4; }
 
@@ -16,6 +34,16 @@ int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
     TLayer &L = c.p->layers[i];
     const RedGeom rg = red_geom(nblk, L.d.cout);
+    if (c.w_pending) {
+        c.w_pending = false;
+        const int nbx_w = ceil_div(c.w.n, 64);
+        const fd_bred_args b{tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias,
+                             tws(c.p, L.coef_off), (int)rg.grid.y};
+        const long slice_off = (long)c.w.ny * 2 * c.w.n;       // doubles used by the weight part's slices
+        FD_LAUNCH(fd_bwd_reduce_pair_f32, dim3((unsigned)(nbx_w + rg.grid.x), (unsigned)std::max(c.w.ny, (int)rg.grid.y)), dim3(1024), 0, c.s, c.w, b, nbx_w,
+                  red_slices(c.p), slice_off, red_counters(c.p));
+        return check_launch("fd_bwd_reduce_pair_f32");
+    }
     FD_LAUNCH(fd_bn_bwd_finalize_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat,
               tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off), red_slices(c.p), red_counters(c.p));
     return check_launch("fd_bn_bwd_finalize_f32");
@@ -91,9 +119,8 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     int rc = check_launch("fd_dw_wgrad");
     if (rc) return rc;
     const int kk = L.d.ksize * L.d.ksize;
-    const RedGeom rg = red_geom(wblk, (long)kk * L.d.cin);
-    FD_LAUNCH(fd_reduce_partials_tapmajor_f32, rg.grid, dim3(1024), 0, c.s, wpart, wblk, rg.rps, kk, L.d.cin, c.grads[i].conv_weight, red_slices(c.p), red_counters(c.p));
-    return check_launch("fd_reduce_partials_tapmajor_f32");
+    defer_weights(c, wpart, wblk, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);     // reduced with the BN partials of the backward-data kernel
+    return FD_OK;
 }
 
 template <typename T>
@@ -132,9 +159,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.s, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
-        const RedGeom rg = red_geom(splits, (long)N * K);
-        FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->wpart_off), splits, rg.rps, (long)N * K, N * K, c.grads[i].conv_weight, red_slices(c.p), red_counters(c.p));
-        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+        defer_weights(c, tws(c.p, c.p->wpart_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
     }
     {
         const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
@@ -176,9 +201,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         int rc = check_launch("fd_pw_wgrad_f32");
         if (rc) return rc;
-        const RedGeom rg = red_geom(splits, (long)N * K);
-        FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->wpart_off), splits, rg.rps, (long)N * K, N * K, c.grads[i].conv_weight, red_slices(c.p), red_counters(c.p));
-        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+        defer_weights(c, tws(c.p, c.p->wpart_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
     }
     // --- data: G_src[M][K]
     {
@@ -228,8 +251,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
         if ((rc = check_launch("fd_head_bwd"))) return rc;
         {
-            const RedGeom rg = red_geom(nb2, Hd.d.cin);
-            FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, s, wpart, nb2, rg.rps, (long)Hd.d.cin, Hd.d.cin, grads[hi].conv_weight, red_slices(plan), red_counters(plan));
+            if ((rc = reduce_weights_now(c, wpart, nb2, Hd.d.cin, 0, 0, grads[hi].conv_weight))) return rc;
         }
         if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
         // the BN partials of the head's producer are now in `part` (nb2 workgroups)
@@ -247,8 +269,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), (size_t)(256 * 33 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout, L.nblk);
             if ((rc = check_launch("fd_stem_wgrad"))) return rc;
             {
-                const RedGeom rg = red_geom(nb_w, 27 * d.cout);
-                FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, s, wpart, nb_w, rg.rps, (long)27 * d.cout, 27 * d.cout, grads[i].conv_weight, red_slices(plan), red_counters(plan));
+                if ((rc = reduce_weights_now(c, wpart, nb_w, 27 * d.cout, 0, 0, grads[i].conv_weight))) return rc;
             }
             if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
             break;

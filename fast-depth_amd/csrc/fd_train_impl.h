@@ -353,8 +353,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
     p->wpart_off = off; p->wpart_bytes = align_up(std::max(max_wpart, (size_t)1) * 4, 256); off += p->wpart_bytes;
     // slice sums (double) of the fused two-level reductions: ceil(rows / 64) x 2 x width, bounded through rows x width <= the partial buffers
-    p->part2_off = off; p->part2_bytes = align_up((std::max(2 * max_part, max_wpart) / 16 + 4 * std::max(max_width, (size_t)1) + 64) * 8, 256); off += p->part2_bytes;
-    p->cnt_off = off; p->cnt_bytes = align_up((ceil_div((long)std::max(max_width, (size_t)1), 64) + 1) * 4, 256); off += p->cnt_bytes;   // arrival counters, one per 64 columns
+    p->part2_off = off; p->part2_bytes = align_up((2 * max_part / 16 + max_wpart / 16 + 8 * std::max(max_width, (size_t)1) + 128) * 8, 256); off += p->part2_bytes;   // two reductions can share a launch
+    p->cnt_off = off; p->cnt_bytes = align_up((2 * ceil_div((long)std::max(max_width, (size_t)1), 64) + 2) * 4, 256); off += p->cnt_bytes;   // arrival counters, one per 64 columns
     p->ws_bytes = off;
     *out_plan = p;
     return FD_OK;
