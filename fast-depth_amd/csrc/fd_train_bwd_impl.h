@@ -12,7 +12,22 @@ struct BwdCtx {
     // its backward-data kernel produces (one launch: fd_bwd_reduce_pair_f32)
     bool w_pending = false;
     fd_wred_args w{};
+    hipStream_t ws = nullptr;        // stream of the weight-gradient kernels (the plan's side stream, or s when concurrency is off)
 };
+
+// fork: the side stream continues from the caller's stream; join: the caller's stream waits for the side stream
+int fork_side(BwdCtx &c)
+{
+    if (c.ws == c.s) return FD_OK;
+    if (hipEventRecord(c.p->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.ws, c.p->ev_fork, 0) != hipSuccess) return fail(FD_ERR_HIP, "stream fork failed");
+    return FD_OK;
+}
+int join_side(BwdCtx &c)
+{
+    if (c.ws == c.s) return FD_OK;
+    if (hipEventRecord(c.p->ev_join, c.ws) != hipSuccess || hipStreamWaitEvent(c.s, c.p->ev_join, 0) != hipSuccess) return fail(FD_ERR_HIP, "stream join failed");
+    return FD_OK;
+}
 
 // the generic single reduction (stem, head: units without a backward-data partner)
 int reduce_weights_now(BwdCtx &c, const float *part, int nrows, int n, int KK, int C, float *out)
@@ -36,6 +51,8 @@ int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
     const RedGeom rg = red_geom(nblk, L.d.cout);
     if (c.w_pending) {
         c.w_pending = false;
+        int jrc = join_side(c);                               // the weight-gradient kernel ran on the side stream
+        if (jrc) return jrc;
         const int nbx_w = ceil_div(c.w.n, 64);
         const fd_bred_args b{tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias,
                              tws(c.p, L.coef_off), (int)rg.grid.y};
@@ -104,9 +121,10 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const size_t wlds = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
     if (wlds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise wgrad: LDS request %zu exceeds 64 KiB", wlds);
     const int wblk = groups_x * L.tiles_y * c.p->B;
+    { int frc = fork_side(c); if (frc) return frc; }
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
-        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
+        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.ws, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
                   L.cbq, L.th, L.tw, L.tiles_x, tpw, L.csplit);                                                                    \
@@ -156,7 +174,8 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         splits = ceil_div(M, rows);
         const size_t need = (size_t)splits * N * K * 4;
         if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
-        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.s, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+        if ((rc = fork_side(c))) return rc;
+        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
         defer_weights(c, tws(c.p, c.p->wpart_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
@@ -197,7 +216,8 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
         const size_t lds = (size_t)FD_BWD_STAGES * 3 * 32 * 64 * 4;
         (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds, c.s, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
+        { int frc = fork_side(c); if (frc) return frc; }
+        FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds, c.ws, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
         int rc = check_launch("fd_pw_wgrad_f32");
         if (rc) return rc;
@@ -230,6 +250,15 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
 {
     constexpr bool F32 = std::is_same<T, float>::value;
     BwdCtx c{plan, params, grads, static_cast<hipStream_t>(stream)};
+    c.ws = c.s;
+    if (plan->concurrent_wgrad) {
+        if (!plan->side) {
+            if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess)
+                return fail(FD_ERR_HIP, "could not create the side stream of the backward pass");
+        }
+        c.ws = plan->side;
+    }
     hipStream_t s = c.s;
     float *part = tws(plan, plan->part_off), *wpart = tws(plan, plan->wpart_off);
     int rc;
