@@ -6,6 +6,7 @@
 // fixed grids, tile shapes and buffer addresses, so a forward is ~38 back-to-back launches on the
 // caller's stream with no host-side decisions, allocations or synchronisation in between.
 #include "fd_kernels_f32.h"
+#include "fd_kernels_gemm16_f32.h"
 #include "fd_kernels_sk_f32.h"
 #include "fd_kernels_h16.h"
 #include "fd_kernels_fused_f32.h"
@@ -81,6 +82,7 @@ struct Layer {
     // pw
     PwCfg pw{};
     int m_tiles = 0, n_tiles = 0, w_pitch = 0;
+    int pw16_tm = 0, pw16_stride = 0;   // > 0: fd_pw_gemm16_f32 (16x16x4 MFMA, one workgroup per CU) with TM row tiles and this M stride per workgroup
     bool sk = false;             // data-parallel rounds + stream-K remainder (fd_pw_gemm_sk_f32)
     int sk_dp_rounds = 0, sk_base = 0, sk_rem = 0;
     size_t lds = 0;
@@ -163,6 +165,34 @@ PwCfg choose_pw(long M, int N)
     return c64x64;
 }
 
+// Second-generation kernel (fd_kernels_gemm16_f32.h): worth it when ONE round of workgroups (one per CU) covers the layer with few
+// idle tile slots -- then its 16x16 quantum removes the 3.06 -> 4 rounding of the 32x32 kernel.  Measured at batch 32
+// (tools/microbench/gemm16.hip, profiles/r02): 6272x512x512 34.2 vs 38.1 us, 1568x1024x1024 40.1 vs 45.1, 6272x256x512 22.0 vs 23.2,
+// 25088x128x256 23.0 vs 24.2; layers that need two rounds (25088x256x256) or have K < 256 gain nothing and keep the first kernel.
+struct Pw16Cfg { int tm = 0, stride = 0; double score = 0; };
+Pw16Cfg choose_pw16(long M, int N, int K, bool force)
+{
+    Pw16Cfg best;
+    if (N % 4 || M <= 0) return best;
+    if (force) {                                             // test mode: the largest row-tile count the layer can fill, balanced strides
+        best.tm = M > 112 ? 13 : (M > 64 ? 7 : 4);
+        const long mt = (M + 16 * best.tm - 1) / (16 * best.tm);
+        best.stride = (int)((M + mt - 1) / mt); best.score = 1.0;
+        return best;
+    }
+    const int nt = ceil_div(N, 64);
+    for (int tm : {13, 7, 4}) {
+        const long mtiles = std::max<long>(1, 256 / nt);      // the most M tiles one round can hold
+        long stride = (M + mtiles - 1) / mtiles;
+        if (stride > 16 * tm) continue;                      // would need a second round
+        const long wgs = ((M + stride - 1) / stride) * nt;
+        const double score = std::min(1.0, wgs / 256.0) * ((double)stride / (16 * tm));      // fraction of the chip's MFMA slots doing useful work
+        if (score > best.score) { best.tm = tm; best.stride = (int)stride; best.score = score; }
+    }
+    if (best.score < 0.72 || K < 256) best = Pw16Cfg();
+    return best;
+}
+
 int pw_lds_bytes(const PwCfg &c) { return 3 * (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 32 * 4; }   // 3-stage ring of 128-byte rows
 
 int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
@@ -222,6 +252,20 @@ template <int ACT>
 int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *wp, const float *bias, float *out, long M, hipStream_t s)
 {
     const int N = L.d.cout, K = L.d.cin;
+    if (L.pw16_tm) {
+#define FD_PW16_CASE(TMV) \
+    case TMV: \
+        (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, 3, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        FD_LAUNCH((fd_pw_gemm16_f32<TMV, 3, ACT>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles); break;
+        switch (L.pw16_tm) {
+            FD_PW16_CASE(13)
+            FD_PW16_CASE(7)
+            FD_PW16_CASE(4)
+        default: return fail(FD_ERR_INVALID, "no gemm16 instance for TM=%d", L.pw16_tm);
+        }
+#undef FD_PW16_CASE
+        return check_launch("fd_pw_gemm16_f32");
+    }
     const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
     if (L.sk) {
         float *scratch = reinterpret_cast<float *>(plan->ws + plan->sk_scratch_off);
@@ -447,9 +491,18 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
                 L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));   // 1-D, XCD-aware mapping inside the kernel
+                if (dtype == FD_F32 && !(flags & FD_PLAN_NO_GEMM16)) {
+                    const Pw16Cfg c16 = choose_pw16(M, d.cout, d.cin, (flags & FD_PLAN_FORCE_GEMM16) != 0);
+                    if (c16.tm) {
+                        L.pw16_tm = c16.tm; L.pw16_stride = c16.stride;
+                        L.lds = (size_t)3 * (c16.tm * 16 + 64) * 32 * 4;
+                        L.m_tiles = ceil_div(M, c16.stride); L.n_tiles = ceil_div(d.cout, 64);
+                        L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
+                    }
+                }
                 // EXPERIMENTAL, opt-in (FD_PLAN_STREAMK): measured on MI355X at batch 32 the balanced decomposition takes exactly as long as
                 // the plain launch (conv7.3: 40.2 vs 40.0 us, conv13.3: 40.3 vs 39.9 us) -- see fd_kernels_sk_f32.h
-                if (dtype == FD_F32 && (flags & FD_PLAN_STREAMK) && L.pw.wgm == 2 && L.pw.wgn == 2 && L.pw.tn == 1) {
+                if (dtype == FD_F32 && (flags & FD_PLAN_STREAMK) && !L.pw16_tm && L.pw.wgm == 2 && L.pw.wgn == 2 && L.pw.tn == 1) {
                     // resident capacity: 256 CUs x (160 KiB LDS / ring size); one workgroup per slot
                     const int per_cu = std::min(4, (int)(160 * 1024 / (L.lds + 256)));
                     const int P = 256 * per_cu;
@@ -568,6 +621,9 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 snprintf(buf, sizeof buf, "pw_gemm_sk<%dx%d> M=%ld N=%d K=%d tiles=%dx%d on %u workgroups: %d full round(s) + stream-K %d.%03d K-tiles each, lds=%zu",
                          L.pw.wgm * L.pw.tm * 32, L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.grid.x,
                          L.sk_dp_rounds, L.sk_base, (int)(1000L * L.sk_rem / L.grid.x), L.lds);
+            else if (L.pw16_tm)
+                snprintf(buf, sizeof buf, "pw_gemm16<TM=%d: %dx64 tile, stride %d> M=%ld N=%d K=%d tiles=%dx%d (%.2f per CU) lds=%zu", L.pw16_tm, L.pw16_tm * 16, L.pw16_stride,
+                         (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.m_tiles * L.n_tiles / 256.0, L.lds);
             else
             snprintf(buf, sizeof buf, "pw_gemm<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
                      L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
@@ -579,6 +635,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
+        else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0>", L.pw16_tm, d.act);
         else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_%sf32<%d, %d, %d, %d, %d>", L.sk ? "sk_" : "", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);
         L.sym = buf;

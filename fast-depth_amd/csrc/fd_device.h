@@ -18,6 +18,7 @@
 inline void fd_glds16(const float *g, float *lds_wave_base) { memcpy((char *)lds_wave_base + hipemu::lane_id() * 16, g, 16); }
 template <int N> inline void fd_wait_vmcnt() {}
 #define FD_SCHED_FENCE() ((void)0)
+#define FD_UNIFORM(x) (x)
 #define FD_OPAQUE(x) ((void)0)
 inline void fd_block_barrier_lds() { __syncthreads(); }
 inline void fd_block_barrier() { __syncthreads(); }
@@ -31,6 +32,8 @@ __device__ __forceinline__ void fd_glds16(const float *g, float *lds_wave_base)
 template <int N> __device__ __forceinline__ void fd_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // keeps the compiler's scheduler from moving instructions across this point (source order = issue order)
 #define FD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// tells the compiler that the (wave-uniform) integer x lives in a scalar register: address arithmetic derived from it stays on the SALU
+#define FD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // makes the compiler forget what it knows about the integer x: loads addressed through it are not hoisted out of the enclosing loop
 // (used to keep per-channel tables out of registers while they are not needed)
 #define FD_OPAQUE(x) asm volatile("" : "+v"(x))
@@ -141,8 +144,11 @@ __device__ __forceinline__ fd_f32x4 fd_zero4() { fd_f32x4 z = {0.f, 0.f, 0.f, 0.
 // with each other inside a kernel; an agent-scope FENCE would make them so by writing back / invalidating the whole L2
 // (buffer_wbl2 / buffer_inv: measured +100 us per launch here, the L2 is full of freshly written activations).  Instead every
 // access to the scratch slots and counters is itself agent-scope (sc1: performed at the device coherence point, bypassing the
-// non-coherent L2 lines), and the only ordering needed -- partial stores complete before the counter moves -- is a
-// workgroup-scope release (s_waitcnt vmcnt(0), no cache maintenance) followed by the workgroup barrier.
+// non-coherent L2 lines), and the only ordering needed -- partial stores complete before the counter moves -- is an explicit
+// s_waitcnt vmcnt(0) (no cache maintenance) followed by the workgroup barrier: the "sc1 payload -> drained vmcnt -> sc1 flag" hand-off
+// of MI355X_MICROARCH.md (a workgroup-scope release FENCE is not enough: outside tgsplit mode it does not wait for vmcnt, so the
+// counter could overtake the slice stores; inline asm because the compiler drops a fence's wait when it believes the scoreboard empty).
+// The reader needs no acquire: its loads are sc1 as well (served by the coherence point, never by its L1 / a stale L2 line).
 #ifdef FD_EMU
 inline int fd_atomic_inc(int *p) { int o = *p; *p = o + 1; return o; }
 inline void fd_store_dev(float *p, float v) { *p = v; }
@@ -159,6 +165,6 @@ __device__ __forceinline__ float fd_load_dev(const float *p) { return __hip_atom
 __device__ __forceinline__ void fd_store_dev(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fd_store_dev(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double fd_load_dev(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void fd_release_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void fd_acquire_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+__device__ __forceinline__ void fd_release_wg() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }          // this wave's sc1 stores have been performed
+__device__ __forceinline__ void fd_acquire_wg() { asm volatile("" ::: "memory"); }                            // compiler ordering only: the loads that follow are sc1
 #endif

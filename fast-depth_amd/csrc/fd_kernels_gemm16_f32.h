@@ -1,0 +1,211 @@
+// fd_kernels_gemm16_f32.h -- second-generation fp32 pointwise GEMM for gfx950: v_mfma_f32_16x16x4_f32, one workgroup per CU,
+// the K tile split between the two waves of a SIMD.
+//
+//   out[M][N] = act(A[M][K] * Wt[N][K32]^T + bias[N])          (pointwise 1x1 conv + folded BN + ReLU/ReLU6;
+//                                                                reference imagenet/mobilenet.py:35-37, models.py:70-75)
+//
+// Why a second kernel (measurements: DESIGN.md section 3): the 32x32x2 kernel of fd_kernels_f32.h quantises the work into 32x32
+// tiles per SIMD -- at batch 32 every pointwise layer has 3.06 of them per SIMD, so a quarter of the machine idles in the last
+// round -- and every one of its (3 per CU) workgroups pays prologue and epilogue at the same moment.  Here
+//   * the MFMA is 16x16x4 (32-cycle issue, 40-cycle dependent latency, 4 accumulator registers): the quantum is a 16x16 tile;
+//   * a workgroup owns  m_stride x 64  outputs, m_stride <= 16*TM chosen by the host so that the grid is (a multiple of) the
+//     256 CUs: M = 6272 -> m_stride 196 (TM = 13, 49 of 52 tile slots useful = 94 %) instead of 3.06 -> 4 rounds (76 %);
+//   * 8 waves: wave (kh, wn) owns the 16-column block wn of all TM row tiles for the k-half kh of every 32-deep K tile.  The two
+//     waves that share a SIMD are the two k-halves of the same columns: perfectly balanced, they interleave on the matrix pipe,
+//     and their partial sums meet once, in the epilogue, through LDS;
+//   * per K tile a wave issues TM+1 ds_read_b128 (A fragments are shared by the 4 column waves, 16 bytes = 4 consecutive k per
+//     lane feed 4 MFMA steps: the K-permutation trick of fd_pw_gemm_f32) and 4*TM MFMAs on TM independent accumulators; the
+//     fragments of tile t+1 are requested WHILE the MFMAs of tile t are issued (double-buffered in registers);
+//   * operands go L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) into an S-stage ring issued S-1 tiles ahead; since a whole K tile's
+//     fragments sit in registers, a stage is free again as soon as every wave has read it: one s_barrier per K tile;
+//   * leader / follower: an LDS-DMA instruction blocks the issuing wave for ~100 cycles.  Measured (tools/microbench/gemm16.hip,
+//     ablations): when both waves of a SIMD issue their share of the DMA, the slower one pays its share uncovered after its partner
+//     has reached the barrier (+0.24 us per K tile on 1.32).  So the kh = 0 waves ("leaders", s_setprio 1) issue ALL the DMA pieces,
+//     spread through their MFMA stream, and win the matrix-pipe arbitration; the followers fill every slot the leaders leave and
+//     finish the K tile with a pure MFMA + ds_read tail;
+//   * epilogue through LDS: partial sums are exchanged in the output tile's own [row][col] image, which is then written with
+//     16-byte stores of whole 256-byte rows.
+// LDS rows are 128 bytes with the XOR swizzle chunk' = chunk ^ ((row >> 1) & 7), applied to the DMA source side and to the
+// fragment reads (conflict-free for the 16-lane groups of ds_read_b128: rows r..r+15 x chunks c..c+3).
+#pragma once
+#include "fd_device.h"
+
+template <int N> struct fd_int { static constexpr int value = N; };
+#ifdef FD_GEMM16_PROBE
+__device__ long long fd_gemm16_probe[4 * 4096];          // measurement aid (tools/microbench/gemm16.hip): shader-clock and 100 MHz timestamps per workgroup
+#endif
+
+// ABL (measurement aid, 0 in the product): 1 = no LDS-DMA in the steady state (stages keep the first tiles), 2 = also no fragment reads,
+// 3 = also no per-tile barrier, 4 = full K loop but no global stores -- wrong results, used by tools/microbench/gemm16.hip to price each
+// ingredient of the kernel.
+template <int TM, int STAGES, int ACT, int ABL = 0>
+__global__ void __launch_bounds__(512)
+fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
+                 float *__restrict__ out, int M, int N, int K, int K32, int m_stride, int m_tiles, int n_tiles)
+{
+    constexpr int BM = TM * 16, BN = 64, BK = 32, ROWS = BM + BN;
+    constexpr int STAGE = ROWS * BK;                        // floats per stage
+    constexpr int NG = ROWS / 8;                            // LDS-DMA row groups (8 rows = 1 KiB) per stage
+    constexpr int RG = (NG + 3) / 4;                        // per leader wave (a leader without an own group in the last round repeats its first)
+    constexpr int OP = BN + 4;                              // row pitch (floats) of the output tile image in LDS
+    static_assert(STAGES * STAGE >= BM * OP, "the output tile image must fit the ring");
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 3, kh = wave >> 2;                 // waves w and w+4 share a SIMD (waves are dealt to the SIMDs cyclically)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nt = slot % n_tiles, mt = (slot / n_tiles) * 8 + xcd;
+    if (mt >= m_tiles) return;
+    const long m0 = (long)mt * m_stride;
+    const int n0 = nt * BN;
+    const bool leader = kh == 0;
+#ifdef FD_GEMM16_PROBE
+    long long pc0 = 0, pw0 = 0;
+    if (tid == 0) { pc0 = clock64(); pw0 = wall_clock64(); }
+#endif
+
+    // ---- LDS-DMA sources (leaders only).  Everything that changes from K tile to K tile is wave-uniform (base pointer + t * 128 bytes,
+    // LDS destination), everything per-lane is loop-invariant (a 32-bit byte offset of the lane's row / swizzled chunk), so that a
+    // piece costs two or three scalar instructions and the DMA itself (global_load_lds_dwordx4 voffset, saddr): the first version
+    // re-derived a 64-bit per-lane address with ~10 vector instructions per piece, and those issue slots were the K loop's overhead.
+    const int wn_u = FD_UNIFORM(wn);
+    unsigned src_off[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        int g = wn_u + 4 * i;
+        if (g >= NG) g = wn_u;                               // duplicate of this wave's first group: identical bytes to the identical place
+        const int r = g * 8 + (lane >> 3);
+        const int chunk4 = ((lane & 7) ^ ((r >> 1) & 7)) * 4;
+        if (r < BM) { long row = m0 + r; if (row > M - 1) row = M - 1; src_off[i] = (unsigned)((row * K + chunk4) * 4); }
+        else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src_off[i] = (unsigned)(((long)row * K32 + chunk4) * 4); }
+    }
+    const bool ragged_k = K != K32;
+    auto piece = [&](int t, int i) {
+        int g = wn_u + 4 * i;
+        if (g >= NG) g = wn_u;
+        const bool is_a = g < BM / 8;                         // a row group is all A rows or all weight rows (BM % 8 == 0)
+        const char *base = reinterpret_cast<const char *>(is_a ? A : Wt) + (size_t)t * (BK * 4);
+        const char *p = base + src_off[i];
+        if (ragged_k && is_a && t == K32 / BK - 1) {         // ragged K, last tile: chunks beyond K read this row's first chunk instead (any
+            const int chunk4 = ((lane & 7) ^ (((g * 8 + (lane >> 3)) >> 1) & 7)) * 4;          // finite data: the padded weights are 0 there)
+            if (t * BK + chunk4 >= K) p -= (t * BK + chunk4) * 4;
+        }
+        fd_glds16(reinterpret_cast<const float *>(p), smem + (t % STAGES) * STAGE + g * 8 * BK);
+    };
+
+    // ---- accumulators: the leader starts at the folded-BN bias of its column, the follower at 0 ----
+    const int col = n0 + wn * 16 + (lane & 15);
+    const float bv = (leader && col < N) ? bias[col] : 0.0f;
+    fd_f32x4 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { acc[i].x = bv; acc[i].y = bv; acc[i].z = bv; acc[i].w = bv; }
+
+    // ---- fragment offsets (floats) within a stage: row tile i sits i * 16 rows further down with the SAME swizzle ((16 i) >> 1 is a
+    // multiple of 8), so one address register + immediate offsets serve all TM reads ----
+    const int chunk = kh * 4 + (lane >> 4);
+    const int a_off0 = (lane & 15) * BK + ((chunk ^ (((lane & 15) >> 1) & 7)) << 2);
+    const int rowb = BM + wn * 16 + (lane & 15);
+    const int b_off = rowb * BK + ((chunk ^ ((rowb >> 1) & 7)) << 2);
+
+    const int T = K32 / BK;
+    fd_f32x4 fa[2][TM], fb[2];
+    // One K tile: 4*TM MFMAs on the fragments in buffer B with the loads spread through the MFMA stream: the leader's DMA pieces of
+    // tile t+STAGES first, then (both roles) the fragment reads of tile t+1.  The uniform branches also pin the instruction order.
+    auto step = [&](auto buf, auto role, int t) {
+        constexpr int B = decltype(buf)::value;
+        constexpr bool LEAD = decltype(role)::value != 0;
+        constexpr int NDMA = LEAD ? RG : 0, NL = NDMA + TM + 1, SP = (4 * TM) / NL;
+        static_assert(SP >= 1, "not enough MFMA slots for the loads");
+        const bool do_frags = ABL != 2 && ABL != 3 && t + 1 < T, do_dma = ABL != 1 && ABL != 2 && ABL != 3 && t + STAGES < T;
+        if (ABL != 3 && t + 1 < T) {
+            if (LEAD) { if ((ABL == 0 || ABL == 4) && t + STAGES - 1 < T) fd_wait_vmcnt<(STAGES - 2) * RG>(); else fd_wait_vmcnt<0>(); }   // tile t+1 has landed
+            fd_block_barrier_lds();                          // ... for every leader, and every wave has finished reading tile t's fragments
+        }
+        const float *nxa = smem + ((t + 1) % STAGES) * STAGE + a_off0, *nxb = smem + ((t + 1) % STAGES) * STAGE + b_off;
+#pragma unroll
+        for (int idx = 0; idx < 4 * TM; ++idx) {
+            const int q = idx / TM, i = idx % TM;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[B][i][q], fb[B][q], acc[i], 0, 0, 0);
+            if ((idx + 1) % SP == 0) {
+                const int l = (idx + 1) / SP - 1;            // load slot
+                if (l < NDMA) {
+                    if (do_dma) piece(t + STAGES, l);        // stage t % STAGES is free again: tile t+STAGES goes there
+                } else if (l < NDMA + TM) {
+                    if (do_frags) fa[1 - B][l - NDMA] = fd_ld4(nxa + (l - NDMA) * 16 * BK);
+                } else if (l == NDMA + TM) {
+                    if (do_frags) fb[1 - B] = fd_ld4(nxb);
+                }
+            }
+        }
+    };
+
+    if (leader) {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s)
+            if (s < T) {
+#pragma unroll
+                for (int i = 0; i < RG; ++i) piece(s, i);
+            }
+        if (T >= STAGES) fd_wait_vmcnt<(STAGES - 1) * RG>(); else fd_wait_vmcnt<0>();
+    }
+    fd_block_barrier();
+    {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = fd_ld4(smem + a_off0 + i * 16 * BK);
+        fb[0] = fd_ld4(smem + b_off);
+    }
+    if (leader) {
+#ifndef FD_EMU
+        __builtin_amdgcn_s_setprio(1);
+#endif
+        for (int t = 0; t < T; t += 2) {
+            step(fd_int<0>{}, fd_int<1>{}, t);
+            if (t + 1 < T) step(fd_int<1>{}, fd_int<1>{}, t + 1);
+        }
+#ifndef FD_EMU
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    } else {
+        for (int t = 0; t < T; t += 2) {
+            step(fd_int<0>{}, fd_int<0>{}, t);
+            if (t + 1 < T) step(fd_int<1>{}, fd_int<0>{}, t + 1);
+        }
+    }
+
+    // ---- epilogue: the two k-halves meet in the [row][col] image of the output tile in LDS.  Every wave deposits the partial sums of
+    // the row tiles its partner finishes (leader: [0, H), follower: [H, TM)); the owner adds its own, applies the activation in
+    // place, and the finished image leaves as whole 256-byte rows, 16 bytes per lane. ----
+    constexpr int H = (TM + 1) / 2;
+    fd_block_barrier_lds();                                  // every wave is done with the ring (all tiles landed and read)
+    float *img = smem + (4 * (lane >> 4)) * OP + wn * 16 + (lane & 15);       // D register r of lane l: row 4*(l>>4) + r, column l & 15
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const bool mine = leader ? i < H : i >= H;
+        if (!mine) {
+            float *o = img + i * 16 * OP;
+            o[0] = acc[i].x; o[OP] = acc[i].y; o[2 * OP] = acc[i].z; o[3 * OP] = acc[i].w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const bool mine = leader ? i < H : i >= H;
+        if (mine) {
+            float *o = img + i * 16 * OP;
+            o[0] = fd_act<ACT>(acc[i].x + o[0]); o[OP] = fd_act<ACT>(acc[i].y + o[OP]);
+            o[2 * OP] = fd_act<ACT>(acc[i].z + o[2 * OP]); o[3 * OP] = fd_act<ACT>(acc[i].w + o[3 * OP]);
+        }
+    }
+    __syncthreads();
+#ifdef FD_GEMM16_PROBE
+    if (tid == 0) { fd_gemm16_probe[4 * blockIdx.x] = pc0; fd_gemm16_probe[4 * blockIdx.x + 1] = clock64(); fd_gemm16_probe[4 * blockIdx.x + 2] = pw0; fd_gemm16_probe[4 * blockIdx.x + 3] = wall_clock64(); }
+#endif
+    if (ABL == 4) return;
+    int rows = M - m0 < m_stride ? (int)(M - m0) : m_stride;
+    if (rows > BM) rows = BM;
+    const int c4 = (lane & 15) * 4;
+    if (n0 + c4 < N) {                                       // N % 4 == 0: a lane's 4 columns are all inside or all outside
+        for (int r = wave * 4 + (lane >> 4); r < rows; r += 32)
+            fd_st4(out + (m0 + r) * N + n0 + c4, fd_ld4(smem + r * OP + c4));
+    }
+}

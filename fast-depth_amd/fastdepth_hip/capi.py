@@ -23,6 +23,8 @@ FD_PLAN_KEEP_ACTIVATIONS = 1
 FD_PLAN_FUSE_SEPARABLE = 4
 FD_PLAN_WGRAD_TILE_ROWS = 8
 FD_PLAN_STREAMK = 32
+FD_PLAN_FORCE_GEMM16 = 16
+FD_PLAN_NO_GEMM16 = 64
 
 
 class LayerDesc(ctypes.Structure):

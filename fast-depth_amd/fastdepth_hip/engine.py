@@ -75,11 +75,12 @@ class Engine:
             p.version = None
 
     def _version(self):
-        v = 0
-        for l in self.layers:
-            for t in (l.conv.weight, l.bn.weight, l.bn.bias, l.bn.running_mean, l.bn.running_var):
-                v = v * 1000003 + t._version + (t.data_ptr() & 0xFFFFFFF)
-        return v
+        """Cheap fingerprint of the parameters the packed weights were made from (torch version counters + addresses).  Edits made
+        through `.data` bypass the counters: call model.repack() after those."""
+        ts = self.__dict__.get("_param_tensors")
+        if ts is None or len(ts) != 5 * len(self.layers) or any(a is not b for a, b in zip(ts[::5], (l.conv.weight for l in self.layers))):
+            ts = self._param_tensors = [t for l in self.layers for t in (l.conv.weight, l.bn.weight, l.bn.bias, l.bn.running_mean, l.bn.running_var)]
+        return hash(tuple((t._version, t.data_ptr()) for t in ts))
 
     def plan_for(self, x):
         b, c, h, w = x.shape
@@ -112,7 +113,11 @@ class Engine:
             if self.dtype == torch.float16:
                 raise capi.FastDepthError("train mode supports float32 or bfloat16 storage (fp16 gradients would need loss scaling)")
             core = self.__dict__.get("_train_core")
-            if core is None or core.dtype != tdt:
+            if core is not None:
+                ps = tuple(p.data_ptr() for l in self.layers for p in (l.conv.weight, l.bn.weight, l.bn.bias))
+                if core.signature() != (tdt, self.layers[0].conv.weight.device, ps):
+                    core = None                   # parameters were moved / re-allocated (model.to(...), load with assign=True): stale pointers
+            if core is None:
                 core = self._train_core = TrainCore(self.model, tdt)
             if torch.is_grad_enabled():
                 return autograd_forward(core, x)

@@ -86,7 +86,16 @@ class TrainCore:
         self.bn_momentum = self.layers[0].bn.momentum
         if any(l.bn.eps != self.eps or l.bn.momentum != self.bn_momentum for l in self.layers):
             raise capi.FastDepthError("mixed BatchNorm eps/momentum values are not supported")
+        if self.bn_momentum is None:
+            raise capi.FastDepthError("BatchNorm momentum=None (cumulative moving average) is not supported by the train step")
         self._nbt = [l.bn.num_batches_tracked for l in self.layers if l.bn.num_batches_tracked is not None]
+        self.generation = 0                       # stamped on every train-mode forward (TrainFunction.backward checks it)
+        self.params_in_order = [p for l in self.layers for p in (l.conv.weight, l.bn.weight, l.bn.bias)]
+        self.views_in_param_order = [self.grad_views[(i, k)] for i in range(self.n) for k in ("conv_weight", "bn_weight", "bn_bias")]
+
+    def signature(self):
+        """What the cached pointers depend on: the engine rebuilds the core when a parameter was re-allocated or moved."""
+        return (self.dtype, self.device, tuple(p.data_ptr() for p in self.params_in_order))
 
     def c_params(self):
         params = (capi.LayerParams * self.n)()
@@ -120,6 +129,7 @@ class TrainCore:
             if self._nbt:
                 torch._foreach_add_(self._nbt, 1)
         self._plan = plan
+        self.generation += 1
         return y
 
     def backward_range(self, dy, from_layer, to_layer):
@@ -134,31 +144,60 @@ class TrainCore:
 
 
 class TrainFunction(torch.autograd.Function):
-    """pred = TrainFunction.apply(core, x, *parameters): autograd entry point of the drop-in module in .train() mode."""
+    """pred = TrainFunction.apply(core, x, *parameters): autograd entry point of the drop-in module in .train() mode.
+
+    The saved activations live in the plan's workspace, i.e. they belong to the LAST train-mode forward of this shape: every forward
+    is stamped with a generation number and backward refuses to run against a workspace a later forward has overwritten (two
+    forwards summed into one loss are not part of this path).  The parameters go through save_for_backward so that autograd's
+    version-counter check fires when one of them is edited in place between forward and backward.
+
+    Gradients are delivered without per-tensor copies: backward writes the flat gradient buffer and hands each parameter its VIEW of
+    it as `.grad` (the usual `optimizer.zero_grad(); loss.backward(); optimizer.step()` loop then costs no copy kernel at all);
+    gradients already present are accumulated into with one multi-tensor add.  Consequence: tensor hooks registered on the
+    parameters do not fire (data parallelism is TrainEngine's job, not DistributedDataParallel's)."""
 
     @staticmethod
     def forward(ctx, core, x, *params):
         if x.requires_grad:
             raise capi.FastDepthError("gradients with respect to the input image are not part of this path")
         ctx.core = core
-        return core.forward(x)
+        y = core.forward(x)
+        ctx.gen = core.generation
+        ctx.save_for_backward(*params)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         core = ctx.core
+        if core.generation != ctx.gen:
+            raise capi.FastDepthError("backward of a train-mode forward whose saved activations were overwritten by a later forward "
+                                      "(one outstanding forward per model: call backward before the next train-mode forward)")
+        params = ctx.saved_tensors                # raises if a parameter was modified in place since forward
+        views = core.views_in_param_order
+        base = core.flat_grad.untyped_storage().data_ptr()
+        had = [(p.grad, v) for p, v in zip(params, views) if p.grad is not None]
+        aliased = [g.untyped_storage().data_ptr() == base for g, _ in had]
+        keep = core.flat_grad.clone() if any(aliased) else None      # accumulation into gradients that ARE the buffer backward overwrites
         core.backward(dy.contiguous())
-        grads = []
-        for l in core.layers:
-            i = core.layers.index(l)
-            grads += [core.grad_views[(i, "conv_weight")].clone(), core.grad_views[(i, "bn_weight")].clone(), core.grad_views[(i, "bn_bias")].clone()]
-        return (None, None, *grads)
+        if had:
+            off = keep.data_ptr() - core.flat_grad.data_ptr() if keep is not None else 0
+            other = []
+            for (g, v), al in zip(had, aliased):
+                if al:
+                    start = (v.data_ptr() - core.flat_grad.data_ptr()) // 4
+                    other.append(keep[start:start + v.numel()].view_as(v))
+                else:
+                    other.append(v)
+            del off
+            torch._foreach_add_([g for g, _ in had], other)
+        for p, v in zip(params, views):
+            if p.grad is None:
+                p.grad = v
+        return (None, None) + (None,) * len(params)
 
 
 def autograd_forward(core, x):
-    params = []
-    for l in core.layers:
-        params += [l.conv.weight, l.bn.weight, l.bn.bias]
-    return TrainFunction.apply(core, x, *params)
+    return TrainFunction.apply(core, x, *core.params_in_order)
 
 
 def make_buckets(layer_bytes, n_buckets):

@@ -47,6 +47,23 @@ def test_emulated_stream_k_gemm_matches_oracle():
     assert not bad and err < TOL, bad
 
 
+@pytest.mark.parametrize("name,plan,b,hw", [("ragged", RAGGED, 2, (32, 96)), ("tiny", TINY, 2, 64)])
+def test_emulated_gemm16_matches_oracle(name, plan, b, hw):
+    """fd_pw_gemm16_f32 (16x16x4 MFMA, k-split wave pairs, leader/follower LDS-DMA, LDS-transposed epilogue) forced onto every
+    pointwise layer: the batch / image sizes make M = 1536, 384, 96, 24, 6 (ragged) resp. 2048 ... 8 (tiny), i.e. all three row-tile
+    counts (13, 7, 4), strides below the full tile, ragged M, ragged N (not a multiple of 64) and ragged K (not a multiple of 32)."""
+    h, w = (hw, hw) if isinstance(hw, int) else hw
+    m = small_model(plan[0], plan[1], seed=21)
+    x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(8))
+    err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), flags=harness.capi.FD_PLAN_FORCE_GEMM16)
+    used = [s for s in info if "pw_gemm16" in s]
+    assert len(used) == 18, info
+    if name == "ragged":
+        assert {s.split("TM=")[1].split(":")[0] for s in used} == {"13", "7", "4"}, used
+    bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
+    assert not bad and err < TOL, bad
+
+
 def test_plan_rejects_bad_shapes():
     m = small_model(*TINY, seed=1)
     with pytest.raises(harness.capi.FastDepthError):
