@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the FastDepth MobileNetSkipAdd hot path on MI355X (BASELINE.json `metric`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: re-launches itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -10,14 +10,26 @@ One "step" = one inference forward of a batch of 32 synthetic 224x224 RGB frames
 runs its own batch of 32 (weak scaling; inference shards over frames with no collective, SURVEY.md 8(e));
 the timed region is bracketed by barrier + torch.cuda.synchronize() and the max over ranks is taken.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      for the kernel symbol with the largest share of device time, timed live with HIP events on the
-                launch stream (fd_forward_timed), priced against the fp32 MFMA peak or HBM bandwidth
-  cpu_baseline  the oracle's torch-functional restatement (the same ATen CPU kernels the reference dispatches
-                to) timed on this box's host cores on a bounded sample (N=1, rank 0 only)
+  roofline          the kernel symbol with the largest share of device time, timed live with HIP events on the launch stream,
+                    priced against the fp32 MFMA peak or HBM bandwidth (MI355X_MICROARCH.md); `traffic` from the committed PMC summary
+  whole_step        algorithmic bytes / flops of the step and its layer-wise roofline bound sum_l max(bytes/HBM, flops/MFMA)
+  train_step, train_step_bf16
+                    the other half of BASELINE's metric: fwd + L1 + bwd + [RCCL all-reduce] + SGD at 32 frames per GPU (configs[2], and
+                    configs[3] at N = 8), each with its own `roofline` (dominant kernel family, fd_trace) and, for N > 1, the all-reduce time
+                    and how much of it backward hides
+  other_configs     configs[4] (pruned fp16 B=64), 16-bit storage B=32, B=1 latency -- N = 1 only, each with a `roofline`
+  cpu_baseline      N = 1, rank 0: the reference's UNMODIFIED module (kind "reference") when /root/reference exists, otherwise the
+                    oracle's torch-functional restatement (kind "port": the same ATen CPU kernels), on the host cores: inference at
+                    B in {1, 8, 32} and the train step (L1Loss + SGD) at B in {8, 32}; warm-up + repeated timed runs, median
+                    (protocol of the reference's deploy/tx2_run_tvm.py:44-53,77-80); bounded to ~25 s
+  train_check       N = 1, rank 0: three SGD steps on 4 frames -- losses of the fp32 and bf16 HIP plans next to the fp64 oracle's
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,90 +37,320 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "fast-depth_amd"))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (== fp32 vector peak)
+MFMA_H16_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
+REFERENCE = "/root/reference"
 
 
-def build_model(device):
-    import models
-    torch.manual_seed(0)
-    m = models.MobileNetSkipAdd((224, 224), pretrained=False)
-    gold = os.path.join(REPO, "tests", "golden", "base_s0_bn.npz")
-    if os.path.exists(gold):        # calibrated-synthetic BN statistics; random-init conv weights
-        bn = np.load(gold)
-        m.load_state_dict({k: torch.from_numpy(bn[k]) for k in bn.files}, strict=False)
-    return m.eval().to(device)
-
-
-def cpu_baseline(batch, budget_s):
-    """Times oracle/torch_ref.py (ATen CPU kernels, fp32, eval) on the host cores: small sweep over
-    (batch, threads, memory format), bounded by `budget_s` seconds in total.  Returns the best frames/s."""
-    from oracle import torch_ref
-    import models
-    torch.manual_seed(0)
-    p = torch_ref.params_from_state(models.MobileNetSkipAdd((224, 224), pretrained=False).state_dict())
-    ncpu = os.cpu_count() or 1
-    thread_opts = sorted({min(ncpu, t) for t in (16, 32, 64, 128)})
-    best, t_start, tried = None, time.time(), []
-    for threads in thread_opts:
-        for b in (8, batch):
-            for cl in (False, True):
-                if time.time() - t_start > budget_s:
-                    break
-                torch.set_num_threads(threads)
-                x = torch.rand(b, 3, 224, 224)
-                if cl:
-                    x = x.contiguous(memory_format=torch.channels_last)
-                with torch.no_grad():
-                    torch_ref.forward(p, x)                       # warm-up
-                    t0 = time.time(); n = 0
-                    while n < 3 and (n == 0 or time.time() - t0 < budget_s / 8):
-                        torch_ref.forward(p, x); n += 1
-                    dt = (time.time() - t0) / n
-                fps = b / dt
-                tried.append({"batch": b, "threads": threads, "channels_last": cl, "fps": round(fps, 1)})
-                if best is None or fps > best["fps"]:
-                    best = {"fps": fps, "threads": threads, "batch": b, "channels_last": cl}
-    return {"value": round(best["fps"], 2), "unit": "frames/s", "cores": best["threads"], "kind": "port",
-            "sample": "oracle/torch_ref.py (ATen CPU conv/batch_norm/hardtanh/upsample/add, fp32 eval), best of a "
-                      "%.0f s sweep: batch %d, %d threads, channels_last=%s; %d configs tried"
-                      % (budget_s, best["batch"], best["threads"], best["channels_last"], len(tried)),
-            "sweep": tried}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE.json configs[1]: 32)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the host-CPU baseline sweep")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the host-CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10, help="instrumented steps for the per-kernel roofline")
-    ap.add_argument("--extra-steps", type=int, default=30, help="timed steps for each entry of `other_configs` (pruned fp16 B=64, "
-                    "bf16 / fp16 B=32, fp32 B=1 latency); 0 disables")
-    ap.add_argument("--train-steps", type=int, default=20, help="timed fp32 train steps (fwd + L1 + bwd [+ RCCL all-reduce] + SGD) reported as "
-                    "`train_step`; 0 disables")
-    args = ap.parse_args()
+    ap.add_argument("--extra-steps", type=int, default=30, help="timed steps for each entry of `other_configs`; 0 disables")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed train steps per plan (`train_step`, `train_step_bf16`); 0 disables")
+    ap.add_argument("--only", default="", choices=["", "infer", "train_f32", "train_bf16", "f16", "bf16", "pruned_f16"],
+                    help="run ONE configuration's timed loop and nothing else (one rocprofv3 invocation per configuration: tools/gpu_round.sh)")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL over xGMI)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+def build_model(device, pruned=False):
+    import numpy as np
+    import torch
+    import models
+    torch.manual_seed(0)
+    m = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None)
+    gold = os.path.join(REPO, "tests", "golden", "base_s0_bn.npz")
+    if os.path.exists(gold) and not pruned:   # calibrated-synthetic BN statistics (SURVEY.md 8(c)); random-init conv weights
+        bn = np.load(gold)
+        m.load_state_dict({k: torch.from_numpy(bn[k]) for k in bn.files}, strict=False)
+    return m.eval().to(device)
+
+
+def layerwise_bound_ms(stats, mfma_peak_tflops):
+    """sum over layers of max(bytes / HBM, flops / MFMA): the roofline that bounds the step.  The pointwise GEMMs are
+    priced against `mfma_peak_tflops`, everything else (VALU work) against the fp32 vector peak, which equals the fp32 MFMA peak."""
+    t = 0.0
+    for name, sym, info, nbytes, flops in stats:
+        peak = mfma_peak_tflops if "pw_gemm" in sym else MFMA_F32_PEAK_TFLOPS
+        t += max(nbytes / (HBM_PEAK_GBS * 1e9), flops / (peak * 1e12))
+    return t * 1e3
+
+
+def roofline_of(entry, sym, mfma_peak_tflops, total_ms):
+    """entry: {"launches", "ms", "bytes", "flops"} summed over the launches of one kernel symbol / family in ONE step."""
+    t_s = entry["ms"] / 1e3
+    hbm_time, mfma_time = entry["bytes"] / (HBM_PEAK_GBS * 1e9), entry["flops"] / (mfma_peak_tflops * 1e12)
+    if "gemm" in sym and mfma_time >= hbm_time:
+        roof = {"bound": "mfma", "achieved": round(entry["flops"] / t_s / 1e12, 3), "peak": mfma_peak_tflops, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": round(entry["bytes"] / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["traffic"] = None
+    traffic_file = os.path.join(REPO, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
+    if os.path.exists(traffic_file):
+        try:
+            roof["traffic"] = json.load(open(traffic_file)).get(sym)
+        except Exception:
+            pass
+    roof.update({"kernel": sym, "launches_per_step": entry["launches"], "avg_launch_us": round(entry["ms"] * 1e3 / entry["launches"], 2),
+                 "share_of_device_time": round(entry["ms"] / total_ms, 4),
+                 "algorithmic_per_launch": {"bytes": entry["bytes"] / entry["launches"], "flops": entry["flops"] / entry["launches"]}})
+    return roof
+
+
+def inference_profile(eng, x, steps, mfma_peak_tflops):
+    """Per-kernel device time of the inference forward (HIP events on the launch stream, fd_forward_timed), aggregated by kernel symbol."""
+    import numpy as np
+    stats = eng.layer_stats(x)
+    acc = np.zeros(len(stats))
+    for _ in range(max(steps, 1)):
+        _, ms = eng.forward_timed(x)
+        acc += np.array(ms)
+    acc /= max(steps, 1)
+    by_sym = {}
+    for (name, sym, info, nbytes, flops), ms in zip(stats, acc):
+        e = by_sym.setdefault(sym, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+        e["launches"] += 1; e["ms"] += float(ms); e["bytes"] += nbytes; e["flops"] += flops
+    total_ms = float(acc.sum())
+    dom_sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    kernels = [{"kernel": s, "launches": e["launches"], "ms_per_step": round(e["ms"], 4),
+                "GBps": round(e["bytes"] / (e["ms"] / 1e3) / 1e9, 1), "TFLOPs": round(e["flops"] / (e["ms"] / 1e3) / 1e12, 2)}
+               for s, e in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])]
+    whole = {"algorithmic_GB": round(sum(s[3] for s in stats) / 1e9, 4), "algorithmic_GFLOP": round(sum(s[4] for s in stats) / 1e9, 3),
+             "device_ms_sum_of_kernels": round(total_ms, 4), "roofline_bound_ms": round(layerwise_bound_ms(stats, mfma_peak_tflops), 4)}
+    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms), whole, kernels, len(stats)
+
+
+# kernel families of the train step whose launches move a unit's activations once (SURVEY.md 8(d): fwd 1x + bwd 2x the inference bytes);
+# everything else (BatchNorm finalisation, partial reductions, operand packing) is overhead with no algorithmic traffic of its own
+_TRAIN_MAJOR = ("gemm_train", "dwconv_train", "stem_train", "head_train", "dgrad", "wgrad", "head_bwd<")
+
+
+def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes):
+    """Per-kernel-family device time of the fused train step (fd_trace: HIP events around every launch), with the algorithmic bytes /
+    flops of the unit each launch belongs to."""
+    import ctypes
+    from fastdepth_hip import capi
+    L = teng.L
+    import torch
+    fam = {}
+    for _ in range(steps):
+        capi.check(L, L.fd_trace_begin(), "fd_trace_begin")
+        teng.step(x, tgt)
+        n = ctypes.c_int32()
+        recs = (capi.TraceRecord * 4096)()
+        capi.check(L, L.fd_trace_end(torch.cuda.current_stream(x.device).cuda_stream, recs, 4096, ctypes.byref(n)), "fd_trace_end")
+        for r in recs[:min(n.value, 4096)]:
+            name = r.kernel.decode().strip("()").split("<")[0].strip()
+            e = fam.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+            e["launches"] += 1; e["ms"] += r.ms
+            raw = r.kernel.decode()
+            if any(t in raw for t in _TRAIN_MAJOR) and r.layer >= 0:
+                mult = 2.0 if "head_bwd<" in raw else 1.0          # the head's backward kernel is its dgrad and wgrad in one
+                e["bytes"] += mult * stats[r.layer][3]; e["flops"] += mult * stats[r.layer][4]
+            elif "sgd" in raw:
+                e["bytes"] += 5.0 * param_bytes                     # grad read, param read+write, momentum read+write
+            elif "l1_loss" in raw:
+                e["bytes"] += 3.0 * x.shape[0] * x.shape[2] * x.shape[3] * 4
+    for e in fam.values():
+        for k in e:
+            e[k] /= steps
+    total_ms = sum(e["ms"] for e in fam.values())
+    dom_sym, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+    kernels = [{"kernel": s, "launches": round(e["launches"], 1), "ms_per_step": round(e["ms"], 4),
+                "GBps": round(e["bytes"] / (e["ms"] / 1e3) / 1e9, 1), "TFLOPs": round(e["flops"] / (e["ms"] / 1e3) / 1e12, 2)}
+               for s, e in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])]
+    alg_bytes = 3.0 * sum(s[3] for s in stats) + 5.0 * param_bytes
+    alg_flops = 3.0 * sum(s[4] for s in stats)
+    whole = {"algorithmic_GB": round(alg_bytes / 1e9, 4), "algorithmic_GFLOP": round(alg_flops / 1e9, 3), "device_ms_sum_of_kernels": round(total_ms, 4),
+             "launches_per_step": round(sum(e["launches"] for e in fam.values()), 1),
+             "roofline_bound_ms": round(3.0 * layerwise_bound_ms(stats, mfma_peak_tflops) + 5.0 * param_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
+    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms), whole, kernels
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(budget_s):
+    """The host-CPU yard-stick of BASELINE.md section 3: the reference's unmodified module (torchvision stub only) when /root/reference is
+    present, else the oracle's torch-functional restatement of it (the same ATen CPU kernels), fp32, eval + no_grad for inference,
+    L1Loss + SGD(0.01, 0.9, 1e-4) for the train step; warm-up then repeated timed runs, median (deploy/tx2_run_tvm.py:44-53,77-80)."""
+    import torch
+    import types
+    t_start = time.time()
+    kind, module, fwd = "port", None, None
+    if os.path.isdir(REFERENCE):
+        # the reference's own packages are called `models` / `imagenet` like the product's drop-ins: swap them in sys.modules for the
+        # duration of the import only (the reference's module objects stay alive through `module`)
+        names = ("torchvision", "torchvision.models", "models", "imagenet", "imagenet.mobilenet")
+        saved = {k: sys.modules.pop(k, None) for k in names}
+        try:
+            import importlib
+            stub = types.ModuleType("torchvision"); stub.models = types.ModuleType("torchvision.models")
+            sys.modules["torchvision"], sys.modules["torchvision.models"] = stub, stub.models     # only the ResNet classes use it
+            sys.path.insert(0, REFERENCE)
+            ref_models = importlib.import_module("models")
+            assert os.path.abspath(ref_models.__file__).startswith(REFERENCE)
+            torch.manual_seed(0)
+            module = ref_models.MobileNetSkipAdd((224, 224), pretrained=False)
+            kind = "reference"
+        except Exception:
+            module = None
+        finally:
+            if REFERENCE in sys.path:
+                sys.path.remove(REFERENCE)
+            for k in names:
+                sys.modules.pop(k, None)
+                if saved[k] is not None:
+                    sys.modules[k] = saved[k]
+    if module is None:
+        from oracle import torch_ref
+        import models
+        torch.manual_seed(0)
+        proto = models.MobileNetSkipAdd((224, 224), pretrained=False)
+
+        class Port(torch.nn.Module):                      # parameters as a module so that the train leg can use torch.optim.SGD
+            def __init__(self):
+                super().__init__()
+                sd = proto.state_dict()
+                self.keys = [k for k in sd if not k.endswith("num_batches_tracked")]
+                self.p = torch.nn.ParameterList([torch.nn.Parameter(sd[k].clone(), requires_grad=not ("running" in k)) for k in self.keys])
+
+            def forward(self, x):
+                return torch_ref.forward(dict(zip(self.keys, self.p)), x, train=self.training)
+        module = Port()
+    ncpu = os.cpu_count() or 1
+
+    def run_infer(b, cl, iters, threads):
+        torch.set_num_threads(threads)
+        module.eval()
+        x = torch.rand(b, 3, 224, 224)
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        ts = []
+        with torch.no_grad():
+            for _ in range(2):
+                module(x)
+            for _ in range(iters):
+                t0 = time.perf_counter(); module(x); ts.append(time.perf_counter() - t0)
+        return b / statistics.median(ts)
+
+    def run_train(b, iters, threads):
+        torch.set_num_threads(threads)
+        module.train()
+        opt = torch.optim.SGD([p for p in module.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4)
+        x, tgt = torch.rand(b, 3, 224, 224), 0.7 + 9.3 * torch.rand(b, 1, 224, 224)
+        crit = torch.nn.L1Loss()
+        ts = []
+        for i in range(iters + 1):
+            t0 = time.perf_counter()
+            opt.zero_grad(); loss = crit(module(x), tgt); loss.backward(); opt.step()
+            if i:
+                ts.append(time.perf_counter() - t0)
+        return b / statistics.median(ts)
+
+    # thread count: quick probe at B = 8 (the 256-thread hosts of the GPU boxes run this network fastest on 16-64 threads)
+    cand = sorted({min(ncpu, t) for t in (16, 32, 64)})
+    probe = {t: run_infer(8, False, 2, t) for t in cand}
+    threads = max(probe, key=probe.get)
+    rows, train_rows = [], []
+    for b, iters in ((1, 10), (8, 10), (32, 3)):
+        for cl in (False, True):
+            if time.time() - t_start > 0.6 * budget_s and rows:
+                break
+            rows.append({"batch": b, "channels_last": cl, "threads": threads, "iters": iters, "fps": round(run_infer(b, cl, iters, threads), 1)})
+    for b, iters in ((8, 3), (32, 2)):
+        if time.time() - t_start > budget_s and train_rows:
+            break
+        train_rows.append({"batch": b, "threads": threads, "iters": iters, "fps": round(run_train(b, iters, threads), 1)})
+    best = max(rows, key=lambda r: r["fps"])
+    b32 = max([r for r in rows if r["batch"] == 32] or [best], key=lambda r: r["fps"])
+    b1 = max([r for r in rows if r["batch"] == 1] or [best], key=lambda r: r["fps"])
+    what = ("/root/reference models.MobileNetSkipAdd, unmodified (torchvision stub only)" if kind == "reference"
+            else "oracle/torch_ref.py (the ATen CPU conv / batch_norm / hardtanh / upsample / add kernels the reference dispatches to)")
+    return {"value": best["fps"], "unit": "frames/s", "cores": threads, "kind": kind,
+            "sample": "%s, fp32 eval + no_grad on %d of %d host threads: best of B in {1, 8, 32} x {contiguous, channels_last}, 2 warm-ups + median of "
+                      "10 timed runs (3 at B=32); best = B %d, channels_last=%s; %.0f s in total" % (what, threads, ncpu, best["batch"], best["channels_last"], time.time() - t_start),
+            "batch32_fps": b32["fps"], "batch1_fps": b1["fps"], "batch1_ms": round(1e3 / b1["fps"], 2), "sweep": rows,
+            "train_step": {"value": max(r["fps"] for r in train_rows), "unit": "frames/s", "sweep": train_rows,
+                           "sample": "torch.nn.L1Loss + torch.optim.SGD(0.01, 0.9, 1e-4), module in .train(), fp32, 1 warm-up + median"}}
+
+
+def train_check(dev):
+    """Three SGD steps on 4 frames: the losses of the fp32 and bf16 HIP plans next to the fp64 oracle's on the same seed (replaces the
+    non-discriminating `final_loss`)."""
+    import copy
+    import torch
+    import models
+    from fastdepth_hip.train import TrainEngine
+    from oracle import torch_ref
+    torch.manual_seed(0)
+    base = models.MobileNetSkipAdd((224, 224), pretrained=False)
+    base.decode_conv6[1].bias.data.fill_(2.8)
+    g = torch.Generator().manual_seed(77)
+    x, tgt = torch.rand(4, 3, 224, 224, generator=g), 0.7 + 9.3 * torch.rand(4, 1, 224, 224, generator=g)
+    out = {"steps": 3, "batch": 4}
+    for dtype, tag in ((torch.float32, "loss_hip_f32"), (torch.bfloat16, "loss_hip_bf16")):
+        eng = TrainEngine(copy.deepcopy(base).to(dev).train(), lr=0.01, momentum=0.9, weight_decay=1e-4, dtype=dtype)
+        out[tag] = [round(float(eng.step(x.to(dev), tgt.to(dev))), 6) for _ in range(3)]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    p = torch_ref.params_from_state(base.state_dict(), torch.float64, requires_grad=True)
+    bufs, losses = {}, []
+    for _ in range(3):
+        loss, grads = torch_ref.l1_train_grads(p, x.double(), tgt.double())
+        torch_ref.sgd_step(p, grads, bufs, 0.01, 0.9, 1e-4)
+        losses.append(round(float(loss), 6))
+    out["loss_oracle_f64"] = losses
+    out["max_rel_dev_f32"] = round(max(abs(a - b) / b for a, b in zip(out["loss_hip_f32"], losses)), 6)
+    out["max_rel_dev_bf16"] = round(max(abs(a - b) / b for a, b in zip(out["loss_hip_bf16"], losses)), 6)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        self_launch(args)
+    import numpy as np  # noqa: F401
+    import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d launched with WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("FD_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL code path on one rank
+    force_dist = os.environ.get("FD_BENCH_FORCE_DIST") == "1"           # exercises the RCCL code path on one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if not dist.is_initialized():
+            if "MASTER_ADDR" not in os.environ:
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            dist.init_process_group("nccl", device_id=dev)
 
+    import models
+    from fastdepth_hip.train import TrainEngine
     model = build_model(dev)
     eng = model._engine()
     g = torch.Generator().manual_seed(1234 + rank)
@@ -119,138 +361,136 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            y = model(x)
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def time_forward(mod, xin, steps, warmup, fn=None):
+        fn = fn or (lambda: mod(xin))
+        with torch.no_grad():
+            for _ in range(warmup):
+                y = fn()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                y = fn()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            barrier()
+        assert torch.isfinite(y).all()
+        return max_over_ranks(elapsed)
+
+    def make_train_engine(dtype):
+        torch.manual_seed(0)
+        tm = models.MobileNetSkipAdd((224, 224), pretrained=False)
+        tm.decode_conv6[1].bias.data.fill_(2.8)
+        tm = tm.to(dev).train()
+        return TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
+                           force_buckets=force_dist, dtype=dtype)
+
+    gt = torch.Generator().manual_seed(1)
+    tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=gt)).to(dev)     # synthetic depth, U[0.7, 10) m
+
+    def time_train(dtype, tag, steps):
+        teng = make_train_engine(dtype)
+        for _ in range(3):
+            loss = teng.step(x, tgt)
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            y = model(x)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            loss = teng.step(x, tgt)
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        t_el = time.perf_counter() - t1
         barrier()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    assert torch.isfinite(y).all()
+        t_el = max_over_ranks(t_el)
+        assert torch.isfinite(loss).all()
+        res = {"metric": "frames/sec (224x224) train step: fwd + L1 loss + bwd + gradient all-reduce + SGD(momentum, wd)",
+               "value": round(world * args.batch * steps / t_el, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": 3,
+               "ms_per_step": round(t_el / steps * 1e3, 4), "dtype": tag, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+               "parallelism": ("dp%d: RCCL all-reduce of the 15.84 MB fp32 gradient vector in %d buckets on a side stream, overlapped with backward" % (world, len(teng.buckets)))
+                              if teng.use_comm else "single GPU"}
+        if teng.use_comm:        # how long the collectives take and how much of them backward hides (3 instrumented steps, synchronising)
+            cs = []
+            for _ in range(3):
+                teng.step(x, tgt, time_comm=True)
+                cs.append(teng.last_comm_us)
+            comm = statistics.median(c[0] for c in cs); exposed = statistics.median(c[2] for c in cs)
+            res["allreduce"] = {"ranks": world, "buckets": len(teng.buckets), "us_per_step_first_issue_to_last_done": round(comm, 1),
+                                "us_exposed_after_backward": round(exposed, 1), "overlap_fraction": round(max(0.0, 1.0 - exposed / comm), 3) if comm > 0 else None}
+        if args.profile_steps > 0 and args.only == "":
+            eng.set_dtype(dtype)
+            stats = eng.layer_stats(x)                      # algorithmic bytes / flops per unit at this storage type
+            eng.set_dtype(torch.float32)
+            peak = MFMA_F32_PEAK_TFLOPS if dtype == torch.float32 else MFMA_H16_PEAK_TFLOPS
+            roof, whole, kernels = train_profile(teng, x, tgt, stats, 3, peak, 4.0 * teng.total)
+            res["roofline"], res["whole_step"], res["kernels"] = roof, whole, kernels[:12]
+            res["whole_step"]["frac_of_roofline"] = round(whole["roofline_bound_ms"] / res["ms_per_step"], 4)
+        return res
 
-    # per-kernel device time, HIP events on the launch stream
-    stats = eng.layer_stats(x)
-    acc = np.zeros(len(stats))
-    for _ in range(max(args.profile_steps, 1)):
-        _, ms = eng.forward_timed(x)
-        acc += np.array(ms)
-    acc /= max(args.profile_steps, 1)
-    by_sym = {}
-    for (name, sym, info, nbytes, flops), ms in zip(stats, acc):
-        e = by_sym.setdefault(sym, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
-        e["launches"] += 1; e["ms"] += float(ms); e["bytes"] += nbytes; e["flops"] += flops
-    dom_sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-    t_s = dom["ms"] / 1e3
-    hbm_time, mfma_time = dom["bytes"] / (HBM_PEAK_GBS * 1e9), dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
-    is_gemm = dom_sym.startswith("fd_pw_gemm")
-    if is_gemm and mfma_time >= hbm_time:
-        roof = {"bound": "mfma", "achieved": round(dom["flops"] / t_s / 1e12, 3), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"}
-    else:
-        roof = {"bound": "hbm", "achieved": round(dom["bytes"] / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    roof["traffic"] = None
-    traffic_file = os.path.join(REPO, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
-    if os.path.exists(traffic_file):
-        try:
-            roof["traffic"] = json.load(open(traffic_file)).get(dom_sym)
-        except Exception:
-            pass
-    roof.update({"kernel": dom_sym, "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
-                 "share_of_device_time": round(dom["ms"] / float(acc.sum()), 4),
-                 "algorithmic_per_launch": {"bytes": dom["bytes"] / dom["launches"], "flops": dom["flops"] / dom["launches"]}})
-    kernels = [{"kernel": s, "launches": e["launches"], "ms_per_step": round(e["ms"], 4),
-                "GBps": round(e["bytes"] / (e["ms"] / 1e3) / 1e9, 1), "TFLOPs": round(e["flops"] / (e["ms"] / 1e3) / 1e12, 2)}
-               for s, e in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])]
-    total_bytes = sum(s[3] for s in stats); total_flops = sum(s[4] for s in stats)
+    # ---- one configuration only (profiling runs) ------------------------------------------------------------------------------------
+    if args.only:
+        if args.only == "infer":
+            t = time_forward(model, x, args.steps, args.warmup)
+        elif args.only in ("f16", "bf16"):
+            model.set_compute_dtype(torch.float16 if args.only == "f16" else torch.bfloat16)
+            t = time_forward(model, x, args.steps, args.warmup)
+        elif args.only == "pruned_f16":
+            pm = build_model(dev, pruned=True); pm.set_compute_dtype(torch.float16)
+            x64 = torch.rand(64, 3, 224, 224, generator=g).to(dev)
+            t = time_forward(pm, x64, args.steps, args.warmup) / 2.0        # reported per 32 frames for comparability
+        else:
+            r = time_train(torch.float32 if args.only == "train_f32" else torch.bfloat16, args.only, args.steps)
+            t = r["ms_per_step"] * args.steps / 1e3
+        if rank == 0:
+            print(json.dumps({"only": args.only, "steps": args.steps, "ms_per_step": round(t / args.steps * 1e3, 4), "n_gpus": world}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
-    # ---- secondary measurement: the train step (BASELINE.json metric: "fwd + train-step"), same batch per GPU: fp32 plan
-    # (`train_step`) and bf16 plan (`train_step_bf16`, BASELINE.json configs[2]/[3]: bf16 storage + bf16 MFMA, fp32 masters)
+    # ---- headline: configs[1] ---------------------------------------------------------------------------------------------------------
+    elapsed = time_forward(model, x, args.steps, args.warmup)
+    roof, whole, kernels, n_kernels = inference_profile(eng, x, args.profile_steps, MFMA_F32_PEAK_TFLOPS)
+    ms_per_step = elapsed / args.steps * 1e3
+    whole["frac_of_roofline"] = round(whole["roofline_bound_ms"] / ms_per_step, 4)
+
+    # ---- the train step (BASELINE.json metric: "fwd + train-step"): fp32 plan and bf16 plan (configs[2]; configs[3] at N = 8) ---------
     train, train_bf16 = None, None
     if args.train_steps > 0:
-        from fastdepth_hip.train import TrainEngine
-        import models
-
-        def time_train(dtype, tag):
-            torch.manual_seed(0)
-            tm = models.MobileNetSkipAdd((224, 224), pretrained=False)
-            tm.decode_conv6[1].bias.data.fill_(2.8)
-            tm = tm.to(dev).train()
-            teng = TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
-                               force_buckets=os.environ.get("FD_BENCH_FORCE_DIST") == "1", dtype=dtype)
-            gt = torch.Generator().manual_seed(1)
-            tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=gt)).to(dev)     # synthetic depth, U[0.7, 10) m
-            for _ in range(3):
-                loss = teng.step(x, tgt)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.train_steps):
-                loss = teng.step(x, tgt)
-            torch.cuda.synchronize()
-            t_el = time.perf_counter() - t1
-            barrier()
-            tt = torch.tensor([t_el], dtype=torch.float64, device=dev)
-            if dist is not None:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_el = float(tt.item())
-            assert torch.isfinite(loss).all()
-            return {"metric": "frames/sec (224x224) train step: fwd + L1 loss + bwd + gradient all-reduce + SGD(momentum, wd)",
-                    "value": round(world * args.batch * args.train_steps / t_el, 1), "unit": "frames/s", "steps": args.train_steps, "warmup": 3,
-                    "ms_per_step": round(t_el / args.train_steps * 1e3, 4), "dtype": tag, "batch_per_gpu": args.batch,
-                    "parallelism": "dp%d (RCCL all-reduce of the 15.84 MB fp32 gradient vector, %d buckets overlapped with backward)" % (world, len(teng.buckets))
-                                   if world > 1 else "single GPU", "final_loss": round(float(loss), 5)}
-
         try:
-            train = time_train(torch.float32, "f32")
-            train_bf16 = time_train(torch.bfloat16, "bf16 storage + bf16 MFMA, fp32 accumulate / master weights / statistics")
+            train = time_train(torch.float32, "f32", args.train_steps)
+            train_bf16 = time_train(torch.bfloat16, "bf16 storage + bf16 MFMA, fp32 accumulate / master weights / statistics", args.train_steps)
         except Exception as e:       # the headline line must survive a failure of the secondary measurement
             train = train or {"error": repr(e)}
             train_bf16 = train_bf16 or {"error": repr(e)}
 
-    # ---- other BASELINE.json configurations, measured briefly on rank 0 only (N=1): parity for them is in tests/test_gpu_parity.py
+    # ---- other BASELINE.json configurations, N = 1 only: parity for them is in tests/test_gpu_parity.py ------------------------------
     extras = []
     if args.extra_steps > 0 and world == 1:
-        import models
-
-        def timed(mod, xin, steps, fn=None):
-            fn = fn or (lambda: mod(xin))
-            with torch.no_grad():
-                for _ in range(5):
-                    fn()
-                torch.cuda.synchronize()
-                t0_ = time.perf_counter()
-                for _ in range(steps):
-                    fn()
-                torch.cuda.synchronize()
-            return (time.perf_counter() - t0_) / steps
-
-        torch.manual_seed(0)
-        pm = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS).eval().to(dev)
+        pm = build_model(dev, pruned=True)
         x64 = torch.rand(64, 3, 224, 224, generator=g).to(dev)
         pm.set_compute_dtype(torch.float16)
-        dt = timed(pm, x64, args.extra_steps)
+        dt = time_forward(pm, x64, args.extra_steps, 5) / args.extra_steps
+        r64, w64, _, _ = inference_profile(pm._engine(), x64, 3, MFMA_H16_PEAK_TFLOPS)
+        w64["frac_of_roofline"] = round(w64["roofline_bound_ms"] / (dt * 1e3), 4)
         extras.append({"config": "configs[4]: pruned plan (mobilenet-nnconv5dw-skipadd-pruned), batch=64, fp16 storage / fp32 accumulate, inference",
-                       "value": round(64 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f16"})
+                       "value": round(64 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f16", "roofline": r64, "whole_step": w64})
+        del pm
         for dtype, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
             model.set_compute_dtype(dtype)
-            dt = timed(model, x, args.extra_steps)
+            dt = time_forward(model, x, args.extra_steps, 5) / args.extra_steps
+            r16, w16, _, _ = inference_profile(eng, x, 3, MFMA_H16_PEAK_TFLOPS)
+            w16["frac_of_roofline"] = round(w16["roofline_bound_ms"] / (dt * 1e3), 4)
             extras.append({"config": "unpruned, batch=32, %s storage / fp32 accumulate, inference" % tag, "value": round(args.batch / dt, 1),
-                           "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": tag})
+                           "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": tag, "roofline": r16, "whole_step": w16})
         model.set_compute_dtype(torch.float32)
         x1 = x[:1].contiguous()
-        dt = timed(model, x1, args.extra_steps, fn=lambda: eng.forward_graph(x1))
-        extras.append({"config": "unpruned, batch=1, fp32, hipGraph replay (latency; the reference publishes 5.6 ms for the PRUNED model on a Jetson TX2)",
+        dt = time_forward(model, x1, args.extra_steps, 5, fn=lambda: eng.forward_graph(x1)) / args.extra_steps
+        extras.append({"config": "configs[0] on the GPU: unpruned, batch=1, fp32, hipGraph replay (latency; the reference publishes 5.6 ms for the PRUNED model on a Jetson TX2)",
                        "value": round(1 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f32"})
-        del pm
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "frames/sec (224x224) MobileNet-NNConv5dw-skipadd inference forward",
             "value": round(world * args.batch * args.steps / elapsed, 1), "unit": "frames/s",
@@ -260,18 +500,20 @@ def main():
             "config": {"workload": "configs[1]: MobileNet-NNConv5(dw)+skipadd unpruned, batch=32 per GPU, 224x224 fp32 "
                                    "inference forward, inputs resident in HBM", "batch_per_gpu": args.batch,
                        "global_batch": world * args.batch, "parallelism": "frames sharded over %d GPU(s), no collective" % world,
-                       "kernels_per_step": len(stats)},
+                       "kernels_per_step": n_kernels, "rccl_ranks": world if dist is not None else 0},
             "roofline": roof,
-            "whole_step": {"algorithmic_GB": round(total_bytes / 1e9, 4), "algorithmic_GFLOP": round(total_flops / 1e9, 3),
-                           "device_ms_sum_of_kernels": round(float(acc.sum()), 4),
-                           "roofline_bound_ms": None},
+            "whole_step": whole,
             "kernels": kernels,
             "train_step": train,
             "train_step_bf16": train_bf16,
             "other_configs": extras,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            try:
+                line["train_check"] = train_check(dev)
+            except Exception as e:
+                line["train_check"] = {"error": repr(e)}
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

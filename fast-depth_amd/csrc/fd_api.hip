@@ -34,12 +34,23 @@ thread_local std::string g_err;
 // launch-gap and event-record overhead that bracketing with hipEventRecord would add.
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
+// fd_trace_begin / fd_trace_end (measurement aid): every launch between the two carries its own begin/end events and is recorded with
+// the source name of its kernel and the layer it belongs to (g_trace_layer, set by the layer loops; -1 outside them).
+thread_local int g_trace_layer = -1;
 #ifdef FD_EMU
 #define FD_LAUNCH(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)
 #else
+struct TraceRec { const char *name; int layer; hipEvent_t e0, e1; };
+thread_local bool g_trace_on = false;
+thread_local std::vector<TraceRec> g_trace;
 #define FD_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
     do {                                                                                                        \
-        if (g_ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
+        if (g_trace_on) {                                                                                       \
+            TraceRec tr_{#kernel, g_trace_layer, nullptr, nullptr};                                             \
+            (void)hipEventCreate(&tr_.e0); (void)hipEventCreate(&tr_.e1);                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tr_.e0, tr_.e1, 0, __VA_ARGS__);           \
+            g_trace.push_back(tr_);                                                                             \
+        } else if (g_ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
     } while (0)
 #endif
@@ -697,12 +708,146 @@ int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)
     if (!plan || !x_nchw || !y) return fail(FD_ERR_INVALID, "null argument");
     if (!plan->ws || !plan->packed) return fail(FD_ERR_STATE, "plan needs a bound workspace and packed weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    for (const Layer &L : plan->layers) {
+    for (size_t i = 0; i < plan->layers.size(); ++i) {
+        const Layer &L = plan->layers[i];
         if (L.skipped) continue;
+        g_trace_layer = (int)i;
         int rc = run_layer(plan, L, static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
         if (rc) return rc;
     }
+    g_trace_layer = -1;
     return FD_OK;
+}
+
+/* ---- deploy bundle: layer descriptions + packed (BatchNorm-folded) weights, self-describing, loadable with no Python.  The analogue of the
+ * reference's TVM artefacts deploy_graph.json + deploy_param.params (deploy/tx2_run_tvm.py:13-20). ---- */
+namespace {
+struct BundleHeader {
+    char magic[8];            // "FDPLAN1\0"
+    uint32_t header_bytes, n_layers;
+    int32_t batch, height, width, dtype;
+    uint32_t flags, desc_bytes;
+    uint64_t weights_bytes;   // the packed-weight region of the workspace, bit for bit
+};
+const char kBundleMagic[8] = {'F', 'D', 'P', 'L', 'A', 'N', '1', 0};
+}  // namespace
+
+size_t fd_plan_export_bytes(const fd_plan *plan)
+{
+    return plan ? sizeof(BundleHeader) + plan->layers.size() * sizeof(fd_layer_desc) + plan->weights_bytes : 0;
+}
+
+int fd_plan_export(const fd_plan *plan, void *host_buffer, size_t bytes, void *stream)
+{
+    if (!plan || !host_buffer) return fail(FD_ERR_INVALID, "null argument");
+    if (!plan->ws || !plan->packed) return fail(FD_ERR_STATE, "export needs a bound workspace with packed weights");
+    if (bytes < fd_plan_export_bytes(plan)) return fail(FD_ERR_INVALID, "export buffer too small: %zu < %zu", bytes, fd_plan_export_bytes(plan));
+    BundleHeader h{};
+    memcpy(h.magic, kBundleMagic, 8);
+    h.header_bytes = sizeof(BundleHeader); h.n_layers = (uint32_t)plan->layers.size();
+    h.batch = plan->B; h.height = plan->H; h.width = plan->W; h.dtype = plan->dtype;
+    h.flags = plan->flags & ~FD_PLAN_KEEP_ACTIVATIONS; h.desc_bytes = sizeof(fd_layer_desc); h.weights_bytes = plan->weights_bytes;
+    unsigned char *o = static_cast<unsigned char *>(host_buffer);
+    memcpy(o, &h, sizeof h); o += sizeof h;
+    for (const Layer &L : plan->layers) { memcpy(o, &L.d, sizeof(fd_layer_desc)); o += sizeof(fd_layer_desc); }
+#ifdef FD_EMU
+    (void)stream;
+    memcpy(o, plan->ws, plan->weights_bytes);
+#else
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(o, plan->ws, plan->weights_bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return fail(FD_ERR_HIP, "copying the packed weights to the host failed");
+#endif
+    return FD_OK;
+}
+
+int fd_plan_import(const void *host_buffer, size_t bytes, int32_t batch_override, fd_plan **out_plan)
+{
+    if (!host_buffer || !out_plan) return fail(FD_ERR_INVALID, "null argument");
+    BundleHeader h{};
+    if (bytes < sizeof h) return fail(FD_ERR_INVALID, "not a deploy bundle (too short)");
+    memcpy(&h, host_buffer, sizeof h);
+    if (memcmp(h.magic, kBundleMagic, 8) || h.header_bytes != sizeof h || h.desc_bytes != sizeof(fd_layer_desc))
+        return fail(FD_ERR_INVALID, "not a deploy bundle of this library version");
+    if (bytes < sizeof h + (size_t)h.n_layers * sizeof(fd_layer_desc) + h.weights_bytes) return fail(FD_ERR_INVALID, "truncated deploy bundle");
+    std::vector<fd_layer_desc> descs(h.n_layers);
+    memcpy(descs.data(), static_cast<const unsigned char *>(host_buffer) + sizeof h, (size_t)h.n_layers * sizeof(fd_layer_desc));
+    // the packed weights do not depend on the batch size: a bundle exported at one batch serves any other
+    fd_plan *p = nullptr;
+    int rc = fd_plan_create(descs.data(), (int32_t)h.n_layers, batch_override > 0 ? batch_override : h.batch, h.height, h.width, h.dtype, h.flags, &p);
+    if (rc) return rc;
+    if (p->weights_bytes != h.weights_bytes) { fd_plan_destroy(p); return fail(FD_ERR_INVALID, "bundle weight layout (%llu bytes) does not match this library (%zu)", (unsigned long long)h.weights_bytes, p->weights_bytes); }
+    *out_plan = p;
+    return FD_OK;
+}
+
+int fd_plan_import_weights(fd_plan *plan, const void *host_buffer, size_t bytes, void *stream)
+{
+    if (!plan || !host_buffer) return fail(FD_ERR_INVALID, "null argument");
+    if (!plan->ws) return fail(FD_ERR_STATE, "bind a workspace before loading the bundle's weights");
+    BundleHeader h{};
+    if (bytes < sizeof h) return fail(FD_ERR_INVALID, "not a deploy bundle (too short)");
+    memcpy(&h, host_buffer, sizeof h);
+    if (memcmp(h.magic, kBundleMagic, 8) || h.weights_bytes != plan->weights_bytes || h.n_layers != plan->layers.size())
+        return fail(FD_ERR_INVALID, "bundle does not belong to this plan");
+    const unsigned char *w = static_cast<const unsigned char *>(host_buffer) + sizeof h + (size_t)h.n_layers * sizeof(fd_layer_desc);
+    if (bytes < (size_t)(w - static_cast<const unsigned char *>(host_buffer)) + h.weights_bytes) return fail(FD_ERR_INVALID, "truncated deploy bundle");
+#ifdef FD_EMU
+    (void)stream;
+    memcpy(plan->ws, w, h.weights_bytes);
+#else
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(plan->ws, w, h.weights_bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return fail(FD_ERR_HIP, "copying the packed weights to the device failed");
+    if (plan->sk_counter_bytes && hipMemsetAsync(plan->ws + plan->sk_counter_off, 0, plan->sk_counter_bytes, s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync failed");
+#endif
+    plan->packed = true;
+    return FD_OK;
+}
+
+int fd_plan_shape(const fd_plan *plan, int32_t *batch, int32_t *height, int32_t *width, int32_t *dtype)
+{
+    if (!plan) return fail(FD_ERR_INVALID, "null plan");
+    if (batch) *batch = plan->B;
+    if (height) *height = plan->H;
+    if (width) *width = plan->W;
+    if (dtype) *dtype = plan->dtype;
+    return FD_OK;
+}
+
+int fd_trace_begin(void)
+{
+#ifdef FD_EMU
+    return fail(FD_ERR_STATE, "kernel tracing needs the HIP build");
+#else
+    for (auto &t : g_trace) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    g_trace.clear();
+    g_trace_on = true;
+    return FD_OK;
+#endif
+}
+
+int fd_trace_end(void *stream, fd_trace_record *records, int32_t max_records, int32_t *n_records)
+{
+#ifdef FD_EMU
+    (void)stream; (void)records; (void)max_records; (void)n_records;
+    return fail(FD_ERR_STATE, "kernel tracing needs the HIP build");
+#else
+    if (!g_trace_on) return fail(FD_ERR_STATE, "fd_trace_end without fd_trace_begin");
+    g_trace_on = false;
+    int rc = FD_OK;
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(FD_ERR_HIP, "synchronisation failed");
+    const int n = (int)g_trace.size();
+    if (n_records) *n_records = n;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.0f;
+        if (rc == FD_OK && hipEventElapsedTime(&ms, g_trace[i].e0, g_trace[i].e1) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
+        if (records && i < max_records) { records[i].kernel = g_trace[i].name; records[i].layer = g_trace[i].layer; records[i].ms = ms; }
+        (void)hipEventDestroy(g_trace[i].e0); (void)hipEventDestroy(g_trace[i].e1);
+    }
+    g_trace.clear();
+    return rc;
+#endif
 }
 
 int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, float *ms_per_layer, int32_t n_layers)

@@ -179,9 +179,11 @@ fd_l1_loss_final_f32(const float *__restrict__ part, int nblk, float inv_numel, 
 __global__ void __launch_bounds__(256)
 fd_depth_metrics_f32(const float *__restrict__ output, const float *__restrict__ target, long numel, double *__restrict__ part)
 {
+    // blockIdx.y = frame (numel elements each): the reference evaluates one image at a time (main.py:40-41 batch size 1, :80-82)
     __shared__ double red[4][10];
     double s[10];
     for (int k = 0; k < 10; ++k) s[k] = 0.0;
+    output += (long)blockIdx.y * numel; target += (long)blockIdx.y * numel;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
         const float ov = output[i], tv = target[i];
         if (tv > 0.0f || ov > 0.0f) {
@@ -209,15 +211,15 @@ fd_depth_metrics_f32(const float *__restrict__ output, const float *__restrict__
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 10) part[(long)blockIdx.x * 10 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 10) part[((long)blockIdx.y * gridDim.x + blockIdx.x) * 10 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __global__ void __launch_bounds__(64)
 fd_depth_metrics_final_f32(const double *__restrict__ part, int nblk, double *__restrict__ sums)
 {
-    if (threadIdx.x < 10) {
+    if (threadIdx.x < 10) {                                  // blockIdx.x = frame
         double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part[(long)b * 10 + threadIdx.x];
-        sums[threadIdx.x] = s;
+        for (int b = 0; b < nblk; ++b) s += part[((long)blockIdx.x * nblk + b) * 10 + threadIdx.x];
+        sums[(long)blockIdx.x * 10 + threadIdx.x] = s;
     }
 }
 

@@ -267,6 +267,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
     TLayer &Hd = plan->layers[hi];
     TLayer &Hp = plan->layers[Hd.d.src];
     if (from_layer == hi) {
+        g_trace_layer = hi;
         const int nb = ceil_div(Hd.M, 256);
         if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
         else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
@@ -291,6 +292,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         TLayer &L = plan->layers[i];
         const fd_layer_desc &d = L.d;
         int nblk = 0;
+        g_trace_layer = i;
         switch (d.op) {
         case FD_OP_STEM: {
             const int nb_w = std::min(L.nblk, 512);          // workgroups walk the 256-pixel blocks grid-stride
@@ -323,6 +325,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         }
         }
     }
+    g_trace_layer = -1;
     return FD_OK;
 }
 
@@ -372,6 +375,21 @@ int fd_depth_metrics(const void *output, const void *target, int64_t numel, doub
     int rc = check_launch("fd_depth_metrics_f32");
     if (rc) return rc;
     FD_LAUNCH(fd_depth_metrics_final_f32, dim3(1), dim3(64), 0, s, static_cast<const double *>(scratch), nb, sums_device);
+    return check_launch("fd_depth_metrics_final_f32");
+}
+
+size_t fd_depth_metrics_frames_scratch_bytes(int32_t n_frames) { return (size_t)std::max(n_frames, 1) * 64 * 10 * sizeof(double); }
+
+int fd_depth_metrics_frames(const void *output, const void *target, int32_t n_frames, int64_t frame_numel, double *sums_device, void *scratch, void *stream)
+{
+    if (!output || !target || !sums_device || !scratch || n_frames <= 0 || frame_numel <= 0) return fail(FD_ERR_INVALID, "null argument / empty batch");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::min<int64_t>(64, (frame_numel + 255) / 256);
+    FD_LAUNCH(fd_depth_metrics_f32, dim3(nb, n_frames), dim3(256), 0, s, static_cast<const float *>(output), static_cast<const float *>(target), (long)frame_numel,
+              static_cast<double *>(scratch));
+    int rc = check_launch("fd_depth_metrics_f32");
+    if (rc) return rc;
+    FD_LAUNCH(fd_depth_metrics_final_f32, dim3(n_frames), dim3(64), 0, s, static_cast<const double *>(scratch), nb, sums_device);
     return check_launch("fd_depth_metrics_final_f32");
 }
 

@@ -40,6 +40,10 @@ class LayerGrads(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias")]
 
 
+class TraceRecord(ctypes.Structure):
+    _fields_ = [("kernel", ctypes.c_char_p), ("layer", ctypes.c_int32), ("ms", ctypes.c_float)]
+
+
 class SgdTensor(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("momentum_buf", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 
@@ -114,6 +118,24 @@ def load(path=None):
     lib.fd_depth_metrics_scratch_bytes.restype = ctypes.c_size_t
     lib.fd_depth_metrics.argtypes = [vp, vp, ctypes.c_int64, vp, vp, vp]
     lib.fd_depth_metrics.restype = ctypes.c_int
+    lib.fd_depth_metrics_frames_scratch_bytes.argtypes = [i32]
+    lib.fd_depth_metrics_frames_scratch_bytes.restype = ctypes.c_size_t
+    lib.fd_depth_metrics_frames.argtypes = [vp, vp, i32, ctypes.c_int64, vp, vp, vp]
+    lib.fd_depth_metrics_frames.restype = ctypes.c_int
+    lib.fd_plan_export_bytes.argtypes = [vp]
+    lib.fd_plan_export_bytes.restype = ctypes.c_size_t
+    lib.fd_plan_export.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.fd_plan_export.restype = ctypes.c_int
+    lib.fd_plan_import.argtypes = [vp, ctypes.c_size_t, i32, ctypes.POINTER(vp)]
+    lib.fd_plan_import.restype = ctypes.c_int
+    lib.fd_plan_import_weights.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    lib.fd_plan_import_weights.restype = ctypes.c_int
+    lib.fd_plan_shape.argtypes = [vp] + [ctypes.POINTER(i32)] * 4
+    lib.fd_plan_shape.restype = ctypes.c_int
+    lib.fd_trace_begin.argtypes = []
+    lib.fd_trace_begin.restype = ctypes.c_int
+    lib.fd_trace_end.argtypes = [vp, ctypes.POINTER(TraceRecord), i32, ctypes.POINTER(i32)]
+    lib.fd_trace_end.restype = ctypes.c_int
     lib.fd_last_error.restype = ctypes.c_char_p
     lib.fd_version.restype = ctypes.c_char_p
     return lib
@@ -124,7 +146,9 @@ EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_p
            "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats",
            "fd_train_plan_create", "fd_train_plan_destroy", "fd_train_plan_workspace_bytes", "fd_train_plan_bind_workspace",
            "fd_train_forward", "fd_train_backward", "fd_train_backward_range", "fd_train_layer_tensor", "fd_l1_loss_scratch_bytes",
-           "fd_l1_loss", "fd_sgd_step", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics", "fd_last_error", "fd_version")
+           "fd_l1_loss", "fd_sgd_step", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
+           "fd_depth_metrics_frames_scratch_bytes", "fd_depth_metrics_frames", "fd_plan_export_bytes", "fd_plan_export",
+           "fd_plan_import", "fd_plan_import_weights", "fd_plan_shape", "fd_trace_begin", "fd_trace_end", "fd_last_error", "fd_version")
 
 
 def check(lib, rc, what):

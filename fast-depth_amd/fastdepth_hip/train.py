@@ -21,9 +21,27 @@ from .engine import lib
 from .plan import layers_of
 
 
+def _stream_ptr(device):
+    """torch's current HIP stream on `device` as the C ABI wants it (None on the CPU: only the tests' emulator build runs there)."""
+    return torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
+
+
+class _device_guard:
+    def __init__(self, device):
+        self.ctx = torch.cuda.device(device) if device.type == "cuda" else None
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 class _TrainPlan:
-    def __init__(self, layers, batch, height, width, device, dtype=torch.float32):
-        L = lib()
+    def __init__(self, layers, batch, height, width, device, dtype=torch.float32, L=None):
+        self.L = L = L or lib()
         n = len(layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in layers])
         handle = ctypes.c_void_p()
@@ -37,14 +55,14 @@ class _TrainPlan:
     def __del__(self):
         if getattr(self, "handle", None):
             try:
-                lib().fd_train_plan_destroy(self.handle)
+                self.L.fd_train_plan_destroy(self.handle)
             except Exception:
                 pass
             self.handle = None
 
 
-def _check_param(t, what):
-    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+def _check_param(t, what, allow_cpu=False):
+    if not ((t.is_cuda or allow_cpu) and t.dtype == torch.float32 and t.is_contiguous()):
         raise capi.FastDepthError("%s must be a contiguous float32 tensor on the GPU" % what)
 
 
@@ -52,7 +70,12 @@ class TrainCore:
     """Shared plumbing: parameter tables, flat gradient buffer (reverse layer order, so that finished buckets are
     contiguous slices), train plans per input shape."""
 
-    def __init__(self, model, dtype=torch.float32):
+    def __init__(self, model, dtype=torch.float32, _library=None):
+        # _library: TEST HOOK -- an already loaded C-ABI library to use instead of libfastdepth_hip.so.  The CPU test tier passes the
+        # emulator build (tests/hipemu) so that the host logic around the kernels (flat gradient buffer, buckets, all-reduce, SGD
+        # table) runs with world_size 2 on gloo; the product never sets it, and without it CPU tensors are rejected.
+        self.L = _library or lib()
+        self._emulated = _library is not None
         self.model = model
         if dtype not in (torch.float32, torch.bfloat16):
             raise capi.FastDepthError("train step storage type must be float32 or bfloat16 (fp16 gradients would need loss scaling)")
@@ -66,7 +89,7 @@ class TrainCore:
         for i in reversed(range(self.n)):
             l = self.layers[i]
             for kind, p in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias)):
-                _check_param(p, "%s.%s" % (l.name, kind))
+                _check_param(p, "%s.%s" % (l.name, kind), self._emulated)
                 self.param_list.append((i, kind, p))
         self.total = sum(p.numel() for _, _, p in self.param_list)
         self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -102,7 +125,7 @@ class TrainCore:
         for q, l in zip(params, self.layers):
             for name, t in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias),
                             ("bn_mean", l.bn.running_mean), ("bn_var", l.bn.running_var)):
-                _check_param(t, "%s.%s" % (l.name, name))
+                _check_param(t, "%s.%s" % (l.name, name), self._emulated)
                 setattr(q, name, t.data_ptr())
         return params
 
@@ -111,20 +134,20 @@ class TrainCore:
         key = (b, h, w, x.device.index, self.dtype)
         p = self.plans.get(key)
         if p is None:
-            p = self.plans[key] = _TrainPlan(self.layers, b, h, w, x.device, self.dtype)
+            p = self.plans[key] = _TrainPlan(self.layers, b, h, w, x.device, self.dtype, self.L)
         return p
 
     def forward(self, x):
-        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or not (x.is_cuda or self._emulated):
             raise capi.FastDepthError("expected a float32 [B,3,H,W] GPU tensor, got %s %s on %s" % (tuple(x.shape), x.dtype, x.device))
-        L = lib()
+        L = self.L
         x = x.contiguous()
         plan = self.plan_for(x)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _stream_ptr(x.device)
         y = torch.empty((x.shape[0], 1, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
         self._params = self.c_params()
         self._x = x                                # the stem's weight gradient re-reads the input in backward
-        with torch.cuda.device(x.device):
+        with _device_guard(x.device):
             capi.check(L, L.fd_train_forward(plan.handle, self._params, self.n, self.eps, self.bn_momentum, x.data_ptr(), y.data_ptr(), stream), "fd_train_forward")
             if self._nbt:
                 torch._foreach_add_(self._nbt, 1)
@@ -133,9 +156,9 @@ class TrainCore:
         return y
 
     def backward_range(self, dy, from_layer, to_layer):
-        L = lib()
-        stream = torch.cuda.current_stream(dy.device).cuda_stream
-        with torch.cuda.device(dy.device):
+        L = self.L
+        stream = _stream_ptr(dy.device)
+        with _device_guard(dy.device):
             capi.check(L, L.fd_train_backward_range(self._plan.handle, self._params, self.c_grads, self.n, dy.data_ptr(), from_layer, to_layer, stream),
                        "fd_train_backward_range")
 
@@ -223,8 +246,8 @@ class TrainEngine(TrainCore):
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4, force_buckets=False,
-                 dtype=torch.float32):
-        super().__init__(model, dtype)
+                 dtype=torch.float32, _library=None):
+        super().__init__(model, dtype, _library)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.group = process_group
         self.world = 1
@@ -243,39 +266,65 @@ class TrainEngine(TrainCore):
         self.layer_bytes = [4 * (self.layer_span[i][1] - self.layer_span[i][0]) for i in range(self.n)]
         self.use_comm = process_group is not None and (self.world > 1 or force_buckets)     # force_buckets: exercise the path on 1 rank
         self.buckets = make_buckets(self.layer_bytes, n_buckets if self.use_comm else 1)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.use_comm else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_comm and self.device.type == "cuda") else None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dpred = None
-        self._scratch = torch.empty(lib().fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
+        self._scratch = torch.empty(self.L.fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
+        self.last_comm_us = None                  # set by step(time_comm=True): device time of the all-reduces / of the whole step
 
     def bucket_slice(self, from_layer, to_layer):
         return self.flat_grad[self.layer_span[from_layer][0]:self.layer_span[to_layer][1]]
 
-    def step(self, x, target):
-        """One train step on this rank's (x, target); returns the local mean-L1 loss as a 1-element GPU tensor."""
-        L = lib()
+    def step(self, x, target, time_comm=False):
+        """One train step on this rank's (x, target); returns the local mean-L1 loss as a 1-element GPU tensor.
+        time_comm=True (measurement aid, synchronises): records HIP events around the step and around the side-stream all-reduces and
+        leaves (all-reduce us, step us, exposed us = step end - backward end) in self.last_comm_us."""
+        L = self.L
         pred = self.forward(x)
         target = target.contiguous()
         if self._dpred is None or self._dpred.shape != pred.shape:
             self._dpred = torch.empty_like(pred)
-        cur = torch.cuda.current_stream(self.device)
-        with torch.cuda.device(self.device):
+        on_gpu = self.device.type == "cuda"
+        cur = torch.cuda.current_stream(self.device) if on_gpu else None
+        sp = cur.cuda_stream if on_gpu else None
+        ev = None
+        if time_comm and on_gpu:
+            ev = {k: torch.cuda.Event(enable_timing=True) for k in ("bwd0", "bwd1", "c0", "c1", "end")}
+        with _device_guard(self.device):
             capi.check(L, L.fd_l1_loss(pred.data_ptr(), target.data_ptr(), self._dpred.data_ptr(), self.loss.data_ptr(), pred.numel(),
-                                       self._scratch.data_ptr(), cur.cuda_stream), "fd_l1_loss")
+                                       self._scratch.data_ptr(), sp), "fd_l1_loss")
+            if ev:
+                ev["bwd0"].record(cur)
             works = []
-            for from_layer, to_layer in self.buckets:
+            for bi, (from_layer, to_layer) in enumerate(self.buckets):
                 self.backward_range(self._dpred, from_layer, to_layer)
                 if self.use_comm:
-                    ev = torch.cuda.Event()
-                    ev.record(cur)
-                    self.comm_stream.wait_event(ev)
-                    with torch.cuda.stream(self.comm_stream):
+                    if on_gpu:
+                        done = torch.cuda.Event()
+                        done.record(cur)
+                        self.comm_stream.wait_event(done)
+                        with torch.cuda.stream(self.comm_stream):
+                            if ev and bi == 0:
+                                ev["c0"].record(self.comm_stream)
+                            works.append(self.dist.all_reduce(self.bucket_slice(from_layer, to_layer), group=self.group, async_op=True))
+                    else:
                         works.append(self.dist.all_reduce(self.bucket_slice(from_layer, to_layer), group=self.group, async_op=True))
+            if ev:
+                ev["bwd1"].record(cur)
             if self.use_comm:
                 for w in works:
-                    w.wait()                       # makes the current stream wait for the collective (no host sync)
-                cur.wait_stream(self.comm_stream)
+                    w.wait()                       # makes the current stream wait for the collective (no host sync on the GPU)
+                if on_gpu:
+                    if ev:
+                        with torch.cuda.stream(self.comm_stream):
+                            ev["c1"].record(self.comm_stream)
+                    cur.wait_stream(self.comm_stream)
             capi.check(L, L.fd_sgd_step(self.sgd_table.data_ptr(), len(self.param_list), self.total, self.lr, self.momentum, self.weight_decay,
-                                        1.0 / self.world, int(self.steps == 0), cur.cuda_stream), "fd_sgd_step")
+                                        1.0 / self.world, int(self.steps == 0), sp), "fd_sgd_step")
+            if ev:
+                ev["end"].record(cur)
+                torch.cuda.synchronize(self.device)
+                comm = ev["c0"].elapsed_time(ev["c1"]) * 1e3 if self.use_comm else 0.0
+                self.last_comm_us = (comm, ev["bwd0"].elapsed_time(ev["end"]) * 1e3, ev["bwd1"].elapsed_time(ev["end"]) * 1e3)
         self.steps += 1
         return self.loss

@@ -37,22 +37,18 @@ class Result(object):
         self._fill(dict(zip(_MEASURES, args)), args[-2], args[-1])
 
     def evaluate(self, output, target):
-        """Same definitions as reference metrics.py:31-55 (valid = target>0 or output>0, millimetres, delta_k thresholds 1.25^k)."""
-        from fastdepth_hip import capi
-        from fastdepth_hip.engine import lib
+        """Same definitions as reference metrics.py:31-55 (valid = target>0 or output>0, millimetres, delta_k thresholds 1.25^k), over
+        all elements of the two tensors -- like the reference, which is only ever handed one image; per-image results of a batch:
+        evaluate_frames."""
         if not (output.is_cuda and target.is_cuda):
             raise RuntimeError("fast-depth_amd metrics run on the GPU only (no CPU path in this package)")
         o = output.detach().float().contiguous()
         t = target.detach().float().contiguous()
         if o.numel() != t.numel():
             raise ValueError("output and target must have the same number of elements")
-        L = lib()
-        sums = torch.empty(10, dtype=torch.float64, device=o.device)
-        scratch = torch.empty(L.fd_depth_metrics_scratch_bytes(), dtype=torch.uint8, device=o.device)
-        with torch.cuda.device(o.device):
-            capi.check(L, L.fd_depth_metrics(o.data_ptr(), t.data_ptr(), o.numel(), sums.data_ptr(), scratch.data_ptr(),
-                                             torch.cuda.current_stream(o.device).cuda_stream), "fd_depth_metrics")
-        s = sums.cpu().numpy()                      # the single synchronisation
+        self._from_sums(_device_sums(o, t, 1)[0])
+
+    def _from_sums(self, s):
         n = s[0]
         self.mse = float(s[1] / n)
         self.rmse = math.sqrt(self.mse)
@@ -64,6 +60,32 @@ class Result(object):
         self.gpu_time = 0
         self.irmse = math.sqrt(s[8] / n)
         self.imae = float(s[9] / n)
+        return self
+
+    @staticmethod
+    def evaluate_frames(output, target):
+        """One Result per image of a batch [B, ...]: what the reference's loop computes with its batch size of 1 (main.py:40-41,
+        80-82 -- RMSE / iRMSE of pooled pixels differ from the mean of the per-image values), still as ONE device reduction and
+        one (B x 80-byte) copy."""
+        if not (output.is_cuda and target.is_cuda):
+            raise RuntimeError("fast-depth_amd metrics run on the GPU only (no CPU path in this package)")
+        o = output.detach().float().contiguous()
+        t = target.detach().float().contiguous()
+        if o.shape != t.shape or o.dim() < 2:
+            raise ValueError("output and target must be batches of the same shape")
+        return [Result()._from_sums(s) for s in _device_sums(o, t, o.shape[0])]
+
+
+def _device_sums(o, t, n_frames):
+    from fastdepth_hip import capi
+    from fastdepth_hip.engine import lib
+    L = lib()
+    sums = torch.empty((n_frames, 10), dtype=torch.float64, device=o.device)
+    scratch = torch.empty(L.fd_depth_metrics_frames_scratch_bytes(n_frames), dtype=torch.uint8, device=o.device)
+    with torch.cuda.device(o.device):
+        capi.check(L, L.fd_depth_metrics_frames(o.data_ptr(), t.data_ptr(), n_frames, o.numel() // n_frames, sums.data_ptr(), scratch.data_ptr(),
+                                                torch.cuda.current_stream(o.device).cuda_stream), "fd_depth_metrics_frames")
+    return sums.cpu().numpy()                   # the single synchronisation
 
 
 class AverageMeter(object):

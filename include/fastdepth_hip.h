@@ -110,6 +110,26 @@ int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream);
  * bench.py's roofline report; not for production calls. */
 int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, float *ms_per_layer, int32_t n_layers);
 
+/* Deploy bundle: the plan's layer descriptions plus its packed, BatchNorm-folded weights in one self-describing
+ * host buffer -- the analogue of the TVM artefacts the reference's runner loads (deploy/tx2_run_tvm.py:13-20: deploy_graph.json +
+ * deploy_param.params).  A C program needs nothing else: fd_plan_import -> fd_plan_workspace_bytes -> hipMalloc ->
+ * fd_plan_bind_workspace -> fd_plan_import_weights -> fd_forward (examples/run_bundle.cpp).  The packed weights do not depend on the
+ * batch size: batch_override > 0 re-plans the bundle for another batch. */
+size_t fd_plan_export_bytes(const fd_plan *plan);
+int fd_plan_export(const fd_plan *plan, void *host_buffer, size_t bytes, void *stream);
+int fd_plan_import(const void *host_buffer, size_t bytes, int32_t batch_override, fd_plan **out_plan);
+int fd_plan_import_weights(fd_plan *plan, const void *host_buffer, size_t bytes, void *stream);
+int fd_plan_shape(const fd_plan *plan, int32_t *batch, int32_t *height, int32_t *width, int32_t *dtype);
+
+/* Measurement aid for bench.py's roofline report (inference AND train step): between fd_trace_begin() and fd_trace_end() every kernel
+ * this thread launches through the library carries its own begin/end HIP events (hipExtLaunchKernelGGL -- the quantity rocprofv3's
+ * kernel trace reports).  fd_trace_end synchronises, fills up to max_records records in launch order and returns the total number of
+ * launches in *n_records.  `kernel` is the source spelling of the launched kernel (a string owned by the library), `layer` the index of
+ * the fused layer it belongs to (-1: loss, SGD, weight packing).  Not for production calls. */
+typedef struct fd_trace_record { const char *kernel; int32_t layer; float ms; } fd_trace_record;
+int fd_trace_begin(void);
+int fd_trace_end(void *stream, fd_trace_record *records, int32_t max_records, int32_t *n_records);
+
 /* Test hook: where layer `layer`'s output lives (NHWC, plan dtype).  Valid after fd_forward on a
  * plan created with FD_PLAN_KEEP_ACTIVATIONS. */
 int fd_layer_output(const fd_plan *plan, int32_t layer, const void **device_ptr, int32_t *n, int32_t *h,
@@ -205,6 +225,13 @@ int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t 
 
 size_t fd_depth_metrics_scratch_bytes(void);
 int fd_depth_metrics(const void *output, const void *target, int64_t numel, double *sums_device, void *scratch, void *stream);
+
+/* The same ten sums PER FRAME: output / target hold n_frames images of frame_numel elements each, sums_device = n_frames x 10 doubles.
+ * The reference evaluates one image at a time and averages the per-image metrics (main.py:40-41 batch size 1, :80-82) -- RMSE and
+ * iRMSE of a pooled batch differ from the mean of the per-image values -- so a batched evaluation loop needs the sums per image. */
+size_t fd_depth_metrics_frames_scratch_bytes(int32_t n_frames);
+int fd_depth_metrics_frames(const void *output, const void *target, int32_t n_frames, int64_t frame_numel, double *sums_device,
+                            void *scratch, void *stream);
 
 const char *fd_last_error(void);
 const char *fd_version(void);

@@ -100,6 +100,20 @@ def randomize_bn(model, seed):
     return model
 
 
+def saturate_encoder(model, gain=4.0):
+    """Encoder BatchNorm gamma x gain (the recipe of oracle/make_golden.py's `sat6` variant): with batch statistics the
+    post-BN values are ~N(beta, gain^2), so for gain 4 about 7 % of every ReLU6 unit's outputs sit on the clamp at 6 and the `y < 6`
+    side of the backward mask (reference imagenet/mobilenet.py:16-20) is really exercised."""
+    for i in range(14):
+        for mod in getattr(model, "conv%d" % i):
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.data.mul_(gain)
+    return model
+
+
+LAST_SAT6_FRAC = None      # fraction of ReLU6-unit pre-activations >= 6 seen by the last train_parity_report / local_train_parity call
+
+
 def compare_with_oracle(kind, model, x, device, dtype=torch.float32, flags=0):
     """Runs the C ABI path and the C oracle on the same weights/input; returns (rel err of the output,
     [rel err per fused layer], plan info)."""
@@ -206,6 +220,7 @@ def train_parity_report(kind, model, x, target, device, dtype=torch.float32, kin
     y = tp.forward(x.to(device)).cpu()
     rep = {"pred_err": rel_err(y.numpy(), pred64.numpy()), "tensors": {}, "running": 0.0, "y_err": 0.0, "mask_flips": 0, "bad_flips": 0}
     masks = []
+    n_sat = n_relu6 = 0
     for i, (cp, bp, _, _, act) in enumerate(names):
         z = tp.tensor(i, 0).double()
         st = tp.tensor(i, 2).double()[0, :, :, 0].t()          # memory is [4][C]; tensor() hands it back as (1, C, 4, 1)
@@ -216,6 +231,8 @@ def train_parity_report(kind, model, x, target, device, dtype=torch.float32, kin
         scale = float(yr.abs().max())
         rep["y_err"] = max(rep["y_err"], float((yo - yr).abs().max()) / scale)
         lo, hi = yo > 0, (yo < 6) if act == oracle.ACT_RELU6 else torch.ones_like(yo, dtype=torch.bool)
+        if act == oracle.ACT_RELU6:
+            n_sat += int((yo >= 6).sum()); n_relu6 += yo.numel()
         lo_r, hi_r = yr > 0, (yr < 6) if act == oracle.ACT_RELU6 else torch.ones_like(yr, dtype=torch.bool)
         flips = (lo != lo_r) | (hi != hi_r)
         rep["mask_flips"] += int(flips.sum())
@@ -224,6 +241,8 @@ def train_parity_report(kind, model, x, target, device, dtype=torch.float32, kin
         if i == 37 and bn64[i].shape[-1] == 2 * yo.shape[-1]:
             lo, hi = lo.repeat_interleave(2, 2).repeat_interleave(2, 3), hi.repeat_interleave(2, 2).repeat_interleave(2, 3)
         masks.append((lo, hi))
+    global LAST_SAT6_FRAC
+    LAST_SAT6_FRAC = n_sat / max(n_relu6, 1)
     # backward with identical masks and identical dLoss/dpred
     p64g = torch_ref.params_from_state(model.state_dict(), torch.float64, requires_grad=True)
     predm = torch_ref.forward(p64g, x.double(), train=True, masks=masks)
@@ -307,6 +326,9 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
         d = torch.minimum(yv.abs(), (yv - 6).abs()) if L[i].desc.act == FD_ACT_RELU6 else yv.abs()
         return d < 1e-5 * scale
 
+    global LAST_SAT6_FRAC
+    n_sat = sum(int((pre(i) >= 6).sum()) for i in range(n) if L[i].desc.act == FD_ACT_RELU6)
+    LAST_SAT6_FRAC = n_sat / max(sum(Z[i].numel() for i in range(n) if L[i].desc.act == FD_ACT_RELU6), 1)
     for i in range(n):
         d = L[i].desc
         head = d.op == FD_OP_PW and d.cout == 1

@@ -9,6 +9,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -90,6 +91,109 @@ def test_bucketed_allreduce_and_mean_sgd_world2(tmp_path):
         opt.step()
     for a, q in zip(p_rank0, ref):
         assert torch.allclose(a, q.detach(), rtol=1e-5, atol=1e-6)
+
+
+def _dp_case():
+    from test_emu_forward import TINY, small_model
+    m = small_model(TINY[0], TINY[1], seed=17)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(4, 3, 64, 64, generator=g)              # global batch 4 = 2 ranks x 2 frames
+    tgt = 2.0 + torch.rand(4, 1, 64, 64, generator=g)
+    return m, x, tgt
+
+
+def _engine_worker(rank, world, port, out):
+    """One data-parallel rank: the PRODUCT's TrainEngine (flat gradient buffer, reverse-layer buckets, bucket-by-bucket all-reduce,
+    fused SGD with grad_scale = 1/world) on the emulator build of the kernels, its own shard of the batch, two steps."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import harness
+    from fastdepth_hip.train import TrainEngine
+    m, x, tgt = _dp_case()
+    m.train()
+    eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=dist.group.WORLD, n_buckets=3, _library=harness.get_lib("emu"))
+    assert eng.use_comm and len(eng.buckets) == 3 and eng.world == world
+    per = x.shape[0] // world
+    xs, ts = x[rank * per:(rank + 1) * per], tgt[rank * per:(rank + 1) * per]
+    losses, after1 = [], None
+    for step in range(2):
+        losses.append(float(eng.step(xs, ts)))
+        if step == 0:
+            after1 = {k: v.clone() for k, v in m.state_dict().items()}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"after1": after1, "after2": {k: v.clone() for k, v in m.state_dict().items()}, "mom": eng.flat_mom.clone(), "losses": losses})
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_train_engine_dp_world2_matches_shard_averaged_oracle(tmp_path):
+    """Row e / SURVEY.md 8(e) "oracle for DP": run the reference restatement on each of the n shards (same weights, train mode), average
+    the gradients, take one SGD step -> compare with EVERY rank's post-step parameters.  Two references:
+      (1) the same kernels single-process (one engine per shard, gradients averaged by hand): the data-parallel plumbing must
+          reproduce that to rounding (the all-reduce only changes the order of one addition);
+      (2) the fp64 torch oracle per shard -> mean -> SGD: agreement at the level the single-GPU optimizer test accepts (the gradient of a
+          randomly initialised train-mode network is chaotic, tests/test_gpu_train.py).
+    BatchNorm statistics stay per replica (nn.DataParallel / DDP semantics, reference imagenet/mobilenet.py:68)."""
+    import copy
+    import harness
+    from fastdepth_hip import capi
+    from fastdepth_hip.train import TrainEngine
+    from oracle import torch_ref
+    out = str(tmp_path / "dp_engine.pt")
+    mp.spawn(_engine_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    base, x, tgt = _dp_case()
+    keys = [k for k, _ in base.named_parameters()]
+    s0 = {k: v.clone() for k, v in base.state_dict().items()}
+    # replicas stay bit-identical in everything that is all-reduced; running statistics are per replica and differ
+    for k in keys:
+        assert torch.equal(r[0]["after1"][k], r[1]["after1"][k]) and torch.equal(r[0]["after2"][k], r[1]["after2"][k]), k
+    assert torch.equal(r[0]["mom"], r[1]["mom"])
+    assert not torch.equal(r[0]["after1"]["conv3.1.running_mean"], r[1]["after1"]["conv3.1.running_mean"])
+    assert all(np.isfinite(v).all() for v in (r[0]["losses"], r[1]["losses"]))
+    # (1) same kernels, single process, gradients averaged by hand
+    L = harness.get_lib("emu")
+    flat = []
+    for rank in range(2):
+        m = copy.deepcopy(base).train()
+        eng = TrainEngine(m, _library=L)
+        xs, ts = x[2 * rank:2 * rank + 2], tgt[2 * rank:2 * rank + 2]
+        pred = eng.forward(xs)
+        dpred, loss = torch.empty_like(pred), torch.zeros(1)
+        scratch = torch.empty(L.fd_l1_loss_scratch_bytes(pred.numel()), dtype=torch.uint8)
+        capi.check(L, L.fd_l1_loss(pred.data_ptr(), ts.contiguous().data_ptr(), dpred.data_ptr(), loss.data_ptr(), pred.numel(), scratch.data_ptr(), None), "fd_l1_loss")
+        eng.backward(dpred)
+        assert float(loss) == pytest.approx(r[rank]["losses"][0], rel=1e-6)
+        flat.append((eng, eng.flat_grad.clone()))
+        for k in s0:                                                     # this replica's running statistics: bit-identical
+            if "running" in k:
+                assert torch.equal(m.state_dict()[k], r[rank]["after1"][k]), k
+    eng = flat[0][0]
+    gmean = (flat[0][1] + flat[1][1]) * 0.5
+    name_of = {id(q): k for k, q in eng.model.named_parameters()}
+    num = den = 0.0
+    for i, kind, q in eng.param_list:
+        view = eng.grad_views[(i, kind)]
+        off = (view.data_ptr() - eng.flat_grad.data_ptr()) // 4
+        g = gmean[off:off + view.numel()].view_as(view)
+        name = name_of[id(q)]
+        want = s0[name] - 0.01 * (g + 1e-4 * s0[name])                    # first SGD step: the momentum buffer starts as d
+        num += float(((r[0]["after1"][name].double() - want.double()) ** 2).sum()); den += float(((want.double() - s0[name].double()) ** 2).sum())
+    assert (num / den) ** 0.5 < 1e-5, (num / den) ** 0.5
+    # (2) fp64 oracle per shard -> mean -> SGD
+    p = torch_ref.params_from_state(base.state_dict(), torch.float64, requires_grad=True)
+    gsum = None
+    for rank in range(2):
+        pr = {k: (v.detach().clone().requires_grad_(v.requires_grad)) for k, v in p.items()}
+        _, grads = torch_ref.l1_train_grads(pr, x[2 * rank:2 * rank + 2].double(), tgt[2 * rank:2 * rank + 2].double())
+        gsum = grads if gsum is None else {k: gsum[k] + grads[k] for k in grads}
+    torch_ref.sgd_step(p, {k: v / 2 for k, v in gsum.items()}, {}, 0.01, 0.9, 1e-4)
+    num = den = 0.0
+    for k in keys:
+        da, db = r[1]["after1"][k].double() - s0[k].double(), p[k].detach() - s0[k].double()
+        num += float(((da - db) ** 2).sum()); den += float((db ** 2).sum())
+    assert (num / den) ** 0.5 < 0.05, (num / den) ** 0.5
 
 
 def test_make_buckets_covers_real_network():

@@ -161,7 +161,10 @@ def test_on_device_metrics_and_eval_harness(tmp_path):
     m, x, y_ref, meta = inputs.golden_case("base_s0")
     ck = str(tmp_path / "model_best.pth.tar")
     torch.save({"epoch": 7, "best_result": None, "model": m}, ck)
-    avg = fd_eval.main(["--evaluate", ck, "--batch-size", "4", "--repeat", "8", "-p", "1"])
+    sd = tmp_path / "samples"; sd.mkdir()
+    for i in range(8):                    # the reference's own NYU sample (tests/golden), eight times
+        np.savez(str(sd / ("s%d.npz" % i)), rgb=np.load(inputs.GOLD + "/sample_rgb_u8.npy"), depth=np.load(inputs.GOLD + "/sample_depth.npy"))
+    avg = fd_eval.main(["--evaluate", ck, "--samples", str(sd), "--batch-size", "4", "-p", "1"])
     want = meta["metrics_vs_sample_depth"]
     assert avg.rmse == pytest.approx(want["rmse"], rel=1e-4) and avg.delta1 == pytest.approx(want["delta1"], rel=1e-4)
 
@@ -270,3 +273,34 @@ def test_batch32_plan_selects_gemm16():
     info = plan.info()
     plan.close()
     assert sum("pw_gemm16" in s for s in info) >= 10, info
+
+
+def test_batched_evaluation_equals_per_image_protocol(tmp_path):
+    """The reference evaluates one image at a time and averages the per-image metrics (main.py:40-41 batch size 1, :80-82); RMSE / iRMSE
+    of pooled pixels are not that average.  fd_depth_metrics_frames gives the ten sums per image, so the harness at --batch-size 4
+    reports exactly what it reports at --batch-size 1, and the per-image values equal the numpy restatement of metrics.py:31-55."""
+    import sys
+    sys.path.insert(0, inputs.PKG)
+    import metrics as fd_metrics
+    import evaluate as fd_eval
+    from oracle import metrics as ometrics
+    g = np.random.default_rng(5)
+    for i in range(6):    # raw-style 224 x 224 frames with different depth statistics per image and some invalid pixels
+        rgb = g.random((224, 224, 3), dtype=np.float32)
+        depth = (0.7 + (2 + 1.5 * i) * g.random((224, 224), dtype=np.float32)).astype(np.float32)
+        depth[:5 * i] = 0.0
+        np.savez(str(tmp_path / ("f%d.npz" % i)), rgb=rgb, depth=depth)
+    a1 = fd_eval.main(["--samples", str(tmp_path), "--batch-size", "1", "-p", "100"])
+    a4 = fd_eval.main(["--samples", str(tmp_path), "--batch-size", "4", "-p", "100"])
+    for f in ("rmse", "mse", "mae", "absrel", "lg10", "irmse", "imae", "delta1", "delta2", "delta3"):
+        assert getattr(a4, f) == pytest.approx(getattr(a1, f), rel=1e-6), f
+    out = (torch.rand(3, 1, 64, 48, generator=torch.Generator().manual_seed(2)) * 4 + 0.2).cuda()
+    tgt = (torch.rand(3, 1, 64, 48, generator=torch.Generator().manual_seed(3)) * 4 + 0.2).cuda()
+    tgt[1, 0, :7] = 0.0; out[1, 0, :7] = 0.0
+    per = fd_metrics.Result.evaluate_frames(out, tgt)
+    for i, r in enumerate(per):
+        want = ometrics.evaluate(out[i].cpu().numpy(), tgt[i].cpu().numpy())
+        for k in ometrics.FIELDS:
+            assert getattr(r, k) == pytest.approx(want[k], rel=2e-5), (i, k)
+    pooled = fd_metrics.Result(); pooled.evaluate(out, tgt)
+    assert abs(pooled.rmse - np.mean([r.rmse for r in per])) > 1e-6        # the two protocols really differ
