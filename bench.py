@@ -443,10 +443,7 @@ def main():
         else:
             r = time_train(torch.float32 if args.only == "train_f32" else torch.bfloat16, args.only, args.steps)
             t = r["ms_per_step"] * args.steps / 1e3
-        if rank == 0:
-            print(json.dumps({"only": args.only, "steps": args.steps, "ms_per_step": round(t / args.steps * 1e3, 4), "n_gpus": world}))
-        if dist is not None:
-            dist.destroy_process_group()
+        finish(dist, {"only": args.only, "steps": args.steps, "ms_per_step": round(t / args.steps * 1e3, 4), "n_gpus": world} if rank == 0 else None)
         return
 
     # ---- headline: configs[1] ---------------------------------------------------------------------------------------------------------
@@ -490,6 +487,7 @@ def main():
         extras.append({"config": "configs[0] on the GPU: unpruned, batch=1, fp32, hipGraph replay (latency; the reference publishes 5.6 ms for the PRUNED model on a Jetson TX2)",
                        "value": round(1 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f32"})
 
+    line = None
     if rank == 0:
         line = {
             "metric": "frames/sec (224x224) MobileNet-NNConv5dw-skipadd inference forward",
@@ -514,9 +512,22 @@ def main():
                 line["train_check"] = train_check(dev)
             except Exception as e:
                 line["train_check"] = {"error": repr(e)}
-        print(json.dumps(line))
+    finish(dist, line)
+
+
+def finish(dist, line):
+    """Rank 0's JSON line must be the LAST thing on stdout: RCCL writes a version banner through C stdio, which would otherwise be flushed
+    at exit, after Python's print."""
+    import ctypes
     if dist is not None:
         dist.destroy_process_group()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(json.dumps(line))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -7,9 +7,13 @@
 // caller's stream with no host-side decisions, allocations or synchronisation in between.
 #include "fd_kernels_f32.h"
 #include "fd_kernels_gemm16_f32.h"
-#include "fd_kernels_sk_f32.h"
 #include "fd_kernels_h16.h"
+// Off-by-default experiments (stream-K GEMM, fused depthwise+pointwise unit, side-stream weight gradients: all measured no faster, DESIGN.md
+// section 3) are compiled only with -DFD_EXPERIMENTS: the product library does not contain them; the emulator test build does.
+#ifdef FD_EXPERIMENTS
+#include "fd_kernels_sk_f32.h"
 #include "fd_kernels_fused_f32.h"
+#endif
 #include "../../include/fastdepth_hip.h"
 
 #include <algorithm>
@@ -278,6 +282,7 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
         return check_launch("fd_pw_gemm16_f32");
     }
     const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
+#ifdef FD_EXPERIMENTS
     if (L.sk) {
         float *scratch = reinterpret_cast<float *>(plan->ws + plan->sk_scratch_off);
         int *counters = reinterpret_cast<int *>(plan->ws + plan->sk_counter_off);
@@ -294,6 +299,7 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
 #undef FD_SK_CASE
         return check_launch("fd_pw_gemm_sk_f32");
     }
+#endif
 #define FD_PW_CASE(a, b, c, d) \
     case a * 1000 + b * 100 + c * 10 + d: \
         if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_pw_gemm_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
@@ -310,6 +316,7 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
     return check_launch("fd_pw_gemm_f32");
 }
 
+#ifdef FD_EXPERIMENTS
 template <int K, int ACT2>
 int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *in, const float *wdw, const float *bdw, const float *wp,
                  const float *bias, float *out, hipStream_t s)
@@ -327,6 +334,8 @@ int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *
 #undef FD_SEP
     return check_launch("fd_sep_unit_f32");
 }
+
+#endif
 
 template <int ACT>
 int launch_pw_t(const fd_plan *plan, const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
@@ -361,6 +370,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
             FD_LAUNCH((fd_head_pw1<T, ACT>), L.grid, dim3(256), 0, s, in, wpf, bias, y, npix, h, w, L.d.cin, L.d.upsample);
             return check_launch("fd_head_pw1");
         }
+#ifdef FD_EXPERIMENTS
         if (L.fused_dw >= 0) {
             if constexpr (std::is_same<T, float>::value) {
                 const Layer &D = p->layers[L.fused_dw];
@@ -372,6 +382,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
                 return fail(FD_ERR_INVALID, "fused units are fp32 only");
             }
         }
+#endif
         return launch_pw_t<ACT>(p, L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
     }
     return fail(FD_ERR_INVALID, "bad op");
@@ -410,6 +421,9 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
     if (dtype != FD_F32 && dtype != FD_F16 && dtype != FD_BF16) return fail(FD_ERR_INVALID, "unknown dtype %d", dtype);
+#ifndef FD_EXPERIMENTS
+    if (flags & (FD_PLAN_STREAMK | FD_PLAN_FUSE_SEPARABLE)) return fail(FD_ERR_INVALID, "this library was built without -DFD_EXPERIMENTS: the stream-K / fused-unit experiments are not in it");
+#endif
     fd_plan *p = new fd_plan();
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
     p->layers.resize(n_layers);
@@ -470,8 +484,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             }
             const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);
-            int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = 8;   // 8x16 outputs x 32 channels: ~37 KB LDS -> 4 workgroups per CU (measured best, round 1)
-            if (const char *e = getenv("FD_TUNE_DW_TILE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b >= 4 && b % 4 == 0) { tmax_h = a; tmax_w = b; } }   // tuning aid
+            const int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = 8;   // 8x16 outputs x 32 channels: ~37 KB LDS -> 4 workgroups per CU (measured best, round 1)
             L.tw = std::min((L.out_w + 3) / 4 * 4, tmax_w);
             L.th = std::min(L.out_h, tmax_h);
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);

@@ -65,7 +65,7 @@ struct fd_train_plan {
     // backward, opt-in experiment: a unit's weight-gradient kernel runs on this side stream, concurrently with its backward-data
     // kernel on the caller's stream (fork / join by events; both only read dz and the saved tensors).  Created lazily, owned by
     // the plan.  Like every other multi-stream attempt on this path it lost to plain in-order launches.
-    bool concurrent_wgrad = false;   // EXPERIMENT (FD_TRAIN_CONCURRENT=1 at plan creation): measured slower at batch 32 (bf16 3.72 vs 3.33 ms, fp32 5.30 vs 5.10 ms)
+    bool concurrent_wgrad = false;   // EXPERIMENT (plan flag FD_PLAN_CONCURRENT_WGRAD, builds with -DFD_EXPERIMENTS only): measured slower at batch 32 (bf16 3.72 vs 3.33 ms, fp32 5.30 vs 5.10 ms)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~fd_train_plan()
@@ -239,7 +239,11 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         return fail(FD_ERR_INVALID, "train plan: dtype %d not supported (fp32 or bf16; fp16 gradients would need loss scaling)", dtype);
     fd_train_plan *p = new fd_train_plan();
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
-    { const char *e = getenv("FD_TRAIN_CONCURRENT"); p->concurrent_wgrad = e && e[0] == '1'; }
+#ifdef FD_EXPERIMENTS
+    p->concurrent_wgrad = (flags & FD_PLAN_CONCURRENT_WGRAD) != 0;
+#else
+    if (flags & FD_PLAN_CONCURRENT_WGRAD) { delete p; return fail(FD_ERR_INVALID, "this library was built without -DFD_EXPERIMENTS: side-stream weight gradients are not in it"); }
+#endif
     const bool h16 = dtype != FD_F32;
     const size_t esz = h16 ? 2 : 4;
     p->esz = esz;

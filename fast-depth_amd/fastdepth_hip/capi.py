@@ -25,6 +25,7 @@ FD_PLAN_WGRAD_TILE_ROWS = 8
 FD_PLAN_STREAMK = 32
 FD_PLAN_FORCE_GEMM16 = 16
 FD_PLAN_NO_GEMM16 = 64
+FD_PLAN_CONCURRENT_WGRAD = 128
 
 
 class LayerDesc(ctypes.Structure):

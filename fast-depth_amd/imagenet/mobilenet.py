@@ -12,7 +12,7 @@ same attribute tree.  Module creation order -- every Conv2d of every block in se
 (unused by FastDepth) 1000-way classifier -- is kept identical to the reference on purpose: the
 default initialisers draw from torch's global RNG, so an identical order means that
 ``torch.manual_seed(s)`` followed by construction yields bit-identical parameters to the reference
-(checked by tests/test_reference_compat.py when /root/reference is present).
+(checked by tests/test_module_surface.py when /root/reference is present).
 """
 import torch.nn as nn
 

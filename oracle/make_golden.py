@@ -6,7 +6,7 @@ module with pretrained=False; 20 train-mode no-grad forwards on cat([sample, ran
 populate BatchNorm running statistics; eval(); head BN beta=2.8, gamma=1.0 so that the output is
 depth-like and non-degenerate.  Variants exercise ReLU6 saturation and non-trivial running stats.
 The new repo's constructor reproduces the reference's parameters bit-for-bit from the same seed
-(tests/test_reference_compat.py), so only seeds, BN statistics and reference OUTPUTS are stored.
+(tests/test_module_surface.py), so only seeds, BN statistics and reference OUTPUTS are stored.
 """
 import hashlib
 import json
