@@ -46,34 +46,7 @@ __device__ __forceinline__ fd_f32x4 fd_actmask4(fd_f32x4 y)
 
 // ---- deterministic partial reductions of the backward pass (bodies shared by the single kernels and by
 // fd_bwd_reduce_pair_f32; (bx, by, ny) = column block, slice, slice count: see fd_two_level_tail) -------------------------------
-// weights:  out[j] = sum_b part[b*n + j]  (KK == 0), or the depthwise form  out[c*KK + t] = sum_b part[(b*KK + t)*C + c]
-// (tap-major partials -> torch's [C][1][k][k]) with n = KK*C
-__device__ __forceinline__ void fd_reduce_partials_dev(const float *__restrict__ part, int nblk, int rps, int n, int KK, int C, float *__restrict__ out,
-                                                       double *__restrict__ slices, int *__restrict__ counters, double (*sh)[64][2], int *s_last,
-                                                       int bx, int by, int ny)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = bx * 64 + lane;
-    const int r0 = by * rps;
-    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
-    double s = 0.0, unused = 0.0;
-    if (j < n)
-#pragma unroll 4
-        for (int b = r0 + wave; b < r1; b += 16) s += (double)part[(long)b * n + j];
-    sh[wave][lane][0] = s;
-    __syncthreads();
-    if (wave == 0) {
-        s = 0.0;
-        for (int w = 0; w < 16; ++w) s += sh[w][lane][0];
-    }
-    __syncthreads();
-    if (!fd_two_level_tail(s, unused, false, j < n, j, 2 * n, slices, counters, s_last, sh, bx, by, ny)) return;
-    if (wave == 0 && j < n) {
-        if (KK == 0) { out[j] = (float)s; }
-        else { const int t = j / C, c = j - t * C; out[(long)c * KK + t] = (float)s; }
-    }
-}
-
+// (the weight-gradient partials are reduced by fd_reduce_weights_batch_f32 below)
 // BatchNorm backward finalize: partial sums of (G, G*xhat) -> dbeta, dgamma and the coefficient table of dz
 __device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
                                                        float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
@@ -108,15 +81,6 @@ __device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__
 }
 
 __global__ void __launch_bounds__(1024)
-fd_reduce_partials_f32(const float *__restrict__ part, int nblk, int rps, int n, int KK, int C, float *__restrict__ out,
-                       double *__restrict__ slices, int *__restrict__ counters)
-{
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
-    fd_reduce_partials_dev(part, nblk, rps, n, KK, C, out, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, gridDim.y);
-}
-
-__global__ void __launch_bounds__(1024)
 fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
                        float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
                        double *__restrict__ slices, int *__restrict__ counters)
@@ -126,23 +90,74 @@ fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C,
     fd_bn_bwd_finalize_dev(part, nblk, rps, C, n, st, dgamma, dbeta, coef, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
-// One launch for the two reductions that close a unit's backward: its weight-gradient partials (column blocks [0, nbx_w)) and
-// the BatchNorm-backward partials its backward-data kernel produced for the producer (column blocks [nbx_w, gridDim.x)).
-// gridDim.y = max of the two slice counts; the counters / slice areas of the second part start at cnt_off / slice_off.
-struct fd_wred_args { const float *part; int nblk, rps, n, KK, C; float *out; int ny; };
-struct fd_bred_args { const float *part; int nblk, rps, C; double n; const float *st; float *dgamma, *dbeta, *coef; int ny; };
-__global__ void __launch_bounds__(1024)
-fd_bwd_reduce_pair_f32(const fd_wred_args W, const fd_bred_args Bn, int nbx_w, double *__restrict__ slices, long slice_off, int *__restrict__ counters)
+// ---- weight-gradient partials of a whole range of units, reduced by ONE launch at the end of the range (round 1: one launch per unit paired
+// with its BatchNorm-backward finalisation, 36 x ~10 us per step).  Every unit's weight-gradient kernel leaves its partial rows in its
+// own region; entry e describes one unit:  out[j] = sum_b part[b*n + j]  (KK == 0), or the depthwise form
+// out[c*KK + t] = sum_b part[(b*KK + t)*C + c]  (tap-major partials -> torch's [C][1][k][k]) with n = KK*C, n % 4 == 0.
+// Two shapes of work in one kernel (uniform per workgroup):
+//   few rows (nblk <= 64: the pointwise layers' M splits)   each of the 16 waves owns 256 columns and adds ALL rows itself, 8 row loads
+//                                                            in flight -- a pure stream, no LDS, no barrier (4096 columns per workgroup);
+//   many rows (depthwise / stem partial rows, up to ~3000)   the 16 waves split the rows of 256 columns (wave w: rows w, w+16, ... in
+//                                                            order), then the 16 wave sums are added in wave order.
+// Fixed orders: bit-reproducible.
+#define FD_WBATCH_MAX 40
+#define FD_WBATCH_FEW_ROWS 64
+struct fd_wred_args { const float *part; float *out; int nblk, n, KK, C; };
+struct fd_wbatch { int count; int cb_start[FD_WBATCH_MAX + 1]; fd_wred_args e[FD_WBATCH_MAX]; };
+__device__ __forceinline__ void fd_wbatch_store(const fd_wred_args &W, int j, fd_f32x4 s)
 {
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
-    if ((int)blockIdx.x < nbx_w) {
-        if ((int)blockIdx.y >= W.ny) return;
-        fd_reduce_partials_dev(W.part, W.nblk, W.rps, W.n, W.KK, W.C, W.out, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, W.ny);
-    } else {
-        if ((int)blockIdx.y >= Bn.ny) return;
-        fd_bn_bwd_finalize_dev(Bn.part, Bn.nblk, Bn.rps, Bn.C, Bn.n, Bn.st, Bn.dgamma, Bn.dbeta, Bn.coef, slices + slice_off, counters + nbx_w, sh, &s_last,
-                               blockIdx.x - nbx_w, blockIdx.y, Bn.ny);
+    if (W.KK == 0) { W.out[j] = s.x; W.out[j + 1] = s.y; W.out[j + 2] = s.z; W.out[j + 3] = s.w; }   // (gradient views need not be 16-byte aligned)
+    else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int t = (j + q) / W.C, c = (j + q) - t * W.C; W.out[(long)c * W.KK + t] = s[q]; }
+    }
+}
+__global__ void __launch_bounds__(1024)
+fd_reduce_weights_batch_f32(const fd_wbatch B)
+{
+    __shared__ fd_f32x4 sh[16][64];
+    int e = 0;
+    while (e + 1 < B.count && (int)blockIdx.x >= B.cb_start[e + 1]) ++e;
+    const fd_wred_args W = B.e[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = (int)blockIdx.x - B.cb_start[e];
+    if (W.nblk <= FD_WBATCH_FEW_ROWS) {
+        const int j = ((cb * 16 + wave) * 64 + lane) * 4;
+        if (j >= W.n) return;
+        const float *p = W.part + j;
+        fd_f32x4 s = fd_zero4();
+        int b = 0;
+        for (; b + 8 <= W.nblk; b += 8) {
+            fd_f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = fd_ld4(p + (long)(b + u) * W.n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < W.nblk; ++b) s += fd_ld4(p + (long)b * W.n);
+        fd_wbatch_store(W, j, s);
+        return;
+    }
+    const int j = (cb * 64 + lane) * 4;
+    fd_f32x4 s = fd_zero4();
+    if (j < W.n) {
+        const float *p = W.part + j;
+        int b = wave;
+        for (; b + 7 * 16 < W.nblk; b += 8 * 16) {
+            fd_f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = fd_ld4(p + (long)(b + 16 * u) * W.n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < W.nblk; b += 16) s += fd_ld4(p + (long)b * W.n);
+    }
+    sh[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < W.n) {
+        s = sh[0][lane];
+        for (int w = 1; w < 16; ++w) s += sh[w][lane];
+        fd_wbatch_store(W, j, s);
     }
 }
 
@@ -228,14 +243,30 @@ struct fd_sgd_rec { float *param; const float *grad; float *buf; long numel; };
 __global__ void __launch_bounds__(256)
 fd_sgd_f32(const fd_sgd_rec *__restrict__ table, int n_tensors, float lr, float momentum, float wd, float grad_scale, int first_step)
 {
-    // blockIdx.y = tensor, blockIdx.x strides over its elements
+    // blockIdx.y = tensor, blockIdx.x strides over its elements: 16 bytes per lane where the tensor's three arrays are 16-byte aligned
+    // (the large ones are: torch allocations and gradient-buffer slices behind multiples of 4 elements), scalar otherwise
     const fd_sgd_rec r = table[blockIdx.y];
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < r.numel; i += (long)gridDim.x * 256) {
-        const float p = r.param[i];
-        const float d = fmaf(wd, p, grad_scale * r.grad[i]);
-        const float b = first_step ? d : fmaf(momentum, r.buf[i], d);
-        r.buf[i] = b;
-        r.param[i] = p - lr * b;
+    auto upd = [&](float p, float g, float m, float &pn, float &mn) {
+        const float d = fmaf(wd, p, grad_scale * g);
+        mn = first_step ? d : fmaf(momentum, m, d);
+        pn = p - lr * mn;
+    };
+    const bool vec = (((size_t)r.param | (size_t)r.grad | (size_t)r.buf) & 15) == 0;
+    const long n4 = vec ? r.numel >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const fd_f32x4 p = fd_ld4(r.param + 4 * i), g = fd_ld4(r.grad + 4 * i), m = first_step ? fd_zero4() : fd_ld4(r.buf + 4 * i);
+        float pn[4], mn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) upd(p[q], g[q], m[q], pn[q], mn[q]);
+        const fd_f32x4 mv = {mn[0], mn[1], mn[2], mn[3]}, pv = {pn[0], pn[1], pn[2], pn[3]};
+        fd_st4(r.buf + 4 * i, mv);
+        fd_st4(r.param + 4 * i, pv);
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < r.numel; i += (long)gridDim.x * 256) {
+        float pn, mn;
+        upd(r.param[i], r.grad[i], first_step ? 0.0f : r.buf[i], pn, mn);
+        r.buf[i] = mn;
+        r.param[i] = pn;
     }
 }
 

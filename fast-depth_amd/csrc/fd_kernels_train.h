@@ -443,7 +443,8 @@ __device__ __forceinline__ bool fd_two_level_tail(double &s, double &q, bool has
 __global__ void __launch_bounds__(1024)
 fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, double n_unbiased, float eps, float momentum,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ run_mean,
-                   float *__restrict__ run_var, float *__restrict__ st, double *__restrict__ slices, int *__restrict__ counters)
+                   float *__restrict__ run_var, float *__restrict__ st, double *__restrict__ slices, int *__restrict__ counters,
+                   long long *__restrict__ nbt)
 {
     __shared__ double sh[16][64][2];
     __shared__ int s_last;
@@ -475,6 +476,7 @@ fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, dou
         st[FD_ST_INVSTD * C + c] = (float)invstd;
         run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
         run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var * (n_unbiased / (n_unbiased - 1.0)));
+        if (c == 0 && nbt) nbt[0] += 1;                       // nn.BatchNorm2d.num_batches_tracked (one finalising workgroup owns channel 0)
     }
 }
 

@@ -8,10 +8,9 @@ struct BwdCtx {
     const fd_layer_params *params;
     const fd_layer_grads *grads;
     hipStream_t s;
-    // weight-gradient partials of the unit being processed, waiting to be reduced together with the BatchNorm-backward partials
-    // its backward-data kernel produces (one launch: fd_bwd_reduce_pair_f32)
-    bool w_pending = false;
-    fd_wred_args w{};
+    // weight-gradient partials of the units processed so far in this range: reduced by ONE launch at the end of the range
+    // (fd_reduce_weights_batch_f32)
+    fd_wbatch wb{};
     hipStream_t ws = nullptr;        // stream of the weight-gradient kernels (the plan's side stream, or s when concurrency is off)
 };
 
@@ -29,18 +28,24 @@ int join_side(BwdCtx &c)
     return FD_OK;
 }
 
-// the generic single reduction (stem, head: units without a backward-data partner)
-int reduce_weights_now(BwdCtx &c, const float *part, int nrows, int n, int KK, int C, float *out)
+int flush_weights(BwdCtx &c)
 {
-    const RedGeom rg = red_geom(nrows, n);
-    FD_LAUNCH(fd_reduce_partials_f32, rg.grid, dim3(1024), 0, c.s, part, nrows, rg.rps, n, KK, C, out, red_slices(c.p), red_counters(c.p));
-    return check_launch("fd_reduce_partials_f32");
+    if (!c.wb.count) return FD_OK;
+    int jrc = join_side(c);                                   // (experiment builds: the weight-gradient kernels ran on the side stream)
+    if (jrc) return jrc;
+    FD_LAUNCH(fd_reduce_weights_batch_f32, dim3((unsigned)c.wb.cb_start[c.wb.count]), dim3(1024), 0, c.s, c.wb);
+    c.wb.count = 0;
+    return check_launch("fd_reduce_weights_batch_f32");
 }
-void defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C, float *out)
+int defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C, float *out)
 {
-    const RedGeom rg = red_geom(nrows, n);
-    c.w = fd_wred_args{part, nrows, rg.rps, n, KK, C, out, (int)rg.grid.y};
-    c.w_pending = true;
+    if (n % 4) return fail(FD_ERR_INVALID, "weight tensor of %d elements: the batched reduction needs a multiple of 4", n);
+    if (c.wb.count == FD_WBATCH_MAX) { int rc = flush_weights(c); if (rc) return rc; }
+    if (c.wb.count == 0) c.wb.cb_start[0] = 0;
+    c.wb.e[c.wb.count] = fd_wred_args{part, out, nrows, n, KK, C};
+    c.wb.cb_start[c.wb.count + 1] = c.wb.cb_start[c.wb.count] + ceil_div(n, nrows <= FD_WBATCH_FEW_ROWS ? 4096 : 256);
+    ++c.wb.count;
+    return FD_OK;
 }
 
 inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size_t)ph * pw * (cb + 4), (size_t)2048) + (size_t)k * k * cb) * 4; }
@@ -49,18 +54,6 @@ int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
     TLayer &L = c.p->layers[i];
     const RedGeom rg = red_geom(nblk, L.d.cout);
-    if (c.w_pending) {
-        c.w_pending = false;
-        int jrc = join_side(c);                               // the weight-gradient kernel ran on the side stream
-        if (jrc) return jrc;
-        const int nbx_w = ceil_div(c.w.n, 64);
-        const fd_bred_args b{tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias,
-                             tws(c.p, L.coef_off), (int)rg.grid.y};
-        const long slice_off = (long)c.w.ny * 2 * c.w.n;       // doubles used by the weight part's slices
-        FD_LAUNCH(fd_bwd_reduce_pair_f32, dim3((unsigned)(nbx_w + rg.grid.x), (unsigned)std::max(c.w.ny, (int)rg.grid.y)), dim3(1024), 0, c.s, c.w, b, nbx_w,
-                  red_slices(c.p), slice_off, red_counters(c.p));
-        return check_launch("fd_bwd_reduce_pair_f32");
-    }
     FD_LAUNCH(fd_bn_bwd_finalize_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat,
               tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off), red_slices(c.p), red_counters(c.p));
     return check_launch("fd_bn_bwd_finalize_f32");
@@ -109,7 +102,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     TLayer &P = c.p->layers[L.d.src];
     const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
-    float *wpart = tws(c.p, c.p->wpart_off);
+    float *wpart = tws(c.p, L.wp_off);
     // tiles per workgroup (along x): as many as keep >= ~1536 workgroups in flight
     int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.grid.x * L.grid.y * L.grid.z / 1536)));
     if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
@@ -137,8 +130,8 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     int rc = check_launch("fd_dw_wgrad");
     if (rc) return rc;
     const int kk = L.d.ksize * L.d.ksize;
-    defer_weights(c, wpart, wblk, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);     // reduced with the BN partials of the backward-data kernel
-    return FD_OK;
+    if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+    return defer_weights(c, wpart, wblk, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
 }
 
 template <typename T>
@@ -172,13 +165,12 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_H16, (long)n_tiles * k_tiles), ceil_div(M, 256)));
         int rows = ceil_div(ceil_div(M, splits), 64) * 64;
         splits = ceil_div(M, rows);
-        const size_t need = (size_t)splits * N * K * 4;
-        if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
+        if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
         if ((rc = fork_side(c))) return rc;
         FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
-                  tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
+                  tws(c.p, L.wp_off), M, N, K, k_tiles, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
-        defer_weights(c, tws(c.p, c.p->wpart_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
+        if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
     }
     {
         const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
@@ -212,16 +204,15 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_F32, (long)n_tiles * k_tiles), ceil_div(M, 256)));
         int rows = ceil_div(ceil_div(M, splits), 64) * 64;
         splits = ceil_div(M, rows);
-        const size_t need = (size_t)splits * N * K * 4;
-        if (need > c.p->wpart_bytes) return fail(FD_ERR_STATE, "weight-gradient partial buffer too small (%zu > %zu)", need, c.p->wpart_bytes);
+        if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
         const size_t lds = (size_t)FD_BWD_STAGES * 3 * 32 * 64 * 4;
         (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         { int frc = fork_side(c); if (frc) return frc; }
         FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds, c.ws, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                  tws(c.p, c.p->wpart_off), M, N, K, k_tiles, rows);
+                  tws(c.p, L.wp_off), M, N, K, k_tiles, rows);
         int rc = check_launch("fd_pw_wgrad_f32");
         if (rc) return rc;
-        defer_weights(c, tws(c.p, c.p->wpart_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
+        if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
     }
     // --- data: G_src[M][K]
     {
@@ -260,7 +251,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         c.ws = plan->side;
     }
     hipStream_t s = c.s;
-    float *part = tws(plan, plan->part_off), *wpart = tws(plan, plan->wpart_off);
+    float *part = tws(plan, plan->part_off);
     int rc;
     // ---- head
     const int hi = n_layers - 1;
@@ -276,14 +267,12 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         constexpr int PPB = 16;
         const int nb2 = ceil_div(Hd.M, 32 * PPB);
         const size_t lds = (size_t)32 * Hd.d.cin * 3 * 4;
-        if ((size_t)nb2 * Hd.d.cin * 4 > plan->wpart_bytes) return fail(FD_ERR_STATE, "wpart too small for the head");
+        float *wpart = tws(plan, Hd.wp_off);
+        if ((size_t)nb2 * Hd.d.cin > Hd.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small for the head");
         if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
         else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
         if ((rc = check_launch("fd_head_bwd"))) return rc;
-        {
-            if ((rc = reduce_weights_now(c, wpart, nb2, Hd.d.cin, 0, 0, grads[hi].conv_weight))) return rc;
-        }
-        if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+        if ((rc = defer_weights(c, wpart, nb2, Hd.d.cin, 0, 0, grads[hi].conv_weight))) return rc;
         // the BN partials of the head's producer are now in `part` (nb2 workgroups)
         if ((rc = bn_bwd_finalize(c, Hd.d.src, nb2))) return rc;
     }
@@ -297,12 +286,10 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         case FD_OP_STEM: {
             const int nb_w = std::min(L.nblk, 512);          // workgroups walk the 256-pixel blocks grid-stride
             if (d.cout > 64) return fail(FD_ERR_INVALID, "stem weight gradient supports at most 64 output channels");
+            float *wpart = tws(plan, L.wp_off);
             FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), (size_t)(256 * 33 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout, L.nblk);
             if ((rc = check_launch("fd_stem_wgrad"))) return rc;
-            {
-                if ((rc = reduce_weights_now(c, wpart, nb_w, 27 * d.cout, 0, 0, grads[i].conv_weight))) return rc;
-            }
-            if ((rc = check_launch("fd_reduce_partials_f32"))) return rc;
+            if ((rc = defer_weights(c, wpart, nb_w, 27 * d.cout, 0, 0, grads[i].conv_weight))) return rc;
             break;
         }
         case FD_OP_DW: {
@@ -326,7 +313,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         }
     }
     g_trace_layer = -1;
-    return FD_OK;
+    return flush_weights(c);                                  // one launch reduces the weight-gradient partials of every unit of this range
 }
 
 }  // namespace

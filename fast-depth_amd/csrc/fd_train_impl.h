@@ -6,7 +6,8 @@
 //   [st_i]  per-unit BatchNorm table [4][C]: scale, shift, mean, invstd (fd_bn_finalize_f32)
 //   [part]  one shared buffer for per-workgroup reduction partials (consumed right after each producer)
 //   backward only: [g_a, g_b] ping-pong dLoss/d(BN output) buffers, [skipgrad_k] decoder->skip gradient buffers,
-//   [coef_i] per-unit BN-backward coefficient tables, [wpart] weight-gradient partials.
+//   [coef_i] per-unit BN-backward coefficient tables, [wpart_i] per-unit weight-gradient partials (reduced by ONE launch per backward
+//   range: fd_reduce_weights_batch_f32).
 //   bf16 plans: [wt_i, wtt_i] the 16-bit operand copies of every pointwise weight (re-made from the fp32 masters each step).
 #pragma once
 #include <type_traits>
@@ -47,6 +48,7 @@ struct TLayer {
     size_t sg_off = 0;               // decoder->skip gradient buffer (only for skip sources)
     size_t wt_off = 0, wtt_off = 0;  // 16-bit plans: W as [N][K64] and W^T as [K][N64]
     size_t dz_off = 0;               // 16-bit pointwise units under FD_PLAN_KEEP_ACTIVATIONS: dz kept apart from G (0 = in place)
+    size_t wp_off = 0, wp_elems = 0; // this unit's weight-gradient partial rows (reduced by one launch per backward range)
     int k64 = 0, n64 = 0;
 };
 
@@ -57,7 +59,7 @@ struct fd_train_plan {
     int B = 0, H = 0, W = 0, dtype = FD_F32;
     uint32_t flags = 0;
     size_t esz = 4;                  // bytes per stored activation / activation-gradient element
-    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, wpart_off = 0, wpart_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
+    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
     unsigned char *ws = nullptr;
     bool forward_done = false;
     float eps = 1e-5f;
@@ -210,7 +212,8 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         if (rc) return rc;
         const RedGeom rg = red_geom(L.nblk, d.cout);
         FD_LAUNCH(fd_bn_finalize_f32, rg.grid, dim3(1024), 0, s, part, L.nblk, rg.rps, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
-                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off), red_slices(plan), red_counters(plan));
+                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off), red_slices(plan), red_counters(plan),
+                  reinterpret_cast<long long *>(q.bn_num_batches_tracked));
         if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
     }
     const TLayer &Hd = plan->layers.back();
@@ -284,7 +287,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.lds = 256 * (L.chunk + 4) * 4;
             L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
             L.nblk = (int)L.grid.x;
-            max_wpart = std::max(max_wpart, (size_t)L.nblk * 27 * d.cout);
+            L.wp_elems = (size_t)std::min(L.nblk, 512) * 27 * d.cout;
             break;
         case FD_OP_DW: {
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);
@@ -299,7 +302,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
-            max_wpart = std::max(max_wpart, (size_t)L.nblk * d.ksize * d.ksize * d.cin);
+            L.wp_elems = (size_t)L.nblk * d.ksize * d.ksize * d.cin;
             break;
         }
         case FD_OP_PW:
@@ -311,7 +314,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.out_w = d.upsample ? L.in_w / 2 : L.in_w;
                 L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w * 8, 256));
                 L.nblk = (int)L.grid.x;
-                max_wpart = std::max(max_wpart, (size_t)L.nblk * d.cin);
+                L.wp_elems = (size_t)ceil_div((long)batch * L.out_h * L.out_w, 32 * 16) * d.cin;
             } else {
                 if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample only as the 1-channel head", i);
                 L.out_h = L.in_h; L.out_w = L.in_w;
@@ -326,7 +329,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                     int splits = std::max(1, std::min(ceil_div(h16 ? FD_WGRAD_TARGET_WGS_H16 : FD_WGRAD_TARGET_WGS_F32, (long)nt * kt), ceil_div(M, 256)));
                     const int rows = ceil_div(ceil_div(M, splits), 64) * 64;
                     splits = ceil_div(M, rows);
-                    max_wpart = std::max(max_wpart, (size_t)splits * d.cout * d.cin);
+                    L.wp_elems = (size_t)splits * d.cout * d.cin;
                 }
             }
             break;
@@ -350,6 +353,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         if (d.op == FD_OP_STEM) max_width = std::max(max_width, (size_t)27 * d.cout);
         if (d.op == FD_OP_PW) max_width = std::max(max_width, (size_t)d.cin * d.cout);
         max_g = std::max(max_g, L.z_elems);
+        max_wpart = std::max(max_wpart, L.wp_elems);
+        L.wp_off = off; off += align_up(std::max(L.wp_elems, (size_t)1) * 4, 256);
     }
     TLayer &last = p->layers.back();
     if (!last.head || (last.d.upsample ? 2 * last.out_h : last.out_h) != height) FD_BAD("the last layer must be the 1-channel head producing [B,1,%d,%d]", height, width);
@@ -370,7 +375,6 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     }
     // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
     p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
-    p->wpart_off = off; p->wpart_bytes = align_up(std::max(max_wpart, (size_t)1) * 4, 256); off += p->wpart_bytes;
     // slice sums (double) of the fused two-level reductions: ceil(rows / 64) x 2 x width, bounded through rows x width <= the partial buffers
     p->part2_off = off; p->part2_bytes = align_up((2 * max_part / 16 + max_wpart / 16 + 8 * std::max(max_width, (size_t)1) + 128) * 8, 256); off += p->part2_bytes;   // two reductions can share a launch
     p->cnt_off = off; p->cnt_bytes = align_up((2 * ceil_div((long)std::max(max_width, (size_t)1), 64) + 2) * 4, 256); off += p->cnt_bytes;   // arrival counters, one per 64 columns

@@ -34,7 +34,7 @@ class LayerDesc(ctypes.Structure):
 
 
 class LayerParams(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias", "bn_mean", "bn_var")]
+    _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias", "bn_mean", "bn_var", "bn_num_batches_tracked")]
 
 
 class LayerGrads(ctypes.Structure):

@@ -91,15 +91,20 @@ class TrainCore:
             for kind, p in (("conv_weight", l.conv.weight), ("bn_weight", l.bn.weight), ("bn_bias", l.bn.bias)):
                 _check_param(p, "%s.%s" % (l.name, kind), self._emulated)
                 self.param_list.append((i, kind, p))
-        self.total = sum(p.numel() for _, _, p in self.param_list)
+        # every tensor starts on a 16-byte boundary of the flat buffer (the fused SGD and the reductions then use 16-byte accesses); the
+        # padding elements stay zero
+        offs, off = [], 0
+        for _, _, p in self.param_list:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.total = off
+        self.flat_offsets = offs
         self.flat_grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad_views, self.layer_span = {}, {}
-        off = 0
-        for i, kind, p in self.param_list:
+        for (i, kind, p), off in zip(self.param_list, offs):
             self.grad_views[(i, kind)] = self.flat_grad[off:off + p.numel()].view_as(p)
             lo, hi = self.layer_span.get(i, (off, off))
-            self.layer_span[i] = (min(lo, off), off + p.numel())
-            off += p.numel()
+            self.layer_span[i] = (min(lo, off), max(hi, off + (p.numel() + 3) // 4 * 4))
         self.c_grads = (capi.LayerGrads * self.n)()
         for i in range(self.n):
             for kind in ("conv_weight", "bn_weight", "bn_bias"):
@@ -111,7 +116,6 @@ class TrainCore:
             raise capi.FastDepthError("mixed BatchNorm eps/momentum values are not supported")
         if self.bn_momentum is None:
             raise capi.FastDepthError("BatchNorm momentum=None (cumulative moving average) is not supported by the train step")
-        self._nbt = [l.bn.num_batches_tracked for l in self.layers if l.bn.num_batches_tracked is not None]
         self.generation = 0                       # stamped on every train-mode forward (TrainFunction.backward checks it)
         self.params_in_order = [p for l in self.layers for p in (l.conv.weight, l.bn.weight, l.bn.bias)]
         self.views_in_param_order = [self.grad_views[(i, k)] for i in range(self.n) for k in ("conv_weight", "bn_weight", "bn_bias")]
@@ -127,6 +131,8 @@ class TrainCore:
                             ("bn_mean", l.bn.running_mean), ("bn_var", l.bn.running_var)):
                 _check_param(t, "%s.%s" % (l.name, name), self._emulated)
                 setattr(q, name, t.data_ptr())
+            nbt = l.bn.num_batches_tracked          # int64 scalar: incremented by the forward kernel's finalisation tail
+            q.bn_num_batches_tracked = nbt.data_ptr() if nbt is not None else None
         return params
 
     def plan_for(self, x):
@@ -149,8 +155,6 @@ class TrainCore:
         self._x = x                                # the stem's weight gradient re-reads the input in backward
         with _device_guard(x.device):
             capi.check(L, L.fd_train_forward(plan.handle, self._params, self.n, self.eps, self.bn_momentum, x.data_ptr(), y.data_ptr(), stream), "fd_train_forward")
-            if self._nbt:
-                torch._foreach_add_(self._nbt, 1)
         self._plan = plan
         self.generation += 1
         return y
@@ -258,10 +262,9 @@ class TrainEngine(TrainCore):
         self.flat_mom = torch.zeros_like(self.flat_grad)
         self.steps = 0
         # SGD table on the device: (param ptr, grad ptr, momentum ptr, numel) per tensor
-        rec, off = [], 0
-        for i, kind, p in self.param_list:
+        rec = []
+        for (i, kind, p), off in zip(self.param_list, self.flat_offsets):
             rec += [p.data_ptr(), self.flat_grad.data_ptr() + 4 * off, self.flat_mom.data_ptr() + 4 * off, p.numel()]
-            off += p.numel()
         self.sgd_table = torch.tensor(rec, dtype=torch.int64).to(self.device)
         self.layer_bytes = [4 * (self.layer_span[i][1] - self.layer_span[i][0]) for i in range(self.n)]
         self.use_comm = process_group is not None and (self.world > 1 or force_buckets)     # force_buckets: exercise the path on 1 rank

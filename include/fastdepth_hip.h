@@ -83,6 +83,7 @@ typedef struct fd_layer_params {
     const float *bn_bias;      /* beta  [cout] */
     const float *bn_mean;      /* running_mean [cout] */
     const float *bn_var;       /* running_var  [cout] */
+    int64_t *bn_num_batches_tracked; /* train forward: += 1 per step (nn.BatchNorm2d's counter); may be NULL; unused by inference */
 } fd_layer_params;
 
 typedef struct fd_plan fd_plan;
@@ -179,7 +180,8 @@ size_t fd_train_plan_workspace_bytes(const fd_train_plan *plan);
 int fd_train_plan_bind_workspace(fd_train_plan *plan, void *device_ptr, size_t bytes);
 
 /* Train-mode forward: reads the LIVE parameters (no folding), saves every unit's raw conv output and batch
- * statistics in the workspace for fd_train_backward, updates running_mean/var in place, writes y [B,1,H,W]. */
+ * statistics in the workspace for fd_train_backward, updates running_mean / running_var / num_batches_tracked in place,
+ * writes y [B,1,H,W]. */
 int fd_train_forward(fd_train_plan *plan, const fd_layer_params *params, int32_t n_layers, float bn_eps,
                      float bn_momentum, const void *x_nchw, void *y, void *stream);
 
