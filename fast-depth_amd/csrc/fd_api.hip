@@ -460,8 +460,12 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 FD_BAD("layer %d: stem must be 3->8k channels, 3x3 stride 2 on the network input", i);
             L.out_h = L.in_h / 2; L.out_w = L.in_w / 2;
             L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
-            L.lds = 0;                                   // the MFMA stem needs no LDS (fd_kernels_f32.h)
-            L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
+            if (d.cout > 64) FD_BAD("layer %d: the stem supports at most 64 output channels", i);
+            {   // LDS: the zero-padded band of input rows under 256 consecutive output pixels (3 planes), later reused as the output staging tiles
+                const int nrows = 2 * ceil_div(255, L.out_w) + 3;
+                L.lds = std::max((size_t)3 * nrows * (L.in_w + 8) * 4, (size_t)4 * 64 * 36 * 4);
+            }
+            L.grid = dim3(ceil_div((long)L.out_h * L.out_w, 256), batch);
             L.w_bytes = (size_t)27 * d.cout * 4; L.w_elems = (size_t)27 * d.cout;
             break;
         case FD_OP_DW: {
@@ -632,7 +636,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
                      L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         else if (d.op == FD_OP_STEM)
-            snprintf(buf, sizeof buf, "stem3x3s2<mfma 32x32x2, 64 px per wave> grid=%u", L.grid.x);
+            snprintf(buf, sizeof buf, "stem3x3s2<mfma 32x32x2, LDS-staged rows, 256 px per workgroup> grid=%ux%u lds=%zu", L.grid.x, L.grid.y, L.lds);
         else if (d.op == FD_OP_DW && L.dw_rows)
             snprintf(buf, sizeof buf, "dw3_rows<s%d> rows/item %d grid=%ux%ux%u", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW)

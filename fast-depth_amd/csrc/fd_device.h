@@ -22,6 +22,7 @@ template <int N> inline void fd_wait_vmcnt() {}
 #define FD_OPAQUE(x) ((void)0)
 inline void fd_block_barrier_lds() { __syncthreads(); }
 inline void fd_block_barrier() { __syncthreads(); }
+inline void fd_wave_lds_fence() { __syncthreads(); }         // the emulator runs a wave's lanes one after the other: a full barrier keeps them in step
 #else
 __device__ __forceinline__ void fd_glds16(const float *g, float *lds_wave_base)
 {
@@ -37,11 +38,40 @@ template <int N> __device__ __forceinline__ void fd_wait_vmcnt() { asm volatile(
 // makes the compiler forget what it knows about the integer x: loads addressed through it are not hoisted out of the enclosing loop
 // (used to keep per-channel tables out of registers while they are not needed)
 #define FD_OPAQUE(x) asm volatile("" : "+v"(x))
+// a wave's own LDS writes have completed before its following LDS reads are issued (wave-private LDS tiles need no workgroup barrier)
+__device__ __forceinline__ void fd_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // raw s_barrier: unlike __syncthreads() it does not drain vmcnt, so LDS-DMA loads stay in flight across it
 __device__ __forceinline__ void fd_block_barrier() { __builtin_amdgcn_s_barrier(); }
 // the same, after this wave's own LDS writes/reads have completed (lgkmcnt) -- still without draining vector-memory loads
 __device__ __forceinline__ void fd_block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #endif
+
+// XCD-aware placement of a (tiles, channel blocks, images) grid: workgroup number b (x fastest) runs on XCD b % 8 and every XCD has its
+// own L2, so with the natural numbering the neighbouring tiles of one image -- whose input halos overlap -- land on eight different L2s and
+// every halo is fetched from memory again (measured: 1.4x the algorithmic bytes on the 5x5 decoder layers).  This remapping gives each
+// group of eight consecutive workgroup numbers eight different IMAGES: all tiles and channel blocks of an image run on one XCD, and the
+// halo re-reads become L2 hits.  Returns the logical (x, y, z) of this workgroup.
+struct fd_blk3 { int x, y, z; };
+// b = linear workgroup number, per = workgroups per image, nimg = images: returns the image in z and the within-image index in x
+__device__ __forceinline__ fd_blk3 fd_xcd_map(unsigned b, unsigned per, unsigned nimg)
+{
+    const unsigned grp = b / (8u * per), rem = b - grp * 8u * per;
+    const unsigned m = nimg - grp * 8u < 8u ? nimg - grp * 8u : 8u;  // images in this group (the last one may be short)
+    fd_blk3 r;
+    r.z = (int)(grp * 8u + rem % m); r.x = (int)(rem / m); r.y = 0;
+    return r;
+}
+__device__ __forceinline__ fd_blk3 fd_xcd_image_map()      // grid (x, y, images)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    fd_blk3 r = fd_xcd_map(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy, gridDim.z);
+    r.y = (int)((unsigned)r.x / gx); r.x -= r.y * (int)gx;
+    return r;
+}
+__device__ __forceinline__ fd_blk3 fd_xcd_image_map2()     // grid (x, images)
+{
+    return fd_xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y);
+}
 
 typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 typedef float fd_f32x2 __attribute__((ext_vector_type(2)));

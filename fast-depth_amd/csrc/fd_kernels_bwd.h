@@ -582,8 +582,9 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
     // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const fd_blk3 bm = fd_xcd_image_map();                 // all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2
+    const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
+    const int c0 = bm.y * CB, n = bm.z;
     const int iy0 = ty * TH, ix0 = tx * TW;
     const int oyb = (iy0 + P - (K - 1) >= 0) ? (iy0 + P - (K - 1)) / S : -((-(iy0 + P - (K - 1)) + S - 1) / S);
     const int oxb = (ix0 + P - (K - 1) >= 0) ? (ix0 + P - (K - 1)) / S : -((-(ix0 + P - (K - 1)) + S - 1) / S);
@@ -763,7 +764,7 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
     if (tid < lanes_c) {
         fd_f32x4 a = fd_zero4(), b = fd_zero4();
         for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
-        const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+        const long blk = (long)bm.z * gridDim.x + bm.x;
         if (c0 + tid * 4 < Cp) {
             fd_st4(part + blk * 2 * Cp + c0 + tid * 4, a);
             fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, b);
@@ -795,8 +796,9 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     // a workgroup walks `tpw` horizontally adjacent tiles and keeps its tap sums in registers across them: one workgroup
     // reduction and one partial row per `tpw` tiles
     const int groups_x = (tiles_x + tpw - 1) / tpw;
-    const int ty = blockIdx.x / groups_x, tgx = blockIdx.x - ty * groups_x;
-    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const fd_blk3 bm = fd_xcd_image_map();                 // all tile groups / channel blocks of an image on one XCD
+    const int ty = bm.x / groups_x, tgx = bm.x - ty * groups_x;
+    const int c0 = bm.y * CB, n = bm.z;
     const int oy0 = ty * TH;
     const int iy0 = oy0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
@@ -923,7 +925,7 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
         for (int kx = 0; kx < K; ++kx) fd_st4(red + ((pg * K * K + ky * K + kx) * lanes_c + c4) * 4, acc[kx]);
     }
     __syncthreads();
-    const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+    const long blk = (long)bm.z * gridDim.x + bm.x;
     for (int i = tid; i < K * K * lanes_c; i += 256) {
         const int t = i >> cbq, cc = i & (lanes_c - 1);
         if (c0 + cc * 4 < C) {

@@ -43,46 +43,88 @@ fd_pack_fold(const float *__restrict__ w, const float *__restrict__ gamma, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem: dense 3x3 stride-2 conv, 3 -> Cout channels, as a [pixels x 27] x [27 x Cout] matrix product on
+// Stem: dense 3x3 stride-2 conv, 3 -> Cout channels (Cout <= 64), as a [pixels x 27] x [27 x Cout] matrix product on
 // v_mfma_f32_32x32x2_f32.  x is NCHW-planar (as the dataloader hands it over), y is NHWC.
-// A wave owns 64 consecutive output pixels (two 32-row tiles): lane l supplies A[pixel l%32][tap 2s + l/32] for the 14 K steps
-// (tap 27 is zero padding) straight from global memory -- 14 gathers per tile instead of 27 per pixel -- and B[tap][channel
-// l%32] from the folded weights wp[27][Cout].  The D layout (lane = channel, register = pixel row) makes every store a
-// 128-byte run of one pixel's channels: no LDS transposition, no LDS at all.  Accumulators start at the folded-BN bias.
+// A workgroup owns 256 consecutive output pixels of ONE image (row-major): they span at most ceil(256 / Wo) + 1 output rows, i.e. a
+// band of input rows that is staged ONCE into LDS with coalesced 16-byte loads -- zero padded, one plane after the other.  (Round 1
+// gathered the 27 taps of every pixel straight from the planes: 28 scalar 4-byte loads per lane with stride-2 addresses, quarter-width
+// transactions -> 30 us for 71 MB = 0.29 of HBM.)  A wave owns 64 of the pixels (two 32-row MFMA tiles): lane l supplies
+// A[pixel l%32][tap 2s + l/32] for the 14 K steps (tap 27 is zero padding) from LDS and B[tap][channel l%32] from the folded weights
+// wp[27][Cout].  The D layout (lane = channel, register = pixel) goes through LDS once more so that the NHWC store is 16 bytes per
+// lane: a pixel's Cout channels are one contiguous run.  Accumulators start at the folded-BN bias.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ACT, int CHUNK>
 __global__ void __launch_bounds__(256)
 fd_stem3x3s2(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
              T *__restrict__ y, int B, int H, int W, int Cout)
 {
-    (void)CHUNK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    (void)CHUNK; (void)B;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int Ho = H >> 1, Wo = W >> 1;
-    const long npix = (long)B * Ho * Wo;
-    const long p0 = ((long)blockIdx.x * 4 + wave) * 64;
-    if (p0 >= npix) return;
+    const fd_blk3 blk = fd_xcd_image_map2();                 // the pixel blocks of an image on one XCD: their input bands overlap
+    const int n = blk.z;
+    const int p0 = blk.x * 256, npix = Ho * Wo;             // pixel range of this workgroup within image n
+    const int p1 = p0 + 256 < npix ? p0 + 256 : npix;
+    const int oy_first = p0 / Wo, oy_last = (p1 - 1) / Wo;
+    const int iy_first = 2 * oy_first - 1, nrows = 2 * (oy_last - oy_first) + 3;       // input rows iy_first .. iy_first + nrows - 1
+    const int PW = W + 4;                                    // patch row: x = -1 at index 3 (so that x = 0 is 16-byte aligned), x = W at index W + 4 - ... see below
+    // patch[c][r][4 + x] for x in [-1, W]: index 3 holds the left padding, index 4 + W the right padding
+    const int PR = PW + 4;                                   // row pitch in floats (multiple of 4)
+    float *patch = smem;                                     // [3][nrows][PR]
+    const float *xn = x + (long)n * 3 * H * W;
+    const int W4 = W >> 2;                                   // W % 4 == 0 (W % 32 == 0)
+    // staging with memory-level parallelism: up to U 16-byte loads per work-item are requested back to back before any of them is
+    // written to LDS (a load -> ds_write chain per chunk would serialise ~6 HBM round trips per workgroup)
+    // (no integer division anywhere on the per-lane path: a wave takes patch rows wave, wave + 4, ..., a lane one 16-byte chunk of the row)
+    constexpr int U = 8;
+    for (int rbase = wave; rbase < 3 * nrows; rbase += 4 * U)
+        for (int qb = lane; qb < W4; qb += 64) {
+            fd_f32x4 v[U];
+            int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = rbase + 4 * u;
+                const int c = (rr >= nrows) + (rr >= 2 * nrows), r = rr - c * nrows;
+                const int iy = iy_first + r;
+                const bool in_patch = rr < 3 * nrows;
+                const bool ok = in_patch && iy >= 0 && iy < H;
+                const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qc = c > 2 ? 2 : c;      // clamped address, unconditional load, padding by select
+                v[u] = CHUNK == 103 ? fd_zero4() : fd_ld4(xn + ((long)qc * H + qy) * W + qb * 4);   // (CHUNK > 100: ablations of tools/microbench/stem.hip)
+                if (!ok) v[u] = fd_zero4();
+                off[u] = in_patch ? rr * PR + 4 + qb * 4 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (off[u] >= 0) fd_st4(patch + off[u], v[u]);
+        }
+    for (int rr = tid; rr < 3 * nrows; rr += 256) { patch[rr * PR + 3] = 0.0f; patch[rr * PR + 4 + W] = 0.0f; }   // left / right padding columns
+    __syncthreads();
+    const int pw0 = p0 + wave * 64;                          // this wave's 64 pixels
+    const int oyw = FD_UNIFORM(pw0 / Wo), oxw = pw0 - oyw * Wo;
     float a[2][14];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const long p = p0 + 32 * m + i;
-        const bool valid = p < npix;
-        int n = 0, oy = 0, ox = 0;
-        if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
-        const float *xn = x + (long)n * 3 * H * W;
+        const int p = pw0 + 32 * m + i;
+        const bool valid = p < p1;
+        int oy = oyw, ox = oxw + 32 * m + i;                  // pixel p = row oy, column ox: walk from the wave's first pixel, no division
+        while (ox >= Wo) { ox -= Wo; ++oy; }
+        if (!valid) { oy = oy_first; ox = 0; }
+        const float *base = patch + (2 * (oy - oy_first)) * PR + 4 + 2 * ox - 1;     // tap (ky = 0, kx = 0) of plane 0
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
-            // tap index 2s + h: both alternatives are compile-time, the lane half selects
-            const int t0 = 2 * s, t1 = 2 * s + 1;
+            const int t0 = 2 * s, t1 = 2 * s + 1;            // tap index 2s + h: both alternatives are compile-time, the lane half selects
             const int c = h ? t1 / 9 : t0 / 9, ky = h ? (t1 % 9) / 3 : (t0 % 9) / 3, kx = h ? t1 % 3 : t0 % 3;
-            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-            const bool ok = valid && (2 * s + h) < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            // branch-free gather: clamped address, unconditional load, padding by select (the 28 loads issue back to back)
-            const int qc = c > 2 ? 2 : c, qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            const float v = xn[((long)qc * H + qy) * W + qx];
+            const bool ok = valid && (2 * s + h) < 27;
+            const int qc = c > 2 ? 2 : c;
+            const float v = base[(qc * nrows + ky) * PR + kx];
             a[m][s] = ok ? v : 0.0f;
         }
     }
+    __syncthreads();                                         // the patch is consumed: its LDS becomes the output staging area
+    float *otile = smem + wave * 64 * 36;                    // [64 pixels][32 channels + 4]
     for (int n0 = 0; n0 < Cout; n0 += 32) {
         const int col = n0 + i;
         const bool col_ok = col < Cout;
@@ -98,19 +140,27 @@ fd_stem3x3s2(const float *__restrict__ x, const float *__restrict__ wp, const fl
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = bv;
+        // tile 0 first, then tile 1: the LDS transposition and the stores of tile 0 are issued under the MFMAs of tile 1
+        const int cw = Cout - n0 < 32 ? Cout - n0 : 32;      // channels of this chunk (multiple of 8)
+        const int lsh = cw >= 32 ? 3 : (cw >= 16 ? 2 : 1), lpp = 1 << lsh;     // lanes per pixel (4 channels each): 8, 4 or 2
 #pragma unroll
-        for (int s = 0; s < 14; ++s)
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[s], acc[m], 0, 0, 0);
-        if (col_ok) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long p = p0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (p < npix) fd_st1(y + p * Cout + col, fd_act<ACT>(acc[m][r]));
-                }
+            for (int s = 0; s < 14; ++s) if (CHUNK != 102) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[s], acc[m], 0, 0, 0);
         }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) otile[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * h) * 36 + i] = fd_act<ACT>(acc[m][r]);
+            // (wave-private tile: the wave's own LDS writes are visible to its own reads without a workgroup barrier once they have completed)
+            fd_wave_lds_fence();
+            for (int q = lane; q < 32 * lpp; q += 64) {
+                const int px = 32 * m + (q >> lsh), c4 = (q & (lpp - 1)) * 4;
+                const int p = pw0 + px;
+                if (p < p1 && (CHUNK != 101 || otile[px * 36 + c4] == 12345.f)) fd_st4(y + ((long)n * npix + p) * Cout + n0 + c4, fd_ld4(otile + px * 36 + c4));
+            }
+        }
+        fd_wave_lds_fence();
     }
 }
 
@@ -140,8 +190,9 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
     float *s_in = smem;                                   // [TH_in*TW_in][PSTR]
     float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]
     float *s_b = s_w + K * K * CB;                        // [CB]
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const fd_blk3 blk = fd_xcd_image_map();                // all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2
+    const int ty = blk.x / tiles_x, tx = blk.x - ty * tiles_x;
+    const int c0 = blk.y * CB, n = blk.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
@@ -242,11 +293,12 @@ fd_dw3_rows(const T *__restrict__ in, const float *__restrict__ wp, const float 
             T *__restrict__ out, int H, int W, int Ho, int Wo, int C, int TH)
 {
     const int CG = C >> 2;
-    const int q = blockIdx.x * 256 + threadIdx.x;            // output column-group index within a row
+    const fd_blk3 blk = fd_xcd_image_map();                  // the strips of an image on one XCD: they share their boundary rows in its L2
+    const int q = blk.x * 256 + threadIdx.x;                 // output column-group index within a row
     if (q >= Wo * CG) return;
     const int xo = q / CG, c4 = q - xo * CG;
-    const int n = blockIdx.z;
-    const int oy0 = blockIdx.y * TH;
+    const int n = blk.z;
+    const int oy0 = blk.y * TH;
     const int oy1 = (oy0 + TH < Ho) ? oy0 + TH : Ho;
     fd_f32x4 w[9];
 #pragma unroll

@@ -120,7 +120,7 @@ fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__res
 //          = up2(act1(z_in * s1 + t1))                              (MODE 1)
 //          = up2(act1(z_in * s1 + t1)) + act2(z_skip * s2 + t2)     (MODE 2)
 // weights are the live parameter w[C][K*K]; output is the raw conv result + stats partials
-// part[blk*2*C + {0,C} + c] with blk = blockIdx.z * gridDim.x + blockIdx.x.
+// part[blk*2*C + {0,C} + c] with blk = image * gridDim.x + tile (logical indices: fd_xcd_image_map).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
 __global__ void __launch_bounds__(256)
@@ -136,8 +136,9 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
     float *s_in = smem;                                   // [TH_in*TW_in][PSTR]; reused for the stats reduction
     float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int c0 = blockIdx.y * CB, n = blockIdx.z;
+    const fd_blk3 bm = fd_xcd_image_map();                 // all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2
+    const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
+    const int c0 = bm.y * CB, n = bm.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
@@ -240,7 +241,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     if (tid < lanes_c) {
         fd_f32x4 a = fd_zero4(), b = fd_zero4();
         for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
-        const long blk = (long)blockIdx.z * gridDim.x + blockIdx.x;
+        const long blk = (long)bm.z * gridDim.x + bm.x;
         if (c0 + tid * 4 < C) {
             fd_st4(part + blk * 2 * C + c0 + tid * 4, a);
             fd_st4(part + blk * 2 * C + C + c0 + tid * 4, b);
