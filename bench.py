@@ -129,6 +129,8 @@ def inference_profile(eng, x, steps, mfma_peak_tflops):
     acc /= max(steps, 1)
     by_sym = {}
     for (name, sym, info, nbytes, flops), ms in zip(stats, acc):
+        if not sym:                  # a depthwise layer evaluated in its producer's epilogue: no launch of its own (its algorithmic work is
+            continue                 # credited to the producer's launch by fd_plan_layer_stats)
         e = by_sym.setdefault(sym, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
         e["launches"] += 1; e["ms"] += float(ms); e["bytes"] += nbytes; e["flops"] += flops
     total_ms = float(acc.sum())
@@ -138,7 +140,7 @@ def inference_profile(eng, x, steps, mfma_peak_tflops):
                for s, e in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])]
     whole = {"algorithmic_GB": round(sum(s[3] for s in stats) / 1e9, 4), "algorithmic_GFLOP": round(sum(s[4] for s in stats) / 1e9, 3),
              "device_ms_sum_of_kernels": round(total_ms, 4), "roofline_bound_ms": round(layerwise_bound_ms(stats, mfma_peak_tflops), 4)}
-    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms), whole, kernels, len(stats)
+    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms), whole, kernels, sum(1 for st in stats if st[1])
 
 
 # kernel families of the train step whose launches move a unit's activations once (fwd 1x + bwd 2x the inference bytes);

@@ -89,6 +89,8 @@ struct Layer {
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0;
     int csplit = 0;              // concatenating consumer: channels [0, csplit) come from src, the rest from skip
     bool skipped = false;        // depthwise layer executed inside the following pointwise layer's fused kernel
+    int fuse_next_dw = -1;       // pointwise layer (fd_pw_gemm16_f32): index of the depthwise consumer evaluated in its epilogue
+    int fused_into = -1;         // depthwise layer: index of the pointwise layer whose kernel produces this layer's output
     int fused_dw = -1;           // pointwise layer: index of the depthwise layer fused into it
     int np = 0, flat = 0, gpw = 0;   // fused kernel: patch pixels, tile mapping, LDS-DMA instructions per wave per chunk
     bool dw_rows = false;        // register-window 3x3 kernel (fd_dw3_rows_f32) instead of the LDS-tiled one
@@ -268,10 +270,22 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
 {
     const int N = L.d.cout, K = L.d.cin;
     if (L.pw16_tm) {
+        fd_dwfuse fz{};
+        int fdw = 0;
+        if (L.fuse_next_dw >= 0) {                            // the consuming depthwise layer runs in this kernel's epilogue
+            const Layer &D = plan->layers[L.fuse_next_dw];
+            fz.w = reinterpret_cast<const float *>(plan->ws + D.w_off); fz.b = reinterpret_cast<const float *>(plan->ws + D.b_off);
+            fz.out = reinterpret_cast<float *>(plan->ws + D.out_off);
+            fz.H = L.out_h; fz.W = L.out_w; fz.S = D.d.stride; fz.up = D.d.upsample;
+            fz.hi = D.d.act == FD_ACT_RELU6 ? 6.0f : __builtin_inff();
+            fz.store_pw = (plan->flags & FD_PLAN_KEEP_ACTIVATIONS) ? 1 : 0;
+            fdw = D.d.ksize;
+        }
+#define FD_PW16_LAUNCH(TMV, FD_) \
+        do { (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, 3, ACT, 0, FD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+             FD_LAUNCH((fd_pw_gemm16_f32<TMV, 3, ACT, 0, FD_>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz); } while (0)
 #define FD_PW16_CASE(TMV) \
-    case TMV: \
-        (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, 3, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        FD_LAUNCH((fd_pw_gemm16_f32<TMV, 3, ACT>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles); break;
+    case TMV: if (fdw == 3) FD_PW16_LAUNCH(TMV, 3); else if (fdw == 5) FD_PW16_LAUNCH(TMV, 5); else FD_PW16_LAUNCH(TMV, 0); break;
         switch (L.pw16_tm) {
             FD_PW16_CASE(13)
             FD_PW16_CASE(7)
@@ -279,6 +293,7 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
         default: return fail(FD_ERR_INVALID, "no gemm16 instance for TM=%d", L.pw16_tm);
         }
 #undef FD_PW16_CASE
+#undef FD_PW16_LAUNCH
         return check_launch("fd_pw_gemm16_f32");
     }
     const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
@@ -565,6 +580,33 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     last.to_output = true;
     p->weights_bytes = woff;
 
+    // ---- fusion: a depthwise layer whose producer is a gemm16 pointwise layer with WHOLE frames per workgroup is evaluated in that
+    // kernel's epilogue (fd_pw_gemm16_f32<..., FDW>): depthwise convolution is per channel, so a workgroup that holds 64 channels of a
+    // few complete frames holds everything the consumer needs for those channels and frames.
+    if (dtype == FD_F32 && !(flags & FD_PLAN_NO_EPILOGUE_FUSION)) {
+        std::vector<int> readers(n_layers, 0);
+        for (int i = 0; i < n_layers; ++i) {
+            if (p->layers[i].d.src >= 0) ++readers[p->layers[i].d.src];
+            if (p->layers[i].d.skip >= 0) ++readers[p->layers[i].d.skip];
+        }
+        for (int j = 1; j < n_layers; ++j) {
+            Layer &D = p->layers[j];
+            if (D.d.op != FD_OP_DW || D.d.src < 0 || D.d.skip >= 0 || D.d.concat) continue;
+            Layer &Pw = p->layers[D.d.src];
+            if (!Pw.pw16_tm || readers[D.d.src] != 1) continue;       // the pointwise output must have no other reader (skip sources keep their tensor)
+            const int hw = Pw.out_h * Pw.out_w;
+            if (Pw.pw16_stride % hw || D.d.cin % 4) continue;         // whole frames per workgroup
+            if (D.d.upsample && D.d.stride != 1) continue;
+            {   // the zero-bordered frame image (+ one dump row) must fit the kernel's LDS ring
+                const int P = D.d.upsample ? (D.d.ksize / 2 + 1) / 2 : D.d.ksize / 2;
+                const long img_rows = (long)(Pw.pw16_stride / hw) * (Pw.out_h + 2 * P) * (Pw.out_w + 2 * P) + 1;
+                if ((size_t)img_rows * 68 * 4 > Pw.lds) continue;
+            }
+            Pw.fuse_next_dw = j;
+            D.fused_into = D.d.src;
+        }
+    }
+
     // ---- fusion: depthwise (stride 1, input as stored) -> pointwise pairs become ONE kernel (fd_sep_unit_f32) -------------
     // EXPERIMENTAL, opt-in (FD_PLAN_FUSE_SEPARABLE): measured on MI355X at batch 32 the fused kernel is SLOWER than the two tuned
     // kernels it replaces (conv7.3: 87 us vs 11.5 + 41 us) -- with M = 6272 rows the depthwise work is recomputed by each of the
@@ -605,7 +647,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             for (int j = 0; j < i; ++j)
                 if (last_use[j] == i - 1 && !p->layers[j].to_output && !p->layers[j].skipped) fl.release(p->layers[j].out_off - woff, p->layers[j].out_bytes);
         // (a buffer whose last reader is layer i-1 is free from layer i on; readers of layer i keep theirs)
+        if (L.fused_into >= 0) continue;                     // allocated together with its producer (below)
         L.out_off = woff + fl.alloc(L.out_bytes);
+        // a depthwise layer evaluated in this layer's epilogue is WRITTEN by this layer's kernel: its buffer must be live now, while this
+        // kernel's own inputs are still being read (it must not reuse a buffer that becomes free only after this layer)
+        if (L.fuse_next_dw >= 0) p->layers[L.fuse_next_dw].out_off = woff + fl.alloc(p->layers[L.fuse_next_dw].out_bytes);
     }
     p->ws_bytes = woff + fl.top;
     if (sk_scratch) {
@@ -632,6 +678,8 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         char buf[256];
         if (L.skipped)
             snprintf(buf, sizeof buf, "(fused into layer %d)", i + 1);
+        else if (L.fused_into >= 0)
+            snprintf(buf, sizeof buf, "(dw k%d s%d%s evaluated in the epilogue of layer %d's pw_gemm16)", d.ksize, d.stride, d.upsample ? " on up2" : "", L.fused_into);
         else if (L.fused_dw >= 0)
             snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
                      L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
@@ -651,19 +699,20 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                          L.sk_dp_rounds, L.sk_base, (int)(1000L * L.sk_rem / L.grid.x), L.lds);
             else if (L.pw16_tm)
                 snprintf(buf, sizeof buf, "pw_gemm16<TM=%d: %dx64 tile, stride %d> M=%ld N=%d K=%d tiles=%dx%d (%.2f per CU) lds=%zu", L.pw16_tm, L.pw16_tm * 16, L.pw16_stride,
-                         (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.m_tiles * L.n_tiles / 256.0, L.lds);
+                         (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.m_tiles * L.n_tiles / 256.0, L.lds),
+                L.fuse_next_dw >= 0 ? (void)snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " + fused dw k%d of layer %d", p->layers[L.fuse_next_dw].d.ksize, L.fuse_next_dw) : (void)0;
             else
             snprintf(buf, sizeof buf, "pw_gemm<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
                      L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         L.info = buf;
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
-        if (L.skipped) buf[0] = 0;
+        if (L.skipped || L.fused_into >= 0) buf[0] = 0;
         else if (L.fused_dw >= 0) snprintf(buf, sizeof buf, "fd_sep_unit_f32<%d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.act, d.act, L.gpw <= 5 ? 5 : (L.gpw == 6 ? 6 : 7));
         else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
-        else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0>", L.pw16_tm, d.act);
+        else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0, %d>", L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_%sf32<%d, %d, %d, %d, %d>", L.sk ? "sk_" : "", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);
         L.sym = buf;
@@ -727,7 +776,7 @@ int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (size_t i = 0; i < plan->layers.size(); ++i) {
         const Layer &L = plan->layers[i];
-        if (L.skipped) continue;
+        if (L.skipped || L.fused_into >= 0) continue;       // (a fused depthwise layer is produced by its producer's kernel)
         g_trace_layer = (int)i;
         int rc = run_layer(plan, L, static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
         if (rc) return rc;
@@ -881,14 +930,14 @@ int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, f
     for (auto &e : ev) if (hipEventCreate(&e) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
     int rc = FD_OK;
     for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
-        if (plan->layers[i].skipped) continue;
+        if (plan->layers[i].skipped || plan->layers[i].fused_into >= 0) continue;
         g_ev_start = ev[2 * i]; g_ev_stop = ev[2 * i + 1];
         rc = run_layer(plan, plan->layers[i], static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
     }
     g_ev_start = g_ev_stop = nullptr;
     if (rc == FD_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(FD_ERR_HIP, "hipStreamSynchronize failed");
     for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
-        if (plan->layers[i].skipped) { ms_per_layer[i] = 0.0f; continue; }
+        if (plan->layers[i].skipped || plan->layers[i].fused_into >= 0) { ms_per_layer[i] = 0.0f; continue; }
         if (hipEventElapsedTime(&ms_per_layer[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
@@ -934,8 +983,9 @@ int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_
     if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return fail(FD_ERR_INVALID, "bad layer index");
     // the per-unit convention of SURVEY.md 8(d) is kept: a fused launch is credited with both of its units' algorithmic work
     const Layer &L = plan->layers[layer];
-    double b = L.skipped ? 0.0 : L.alg_bytes, f = L.skipped ? 0.0 : L.alg_flops;
+    double b = (L.skipped || L.fused_into >= 0) ? 0.0 : L.alg_bytes, f = (L.skipped || L.fused_into >= 0) ? 0.0 : L.alg_flops;
     if (L.fused_dw >= 0) { b += plan->layers[L.fused_dw].alg_bytes; f += plan->layers[L.fused_dw].alg_flops; }
+    if (L.fuse_next_dw >= 0) { b += plan->layers[L.fuse_next_dw].alg_bytes; f += plan->layers[L.fuse_next_dw].alg_flops; }
     if (algorithmic_bytes) *algorithmic_bytes = b;
     if (algorithmic_flops) *algorithmic_flops = f;
     return FD_OK;

@@ -27,8 +27,23 @@
 //     16-byte stores of whole 256-byte rows.
 // LDS rows are 128 bytes with the XOR swizzle chunk' = chunk ^ ((row >> 1) & 7), applied to the DMA source side and to the
 // fragment reads (conflict-free for the 16-lane groups of ds_read_b128: rows r..r+15 x chunks c..c+3).
+//   * fused consumer: where a workgroup's m_stride rows are WHOLE frames of the stored output (14x14 = 196 rows, 7x7 = 49) the depthwise
+//     layer that consumes this output -- per-channel, so it needs exactly this workgroup's 64 columns of exactly these frames -- is
+//     evaluated in the epilogue, from the LDS image of the tile, and ITS output is what leaves the kernel: no launch, no HBM round trip
+//     for the intermediate tensor (3x3 stride 1 / 2, 5x5, and 5x5 on the nearest-x2 upsampling of the tile: FDW template parameter).
 #pragma once
 #include "fd_device.h"
+
+// the depthwise layer fused behind a pointwise GEMM (fd_pw_gemm16_f32<..., FDW = its kernel size>)
+struct fd_dwfuse {
+    const float *w;            // folded taps, tap-major [K*K][C]  (C = the GEMM's N)
+    const float *b;            // folded bias [C]
+    float *out;                // its output, NHWC [frames][Ho][Wo][C]
+    int H, W;                  // frame size of the GEMM's stored output (m_stride % (H*W) == 0)
+    int S, up;                 // stride (1 | 2); up = 1: the input is the nearest-x2 upsampling of the frame (S == 1)
+    float hi;                  // activation: clamp(0, hi), hi = 6 (ReLU6) or +inf (ReLU)
+    int store_pw;              // also store the GEMM's own output (plans that keep every layer's activations)
+};
 
 template <int N> struct fd_int { static constexpr int value = N; };
 #ifdef FD_GEMM16_PROBE
@@ -38,10 +53,10 @@ __device__ long long fd_gemm16_probe[4 * 4096];          // measurement aid (too
 // ABL (measurement aid, 0 in the product): 1 = no LDS-DMA in the steady state (stages keep the first tiles), 2 = also no fragment reads,
 // 3 = also no per-tile barrier, 4 = full K loop but no global stores -- wrong results, used by tools/microbench/gemm16.hip to price each
 // ingredient of the kernel.
-template <int TM, int STAGES, int ACT, int ABL = 0>
+template <int TM, int STAGES, int ACT, int ABL = 0, int FDW = 0>
 __global__ void __launch_bounds__(512)
 fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
-                 float *__restrict__ out, int M, int N, int K, int K32, int m_stride, int m_tiles, int n_tiles)
+                 float *__restrict__ out, int M, int N, int K, int K32, int m_stride, int m_tiles, int n_tiles, const fd_dwfuse fz)
 {
     constexpr int BM = TM * 16, BN = 64, BK = 32, ROWS = BM + BN;
     constexpr int STAGE = ROWS * BK;                        // floats per stage
@@ -174,16 +189,44 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
 
     // ---- epilogue: the two k-halves meet in the [row][col] image of the output tile in LDS.  Every wave deposits the partial sums of
     // the row tiles its partner finishes (leader: [0, H), follower: [H, TM)); the owner adds its own, applies the activation in
-    // place, and the finished image leaves as whole 256-byte rows, 16 bytes per lane. ----
+    // place, and the finished image leaves as whole 256-byte rows, 16 bytes per lane.
+    // With a fused depthwise consumer (FDW) the image is laid out as zero-bordered frames -- pixel (y, x) of frame f sits in image row
+    // f*PH*PW + (y + P)*PW + (x + P), P = the consumer's padding in stored pixels -- so that its taps are branch-free reads at constant
+    // offsets; `rowmap` translates a tile row (= pixel number) into its image row. ----
     constexpr int H = (TM + 1) / 2;
+    constexpr int KD = FDW == 0 ? 1 : FDW;
+    __shared__ int rowmap[FDW != 0 ? BM : 1];
+    int rows = M - m0 < m_stride ? (int)(M - m0) : m_stride;
+    if (rows > BM) rows = BM;
+    const int fH = fz.H, fW = fz.W, fHW = fH * fW, us = (FDW != 0 && fz.up) ? 1 : 0;
+    const int P = FDW == 0 ? 0 : (us ? (KD / 2 + 1) / 2 : KD / 2);           // border in stored pixels (the upsampled 5x5 reaches 1 stored pixel out)
+    const int PW = fW + 2 * P, PHW = (fH + 2 * P) * PW;
+    const int frames = FDW != 0 ? rows / fHW : 0;
     fd_block_barrier_lds();                                  // every wave is done with the ring (all tiles landed and read)
-    float *img = smem + (4 * (lane >> 4)) * OP + wn * 16 + (lane & 15);       // D register r of lane l: row 4*(l>>4) + r, column l & 15
+    if (FDW != 0) {
+        const int img_rows = frames * PHW + 1;                // + a dump row for the tile's slack rows
+        for (int i = tid; i < img_rows * (OP / 4); i += 512) fd_st4(smem + i * 4, fd_zero4());
+        for (int t = tid; t < BM; t += 512) {
+            const int fr = t / fHW, rem = t - fr * fHW, y = rem / fW, x = rem - y * fW;
+            rowmap[t] = fr < frames ? fr * PHW + (y + P) * PW + (x + P) : frames * PHW;
+        }
+        __syncthreads();
+    }
+    int prow[TM][4];                                          // image row of D register r of row tile i: tile row i*16 + 4*(l>>4) + r
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = i * 16 + 4 * (lane >> 4) + r;
+            prow[i][r] = FDW != 0 ? rowmap[t] : t;
+        }
+    float *img = smem + wn * 16 + (lane & 15);                // column l & 15 of this wave's 16-column block
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const bool mine = leader ? i < H : i >= H;
         if (!mine) {
-            float *o = img + i * 16 * OP;
-            o[0] = acc[i].x; o[OP] = acc[i].y; o[2 * OP] = acc[i].z; o[3 * OP] = acc[i].w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[prow[i][r] * OP] = acc[i][r];
         }
     }
     __syncthreads();
@@ -191,9 +234,8 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
     for (int i = 0; i < TM; ++i) {
         const bool mine = leader ? i < H : i >= H;
         if (mine) {
-            float *o = img + i * 16 * OP;
-            o[0] = fd_act<ACT>(acc[i].x + o[0]); o[OP] = fd_act<ACT>(acc[i].y + o[OP]);
-            o[2 * OP] = fd_act<ACT>(acc[i].z + o[2 * OP]); o[3 * OP] = fd_act<ACT>(acc[i].w + o[3 * OP]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float *o = img + prow[i][r] * OP; o[0] = fd_act<ACT>(acc[i][r] + o[0]); }
         }
     }
     __syncthreads();
@@ -201,11 +243,53 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
     if (tid == 0) { fd_gemm16_probe[4 * blockIdx.x] = pc0; fd_gemm16_probe[4 * blockIdx.x + 1] = clock64(); fd_gemm16_probe[4 * blockIdx.x + 2] = pw0; fd_gemm16_probe[4 * blockIdx.x + 3] = wall_clock64(); }
 #endif
     if (ABL == 4) return;
-    int rows = M - m0 < m_stride ? (int)(M - m0) : m_stride;
-    if (rows > BM) rows = BM;
     const int c4 = (lane & 15) * 4;
-    if (n0 + c4 < N) {                                       // N % 4 == 0: a lane's 4 columns are all inside or all outside
+    if ((FDW == 0 || fz.store_pw) && n0 + c4 < N) {          // N % 4 == 0: a lane's 4 columns are all inside or all outside
         for (int r = wave * 4 + (lane >> 4); r < rows; r += 32)
-            fd_st4(out + (m0 + r) * N + n0 + c4, fd_ld4(smem + r * OP + c4));
+            fd_st4(out + (m0 + r) * N + n0 + c4, fd_ld4(smem + (FDW != 0 ? rowmap[r] : r) * OP + c4));
+    }
+    if (FDW != 0) {
+        // ---- the consuming depthwise layer on the zero-bordered frames: work-item = 4 channels (cg) x every 32nd output pixel of a frame ----
+        constexpr int PD = KD / 2;
+        const int cg = tid & 15, pl = tid >> 4;
+        const int c = n0 + cg * 4;
+        if (c >= N) return;
+        fd_f32x4 wv[KD * KD];
+#pragma unroll
+        for (int t = 0; t < KD * KD; ++t) wv[t] = fd_ld4(fz.w + (long)t * N + c);
+        const fd_f32x4 b4 = fd_ld4(fz.b + c);
+        const int S = fz.S;
+        const int Ho = (fH << us) / S, Wo = (fW << us) / S, HWo = Ho * Wo;
+        const long f0 = m0 / fHW;
+        const int dy = 32 / Wo, dx = 32 - dy * Wo;
+        for (int fr = 0; fr < frames; ++fr) {
+            const float *img_f = smem + (long)fr * PHW * OP + cg * 4;
+            int oy = pl / Wo, ox = pl - oy * Wo;                 // pixel pl, pl + 32, ...: walked without further divisions
+            for (int op = pl; op < HWo; op += 32) {
+                fd_f32x4 a4 = b4;
+                if (us) {
+                    // tap (ky, kx) of output (oy, ox) reads stored pixel ((oy - PD + ky) >> 1, (ox - PD + kx) >> 1): arithmetic shifts, border P = 1
+                    int ry[KD], rx[KD];
+#pragma unroll
+                    for (int k = 0; k < KD; ++k) { ry[k] = (((oy - PD + k) >> 1) + P) * PW; rx[k] = ((ox - PD + k) >> 1) + P; }
+#pragma unroll
+                    for (int ky = 0; ky < KD; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < KD; ++kx) a4 += fd_ld4(img_f + (ry[ky] + rx[kx]) * OP) * wv[ky * KD + kx];
+                } else {
+                    const float *p0 = img_f + ((oy * S) * PW + ox * S) * OP;       // tap (0, 0): stored pixel (oy*S - PD, ox*S - PD) = image (oy*S, ox*S)
+#pragma unroll
+                    for (int ky = 0; ky < KD; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < KD; ++kx) a4 += fd_ld4(p0 + (ky * PW + kx) * OP) * wv[ky * KD + kx];
+                }
+                fd_f32x4 r4;
+                r4.x = fminf(fmaxf(a4.x, 0.0f), fz.hi); r4.y = fminf(fmaxf(a4.y, 0.0f), fz.hi);
+                r4.z = fminf(fmaxf(a4.z, 0.0f), fz.hi); r4.w = fminf(fmaxf(a4.w, 0.0f), fz.hi);
+                fd_st4(fz.out + ((f0 + fr) * HWo + op) * N + c, r4);
+                ox += dx; oy += dy;
+                if (ox >= Wo) { ox -= Wo; ++oy; }
+            }
+        }
     }
 }

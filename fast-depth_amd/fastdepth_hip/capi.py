@@ -26,6 +26,7 @@ FD_PLAN_STREAMK = 32
 FD_PLAN_FORCE_GEMM16 = 16
 FD_PLAN_NO_GEMM16 = 64
 FD_PLAN_CONCURRENT_WGRAD = 128
+FD_PLAN_NO_EPILOGUE_FUSION = 512
 
 
 class LayerDesc(ctypes.Structure):

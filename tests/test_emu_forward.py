@@ -56,10 +56,15 @@ def test_emulated_gemm16_matches_oracle(name, plan, b, hw):
     m = small_model(plan[0], plan[1], seed=21)
     x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(8))
     err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), flags=harness.capi.FD_PLAN_FORCE_GEMM16)
-    used = [s for s in info if "pw_gemm16" in s]
+    used = [s for s in info if s.startswith("pw_gemm16")]
     assert len(used) == 18, info
     if name == "ragged":
         assert {s.split("TM=")[1].split(":")[0] for s in used} == {"13", "7", "4"}, used
+    if name == "tiny":
+        # 64 x 64 frames: from 4 x 4 down a workgroup holds whole frames, so the depthwise consumers run in the GEMM epilogues -- all four
+        # variants: 3x3 stride 1, 3x3 stride 2, 5x5, 5x5 on the nearest-x2 upsampling (each checked layer-wise against the oracle above)
+        fused = [s for s in info if "evaluated in the epilogue" in s]
+        assert {s.split("(dw ")[1].split(" evaluated")[0] for s in fused} >= {"k3 s1", "k3 s2", "k5 s1", "k5 s1 on up2"}, fused
     bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
     assert not bad and err < TOL, bad
 

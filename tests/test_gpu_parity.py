@@ -262,7 +262,7 @@ def test_forced_gemm16_layerwise(pruned, b):
     m = harness.randomize_bn(models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None), 71 + b)
     x = inputs.batch_variants(inputs.load_sample()[0], b, seed=6)
     err, per_layer, info = harness.compare_with_oracle("hip", m, x, torch.device("cuda"), flags=harness.capi.FD_PLAN_FORCE_GEMM16)
-    assert sum("pw_gemm16" in s for s in info) == 18, info
+    assert sum(s.startswith("pw_gemm16") for s in info) == 18, info
     bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
     assert not bad and err < TOL, bad
 
@@ -272,7 +272,7 @@ def test_batch32_plan_selects_gemm16():
     plan = harness.CPlan("hip", m, inputs.batch_variants(inputs.load_sample()[0], 32, seed=0).cuda(), keep=False)
     info = plan.info()
     plan.close()
-    assert sum("pw_gemm16" in s for s in info) >= 10, info
+    assert sum(s.startswith("pw_gemm16") for s in info) >= 10 and sum("evaluated in the epilogue" in s for s in info) >= 8, info
 
 
 def test_batched_evaluation_equals_per_image_protocol(tmp_path):

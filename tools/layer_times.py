@@ -24,5 +24,7 @@ for _ in range(a.iters): acc += np.array(eng.forward_timed(x)[1])
 acc /= a.iters
 print("%-18s %-34s %8s %8s %8s  %s" % ("layer", "kernel", "us", "GB/s", "TF/s", "info"))
 for (name, sym, info, nb, fl), ms in zip(stats, acc):
+    if not sym:
+        print("%-18s %-34s %8s %8s %8s  %s" % (name, "", "-", "-", "-", info)); continue
     print("%-18s %-34s %8.1f %8.0f %8.1f  %s" % (name, sym, ms * 1e3, nb / ms / 1e6, fl / ms / 1e9, info))
 print("sum of kernels: %.4f ms; algorithmic %.3f GB, %.2f GFLOP" % (acc.sum(), sum(s[3] for s in stats) / 1e9, sum(s[4] for s in stats) / 1e9))
