@@ -14,6 +14,7 @@
 #include "fd_kernels_sk_f32.h"
 #include "fd_kernels_fused_f32.h"
 #endif
+#include "fd_kernels_dwpw_f32.h"
 #include "../../include/fastdepth_hip.h"
 
 #include <algorithm>
@@ -93,6 +94,8 @@ struct Layer {
     int fused_into = -1;         // depthwise layer: index of the pointwise layer whose kernel produces this layer's output
     int fused_dw = -1;           // pointwise layer: index of the depthwise layer fused into it
     int np = 0, flat = 0, gpw = 0;   // fused kernel: patch pixels, tile mapping, LDS-DMA instructions per wave per chunk
+    bool dwpw = false;           // pointwise layer: fused_dw runs inside fd_dwpw_f32 (large maps: tile of pixels x all output channels)
+    int dp_th = 0, dp_tw = 0 /* log2 of the tile width */, dp_tiles_x = 0, dp_wm = 0, dp_nt = 0, dp_nld = 0, dp_xcd = 0;
     bool dw_rows = false;        // register-window 3x3 kernel (fd_dw3_rows_f32) instead of the LDS-tiled one
     // stem
     int chunk = 0;
@@ -352,6 +355,38 @@ int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *
 
 #endif
 
+
+// depthwise + pointwise unit of a large map as one kernel (fd_kernels_dwpw_f32.h)
+template <int ACT>
+int launch_dwpw(const fd_plan *p, const Layer &L, float *out, hipStream_t s)
+{
+    const Layer &D = p->layers[L.fused_dw];
+    const float *din = reinterpret_cast<const float *>(p->ws + p->layers[D.d.src].out_off);
+    const float *dskip = D.d.skip >= 0 ? reinterpret_cast<const float *>(p->ws + p->layers[D.d.skip].out_off) : nullptr;
+    const float *wdw = reinterpret_cast<const float *>(p->ws + D.w_off), *bdw = reinterpret_cast<const float *>(p->ws + D.b_off);
+    const float *wp = reinterpret_cast<const float *>(p->ws + L.w_off), *bias = reinterpret_cast<const float *>(p->ws + L.b_off);
+    const int key = D.d.ksize * 1000 + D.d.stride * 100 + D.mode * 10 + L.dp_nt;
+#define FD_DWPW_CASE(KSV, SV, MODEV, WMV, NTV, NLDV)                                                                                   \
+    case KSV * 1000 + SV * 100 + MODEV * 10 + NTV:                                                                                     \
+        (void)hipFuncSetAttribute((const void *)fd_dwpw_f32<KSV, SV, MODEV, ACT, WMV, NTV, NLDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        FD_LAUNCH((fd_dwpw_f32<KSV, SV, MODEV, ACT, WMV, NTV, NLDV>), L.grid, dim3(512), L.lds, s, din, dskip, wdw, bdw, wp, bias, out, p->B, D.in_h, D.in_w, \
+                  D.out_h, D.out_w, D.d.cin, L.w_pitch, L.d.cout, L.dp_th, L.dp_tw, L.dp_tiles_x, L.dp_tiles_x * ceil_div(D.out_h, L.dp_th), L.dp_xcd);      \
+        break;
+    switch (key) {
+        FD_DWPW_CASE(3, 1, 0, 4, 1, 6)
+        FD_DWPW_CASE(3, 1, 0, 4, 2, 6)
+        FD_DWPW_CASE(3, 1, 0, 4, 4, 6)
+        FD_DWPW_CASE(5, 1, 2, 4, 1, 8)
+        FD_DWPW_CASE(5, 1, 2, 4, 2, 8)
+        FD_DWPW_CASE(5, 1, 2, 4, 4, 8)
+        FD_DWPW_CASE(3, 2, 0, 2, 2, 10)
+        FD_DWPW_CASE(3, 2, 0, 2, 4, 10)
+    default: return fail(FD_ERR_INVALID, "no fd_dwpw_f32 instance %d", key);
+    }
+#undef FD_DWPW_CASE
+    return check_launch("fd_dwpw_f32");
+}
+
 template <int ACT>
 int launch_pw_t(const fd_plan *plan, const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
 {
@@ -384,6 +419,10 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
             const long npix = (long)p->B * h * w;
             FD_LAUNCH((fd_head_pw1<T, ACT>), L.grid, dim3(256), 0, s, in, wpf, bias, y, npix, h, w, L.d.cin, L.d.upsample);
             return check_launch("fd_head_pw1");
+        }
+        if (L.dwpw) {
+            if constexpr (std::is_same<T, float>::value) return launch_dwpw<ACT>(p, L, out, s);
+            else return fail(FD_ERR_INVALID, "fused units are fp32 only");
         }
 #ifdef FD_EXPERIMENTS
         if (L.fused_dw >= 0) {
@@ -607,6 +646,60 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         }
     }
 
+    // ---- fusion: depthwise -> pointwise units of the LARGE maps become one kernel (fd_dwpw_f32): the depthwise output (up to 103 MB at
+    // batch 32) never makes its HBM round trip.  Applies where a workgroup can own a pixel tile with ALL output channels (N <= 128, or
+    // <= 256 behind a stride-2 depthwise) -- on the small maps the GEMM is the cost and the opposite fusion (above) is used.
+    if (dtype == FD_F32 && !(flags & FD_PLAN_NO_UNIT_FUSION) && (!(flags & FD_PLAN_KEEP_ACTIVATIONS) || (flags & FD_PLAN_FORCE_UNIT_FUSION))) {
+        std::vector<int> readers(n_layers, 0);
+        for (int i = 0; i < n_layers; ++i) {
+            if (p->layers[i].d.src >= 0) ++readers[p->layers[i].d.src];
+            if (p->layers[i].d.skip >= 0) ++readers[p->layers[i].d.skip];
+        }
+        for (int i = 0; i + 1 < n_layers; ++i) {
+            Layer &D = p->layers[i], &Pw = p->layers[i + 1];
+            if (D.d.op != FD_OP_DW || D.fused_into >= 0 || D.skipped || D.d.src < 0 || readers[i] != 1) continue;
+            if (Pw.d.op != FD_OP_PW || Pw.head || Pw.d.src != i || Pw.d.upsample || Pw.fuse_next_dw >= 0 || Pw.to_output) continue;
+            const int C = D.d.cin, N = Pw.d.cout, KS = D.d.ksize, S = D.d.stride;
+            if (D.d.act != Pw.d.act || D.d.act == FD_ACT_NONE || C % 32 || C > 256 || N % 32) continue;
+            int wm = 0, nld = 0;
+            if (KS == 3 && S == 1 && D.mode == 0) { wm = 4; nld = 6; }
+            else if (KS == 5 && S == 1 && D.mode == 2) { wm = 4; nld = 8; }
+            else if (KS == 3 && S == 2 && D.mode == 0) { wm = 2; nld = 10; }
+            else continue;
+            const int wn = 4 / wm, nt = N / 32 / wn;
+            if (nt * wn * 32 != N || !(nt == 1 || nt == 2 || nt == 4) || (wm == 2 && nt == 1)) continue;
+            // Where it pays (measured in the batch-32 plan): units with <= 64 depthwise channels on maps of >= 28x28
+            // pixels (conv1: 52.7 -> 39 us, conv2: 50.4 -> 42 us, decode_conv5: 87 -> 80 us).  The 128-channel units are bound by the fp32
+            // MFMAs (conv3) or the 5x5 taps' LDS reads (decode_conv4) and lose 7 us each; small maps are launch-bound and use the
+            // GEMM-epilogue fusion above.
+            if (!(flags & FD_PLAN_FORCE_UNIT_FUSION) && (C > 64 || D.out_h * D.out_w < 28 * 28)) continue;
+            // the whole weight matrix, the taps and two A tiles stay in LDS next to the patch
+            const size_t lds = ((size_t)nld * 32 * 36 + 2 * 32 * wm * 32 + (size_t)N * C + (size_t)KS * KS * C + C) * 4;
+            if ((C / 32) & (C / 32 - 1) || lds > 160 * 1024) continue;
+            // pixel tile: TH x TW <= 32*wm outputs, TW a power of two >= 4, patch <= 32*nld pixels; fewest staged patch pixels + MFMA rows wins
+            long best = -1; int bth = 0, btw = 0;
+            for (int tws = 2; tws <= 5; ++tws) {
+                const int tw = 1 << tws;
+                if (tw > 32 * wm || (tw > 4 && tw >= 2 * D.out_w)) continue;
+                for (int th = 1; th * tw <= 32 * wm && th <= D.out_h; ++th) {
+                    const int ph = (th - 1) * S + KS, pw = (tw - 1) * S + KS;
+                    if (ph * pw > 32 * nld) continue;
+                    const long tiles = (long)ceil_div(D.out_h, th) * ceil_div(D.out_w, tw);
+                    const long cost = tiles * (ph * pw + 32 * wm);
+                    if (best < 0 || cost < best) { best = cost; bth = th; btw = tws; }
+                }
+            }
+            if (best < 0) continue;
+            D.skipped = true;
+            Pw.fused_dw = i; Pw.dwpw = true; Pw.pw16_tm = 0; Pw.sk = false;
+            Pw.dp_th = bth; Pw.dp_tw = btw; Pw.dp_tiles_x = ceil_div(D.out_w, 1 << btw); Pw.dp_wm = wm; Pw.dp_nt = nt; Pw.dp_nld = nld;
+            const long tiles = (long)Pw.dp_tiles_x * ceil_div(D.out_h, bth) * batch;
+            Pw.dp_xcd = batch >= 8 ? 1 : 0;                    // images dealt to XCDs (b mod 8); small batches: tiles dealt round-robin
+            Pw.grid = dim3((unsigned)(Pw.dp_xcd ? 256 : std::min<long>(256, tiles)));
+            Pw.lds = lds;
+        }
+    }
+
     // ---- fusion: depthwise (stride 1, input as stored) -> pointwise pairs become ONE kernel (fd_sep_unit_f32) -------------
     // EXPERIMENTAL, opt-in (FD_PLAN_FUSE_SEPARABLE): measured on MI355X at batch 32 the fused kernel is SLOWER than the two tuned
     // kernels it replaces (conv7.3: 87 us vs 11.5 + 41 us) -- with M = 6272 rows the depthwise work is recomputed by each of the
@@ -637,7 +730,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     for (int i = 0; i < n_layers; ++i) {
         if (p->layers[i].d.src >= 0) last_use[p->layers[i].d.src] = i;
         if (p->layers[i].d.skip >= 0) last_use[p->layers[i].d.skip] = i;
-        if (p->layers[i].fused_dw >= 0) last_use[p->layers[p->layers[i].fused_dw].d.src] = i;   // the fused kernel reads the depthwise layer's input
+        if (p->layers[i].fused_dw >= 0) {                     // the fused kernel reads the depthwise layer's inputs
+            const fd_layer_desc &dd = p->layers[p->layers[i].fused_dw].d;
+            last_use[dd.src] = i;
+            if (dd.skip >= 0) last_use[dd.skip] = i;
+        }
     }
     FreeList fl;
     for (int i = 0; i < n_layers; ++i) {
@@ -680,6 +777,9 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             snprintf(buf, sizeof buf, "(fused into layer %d)", i + 1);
         else if (L.fused_into >= 0)
             snprintf(buf, sizeof buf, "(dw k%d s%d%s evaluated in the epilogue of layer %d's pw_gemm16)", d.ksize, d.stride, d.upsample ? " on up2" : "", L.fused_into);
+        else if (L.dwpw)
+            snprintf(buf, sizeof buf, "dwpw<dw k%d s%d mode%d + pw> persistent, 4 producer + 4 consumer waves; tile %dx%d px x all %d channels, C=%d in %d chunks, weights in LDS, grid=%u lds=%zu", p->layers[L.fused_dw].d.ksize,
+                     p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, L.dp_th, 1 << L.dp_tw, d.cout, d.cin, d.cin / 32, L.grid.x, L.lds);
         else if (L.fused_dw >= 0)
             snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
                      L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
@@ -707,6 +807,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         L.info = buf;
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
         if (L.skipped || L.fused_into >= 0) buf[0] = 0;
+        else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld);
         else if (L.fused_dw >= 0) snprintf(buf, sizeof buf, "fd_sep_unit_f32<%d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.act, d.act, L.gpw <= 5 ? 5 : (L.gpw == 6 ? 6 : 7));
         else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);

@@ -73,6 +73,9 @@ __device__ __forceinline__ fd_blk3 fd_xcd_image_map2()     // grid (x, images)
     return fd_xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y);
 }
 
+// compile-time integer as a value (selects statically indexed register sets inside generic lambdas)
+template <int N> struct fd_int { static constexpr int value = N; };
+
 typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 typedef float fd_f32x2 __attribute__((ext_vector_type(2)));
 typedef float fd_f32x16 __attribute__((ext_vector_type(16)));
@@ -86,7 +89,11 @@ template <int ACT>
 __device__ __forceinline__ float fd_act(float v)
 {
     if (ACT == FD_ACT_RELU_) return fmaxf(v, 0.0f);
+#ifdef FD_EMU
     if (ACT == FD_ACT_RELU6_) return fminf(fmaxf(v, 0.0f), 6.0f);
+#else
+    if (ACT == FD_ACT_RELU6_) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);     // one v_med3_f32 (same value for every non-NaN input)
+#endif
     return v;
 }
 template <int ACT>

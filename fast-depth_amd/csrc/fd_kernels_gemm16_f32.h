@@ -45,7 +45,6 @@ struct fd_dwfuse {
     int store_pw;              // also store the GEMM's own output (plans that keep every layer's activations)
 };
 
-template <int N> struct fd_int { static constexpr int value = N; };
 #ifdef FD_GEMM16_PROBE
 __device__ long long fd_gemm16_probe[4 * 4096];          // measurement aid (tools/microbench/gemm16.hip): shader-clock and 100 MHz timestamps per workgroup
 #endif

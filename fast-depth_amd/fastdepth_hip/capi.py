@@ -27,6 +27,8 @@ FD_PLAN_FORCE_GEMM16 = 16
 FD_PLAN_NO_GEMM16 = 64
 FD_PLAN_CONCURRENT_WGRAD = 128
 FD_PLAN_NO_EPILOGUE_FUSION = 512
+FD_PLAN_NO_UNIT_FUSION = 1024
+FD_PLAN_FORCE_UNIT_FUSION = 2048
 
 
 class LayerDesc(ctypes.Structure):

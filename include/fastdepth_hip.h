@@ -56,6 +56,8 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_WGRAD_TILE_ROWS 8u  /* train plans: depthwise weight-gradient workgroups always walk a whole row of tiles (default: only when that still leaves >= ~1536 workgroups); lets small test shapes exercise the tile loop */
 #define FD_PLAN_FORCE_GEMM16 16u     /* every fp32 pointwise layer with cout % 4 == 0 runs on fd_pw_gemm16_f32 (16x16x4 MFMA, one workgroup per CU), whatever its shape: lets small test shapes exercise that kernel; default: only where one round of workgroups covers the layer */
 #define FD_PLAN_NO_EPILOGUE_FUSION 512u /* never evaluate a depthwise layer in the epilogue of its pointwise producer (A/B measurements, tests of the unfused kernels) */
+#define FD_PLAN_NO_UNIT_FUSION 1024u   /* never run a depthwise + pointwise unit of a large map as one kernel (fd_dwpw_f32): A/B measurements, tests of the unfused kernels */
+#define FD_PLAN_FORCE_UNIT_FUSION 2048u /* fd_dwpw_f32 for every eligible depthwise + pointwise pair whatever the map size: lets small test shapes exercise that kernel */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
 /* The three flags below select experiments that were measured no faster than the default path; they exist only in
  * libraries built with -DFD_EXPERIMENTS (the emulator test build), the product library rejects them. */

@@ -69,6 +69,43 @@ def test_emulated_gemm16_matches_oracle(name, plan, b, hw):
     assert not bad and err < TOL, bad
 
 
+UNITS = ((32, 64, 128, 128, 256, 256, 40, 40, 40, 40, 40, 40, 48, 48), (40, 256, 128, 64, 32, 1))   # the large-map units at full width
+
+
+@pytest.mark.parametrize("b,hw", [(2, (64, 64)), (1, (96, 160)), (9, (32, 32))])
+def test_emulated_dwpw_units_match_oracle(b, hw):
+    """fd_dwpw_f32 (depthwise + pointwise unit of a large map as ONE persistent, wave-specialised kernel: producer waves stage patch
+    chunks and run the depthwise taps into the GEMM's A tile, consumer waves run the 32x32x2 MFMAs over all output channels) forced
+    onto every eligible pair: conv1 / conv3 (3x3 stride 1), conv2 (3x3 stride 2, 64-pixel tiles), decode_conv4 / 5 (5x5 on up2(low) +
+    skip); 1..4 channel chunks, several tiles per workgroup at batch 2, ragged tiles (96 x 160 input: 48 x 80, 24 x 40 maps), checked
+    layer by layer against the oracle."""
+    from oracle import oracle
+    m = small_model(UNITS[0], UNITS[1], seed=31).eval()
+    x = torch.rand(b, 3, *hw, generator=torch.Generator().manual_seed(9))
+    y_ref, taps_ref = oracle.forward(m.state_dict(), x.numpy(), taps=True)
+    cp = harness.CPlan("emu", m, x, keep=True, flags=harness.capi.FD_PLAN_FORCE_UNIT_FUSION)
+    info = cp.info()
+    y = cp.forward(x).numpy()
+    units = [i for i, s in enumerate(info) if s.startswith("dwpw<")]
+    assert len(units) == 5, info
+    assert {info[i].split("<")[1].split(" +")[0] for i in units} == {"dw k3 s1 mode0", "dw k3 s2 mode0", "dw k5 s1 mode2"}, info
+    for i in range(len(taps_ref) - 1):
+        if info[i].startswith("(fused into"):
+            continue
+        e = harness.rel_err(cp.tap(i).numpy(), taps_ref[i])
+        assert e < TOL, (i, e, info[i])
+    assert harness.rel_err(y, y_ref) < TOL
+    cp.close()
+    # the default plan (no force flag, no kept activations) selects the kernel only where it was measured to pay: units with <= 64 depthwise
+    # channels on maps of >= 28 x 28 pixels (conv1, conv2, decode_conv5)
+    cp = harness.CPlan("emu", m, x, keep=False)
+    sel = [s for s in cp.info() if s.startswith("dwpw<")]
+    y2 = cp.forward(x).numpy()
+    cp.close()
+    assert len(sel) == {(64, 64): 2, (96, 160): 3, (32, 32): 0}[hw], sel     # (batch 9: images dealt to XCDs, a ragged last group)
+    assert harness.rel_err(y2, y_ref) < TOL
+
+
 def test_plan_rejects_bad_shapes():
     m = small_model(*TINY, seed=1)
     with pytest.raises(harness.capi.FastDepthError):

@@ -275,6 +275,45 @@ def test_batch32_plan_selects_gemm16():
     assert sum(s.startswith("pw_gemm16") for s in info) >= 10 and sum("evaluated in the epilogue" in s for s in info) >= 8, info
 
 
+@pytest.mark.parametrize("b,h,w", [(3, 224, 224), (2, 160, 288)])
+def test_dwpw_units_layerwise(b, h, w):
+    """fd_dwpw_f32 (depthwise + pointwise unit of a large map as one persistent, wave-specialised kernel) on every eligible pair --
+    conv1..conv3 and decode_conv4 / 5 at full width -- with the other layers' outputs kept, layer by layer against the C oracle;
+    160 x 288 gives ragged tiles (80 x 144, 40 x 72 maps); batch 3 / 2 use the round-robin tile deal, the batch-32 test below the
+    per-XCD image deal."""
+    models = inputs.product_models()
+    torch.manual_seed(90 + b)
+    m = harness.randomize_bn(models.MobileNetSkipAdd((h, w), pretrained=False), 91 + b).eval()
+    x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(92 + b))
+    y_ref, taps_ref = oracle.forward(m.state_dict(), x.numpy(), taps=True)
+    cp = harness.CPlan("hip", m, x.cuda(), keep=True, flags=harness.capi.FD_PLAN_FORCE_UNIT_FUSION)
+    info = cp.info()
+    y = cp.forward(x.cuda()).cpu().numpy()
+    assert sum(s.startswith("dwpw<") for s in info) == 5, info
+    for i in range(len(taps_ref) - 1):
+        if info[i].startswith("(fused into"):
+            continue
+        e = harness.rel_err(cp.tap(i).cpu().numpy(), taps_ref[i])
+        assert e < TOL, (i, e, info[i])
+    assert harness.rel_err(y, y_ref) < TOL
+    cp.close()
+
+
+def test_batch32_plan_selects_dwpw_units():
+    m, x, _, _ = inputs.golden_case("base_s0")
+    xb = inputs.batch_variants(inputs.load_sample()[0], 32, seed=0).cuda()
+    plan = harness.CPlan("hip", m, xb, keep=False)
+    info = plan.info()
+    y = plan.forward(xb)
+    plan.close()
+    assert sum(s.startswith("dwpw<") for s in info) == 3, info          # conv1, conv2, decode_conv5 (where the fused unit was measured to pay)
+    plain = harness.CPlan("hip", m, xb, keep=False, flags=harness.capi.FD_PLAN_NO_UNIT_FUSION)
+    assert not any(s.startswith("dwpw<") for s in plain.info())
+    y0 = plain.forward(xb)
+    plain.close()
+    assert harness.rel_err(y.cpu().numpy(), y0.cpu().numpy()) < 1e-5      # same arithmetic, different summation order in the GEMMs
+
+
 def test_batched_evaluation_equals_per_image_protocol(tmp_path):
     """The reference evaluates one image at a time and averages the per-image metrics (main.py:40-41 batch size 1, :80-82); RMSE / iRMSE
     of pooled pixels are not that average.  fd_depth_metrics_frames gives the ten sums per image, so the harness at --batch-size 4
