@@ -107,6 +107,7 @@ __device__ __forceinline__ fd_f32x4 fd_ld4(const float *p) { return *reinterpret
 __device__ __forceinline__ void fd_st4(float *p, fd_f32x4 v) { *reinterpret_cast<fd_f32x4 *>(p) = v; }
 
 // ---- 16-bit storage types (activations / pointwise weights; all arithmetic and accumulation stay fp32) ---------------
+typedef float fd_f32x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 fd_half;
 struct fd_bf16 { unsigned short v; };                       // raw bfloat16 bits
 typedef _Float16 fd_f16x4 __attribute__((ext_vector_type(4)));
@@ -115,12 +116,25 @@ typedef unsigned short fd_u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short fd_u16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float fd_bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+#ifdef FD_EMU
 __device__ __forceinline__ unsigned short fd_f32_to_bf16(float f)
 {   // round to nearest even (NaN handling is not needed on this path: inputs are finite)
     unsigned u = __builtin_bit_cast(unsigned, f);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+// two values -> one 32-bit word (low half = a)
+__device__ __forceinline__ unsigned fd_f32x2_to_bf16x2(float a, float b) { return (unsigned)fd_f32_to_bf16(a) | ((unsigned)fd_f32_to_bf16(b) << 16); }
+#else
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round to nearest even: the same value as the integer formula above for every finite input)
+__device__ __forceinline__ unsigned short fd_f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned fd_f32x2_to_bf16x2(float a, float b)
+{
+    typedef __bf16 fd_bf16x2_hw __attribute__((ext_vector_type(2)));
+    const fd_f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, fd_bf16x2_hw));
+}
+#endif
 // 4 consecutive channels: one 8-byte access
 __device__ __forceinline__ fd_f32x4 fd_ld4(const fd_half *p)
 {
@@ -141,8 +155,9 @@ __device__ __forceinline__ fd_f32x4 fd_ld4(const fd_bf16 *p)
 }
 __device__ __forceinline__ void fd_st4(fd_bf16 *p, fd_f32x4 v)
 {
-    fd_u16x4 h = {fd_f32_to_bf16(v.x), fd_f32_to_bf16(v.y), fd_f32_to_bf16(v.z), fd_f32_to_bf16(v.w)};
-    *reinterpret_cast<fd_u16x4 *>(p) = h;
+    typedef unsigned fd_u32x2 __attribute__((ext_vector_type(2)));
+    const fd_u32x2 h = {fd_f32x2_to_bf16x2(v.x, v.y), fd_f32x2_to_bf16x2(v.z, v.w)};
+    *reinterpret_cast<fd_u32x2 *>(p) = h;
 }
 // raw (unconverted) 4-channel loads: lets a kernel keep prefetched 16-bit data in half the registers until it is used
 __device__ __forceinline__ fd_f32x4 fd_ldraw4(const float *p) { return *reinterpret_cast<const fd_f32x4 *>(p); }

@@ -31,10 +31,9 @@ __device__ __forceinline__ void fd_unpack8(fd_half, fd_u16x8 r, float (&f)[8])
 }
 __device__ __forceinline__ fd_u16x8 fd_pack8(fd_bf16, const float (&f)[8])
 {
-    fd_u16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = fd_f32_to_bf16(f[j]);
-    return r;
+    typedef unsigned fd_u32x4 __attribute__((ext_vector_type(4)));
+    const fd_u32x4 r = {fd_f32x2_to_bf16x2(f[0], f[1]), fd_f32x2_to_bf16x2(f[2], f[3]), fd_f32x2_to_bf16x2(f[4], f[5]), fd_f32x2_to_bf16x2(f[6], f[7])};
+    return __builtin_bit_cast(fd_u16x8, r);
 }
 __device__ __forceinline__ fd_u16x8 fd_pack8(fd_half, const float (&f)[8])
 {
