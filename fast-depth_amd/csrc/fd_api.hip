@@ -94,6 +94,7 @@ struct Layer {
     int fused_into = -1;         // depthwise layer: index of the pointwise layer whose kernel produces this layer's output
     int fused_dw = -1;           // pointwise layer: index of the depthwise layer fused into it
     int np = 0, flat = 0, gpw = 0;   // fused kernel: patch pixels, tile mapping, LDS-DMA instructions per wave per chunk
+    int fuse_head = -1;          // fd_dwpw_f32 unit: index of the 32 -> 1 pointwise head evaluated on its accumulators (that layer's fused_into = this one)
     bool dwpw = false;           // pointwise layer: fused_dw runs inside fd_dwpw_f32 (large maps: tile of pixels x all output channels)
     int dp_th = 0, dp_tw = 0 /* log2 of the tile width */, dp_tiles_x = 0, dp_wm = 0, dp_nt = 0, dp_nld = 0, dp_xcd = 0;
     bool dw_rows = false;        // register-window 3x3 kernel (fd_dw3_rows_f32) instead of the LDS-tiled one
@@ -358,29 +359,36 @@ int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *
 
 // depthwise + pointwise unit of a large map as one kernel (fd_kernels_dwpw_f32.h)
 template <int ACT>
-int launch_dwpw(const fd_plan *p, const Layer &L, float *out, hipStream_t s)
+int launch_dwpw(const fd_plan *p, const Layer &L, float *out, float *y, hipStream_t s)
 {
     const Layer &D = p->layers[L.fused_dw];
     const float *din = reinterpret_cast<const float *>(p->ws + p->layers[D.d.src].out_off);
     const float *dskip = D.d.skip >= 0 ? reinterpret_cast<const float *>(p->ws + p->layers[D.d.skip].out_off) : nullptr;
     const float *wdw = reinterpret_cast<const float *>(p->ws + D.w_off), *bdw = reinterpret_cast<const float *>(p->ws + D.b_off);
     const float *wp = reinterpret_cast<const float *>(p->ws + L.w_off), *bias = reinterpret_cast<const float *>(p->ws + L.b_off);
-    const int key = D.d.ksize * 1000 + D.d.stride * 100 + D.mode * 10 + L.dp_nt;
-#define FD_DWPW_CASE(KSV, SV, MODEV, WMV, NTV, NLDV)                                                                                   \
-    case KSV * 1000 + SV * 100 + MODEV * 10 + NTV:                                                                                     \
-        (void)hipFuncSetAttribute((const void *)fd_dwpw_f32<KSV, SV, MODEV, ACT, WMV, NTV, NLDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        FD_LAUNCH((fd_dwpw_f32<KSV, SV, MODEV, ACT, WMV, NTV, NLDV>), L.grid, dim3(512), L.lds, s, din, dskip, wdw, bdw, wp, bias, out, p->B, D.in_h, D.in_w, \
-                  D.out_h, D.out_w, D.d.cin, L.w_pitch, L.d.cout, L.dp_th, L.dp_tw, L.dp_tiles_x, L.dp_tiles_x * ceil_div(D.out_h, L.dp_th), L.dp_xcd);      \
+    fd_dwpw_head hd{};
+    if (L.fuse_head >= 0) {
+        const Layer &H = p->layers[L.fuse_head];
+        hd.w = reinterpret_cast<const float *>(p->ws + H.w_off); hd.b = reinterpret_cast<const float *>(p->ws + H.b_off);
+        hd.y = y; hd.act = H.d.act == FD_ACT_RELU6 ? 2 : (H.d.act == FD_ACT_RELU ? 1 : 0); hd.up = H.d.upsample;
+    }
+    const int key = D.d.ksize * 1000 + D.d.stride * 100 + D.mode * 10 + L.dp_nt + (L.fuse_head >= 0 ? 10000 : 0);
+#define FD_DWPW_CASE(KSV, SV, MODEV, WMV, NTV, NLDV, HEADV)                                                                            \
+    case KSV * 1000 + SV * 100 + MODEV * 10 + NTV + HEADV * 10000:                                                                     \
+        (void)hipFuncSetAttribute((const void *)fd_dwpw_f32<KSV, SV, MODEV, ACT, WMV, NTV, NLDV, HEADV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        FD_LAUNCH((fd_dwpw_f32<KSV, SV, MODEV, ACT, WMV, NTV, NLDV, HEADV>), L.grid, dim3(512), L.lds, s, din, dskip, wdw, bdw, wp, bias, out, p->B, D.in_h, D.in_w, \
+                  D.out_h, D.out_w, D.d.cin, L.w_pitch, L.d.cout, L.dp_th, L.dp_tw, L.dp_tiles_x, L.dp_tiles_x * ceil_div(D.out_h, L.dp_th), L.dp_xcd, hd);  \
         break;
     switch (key) {
-        FD_DWPW_CASE(3, 1, 0, 4, 1, 6)
-        FD_DWPW_CASE(3, 1, 0, 4, 2, 6)
-        FD_DWPW_CASE(3, 1, 0, 4, 4, 6)
-        FD_DWPW_CASE(5, 1, 2, 4, 1, 8)
-        FD_DWPW_CASE(5, 1, 2, 4, 2, 8)
-        FD_DWPW_CASE(5, 1, 2, 4, 4, 8)
-        FD_DWPW_CASE(3, 2, 0, 2, 2, 10)
-        FD_DWPW_CASE(3, 2, 0, 2, 4, 10)
+        FD_DWPW_CASE(3, 1, 0, 4, 1, 6, 0)
+        FD_DWPW_CASE(3, 1, 0, 4, 2, 6, 0)
+        FD_DWPW_CASE(3, 1, 0, 4, 4, 6, 0)
+        FD_DWPW_CASE(5, 1, 2, 4, 1, 8, 0)
+        FD_DWPW_CASE(5, 1, 2, 4, 1, 8, 1)
+        FD_DWPW_CASE(5, 1, 2, 4, 2, 8, 0)
+        FD_DWPW_CASE(5, 1, 2, 4, 4, 8, 0)
+        FD_DWPW_CASE(3, 2, 0, 2, 2, 10, 0)
+        FD_DWPW_CASE(3, 2, 0, 2, 4, 10, 0)
     default: return fail(FD_ERR_INVALID, "no fd_dwpw_f32 instance %d", key);
     }
 #undef FD_DWPW_CASE
@@ -421,7 +429,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
             return check_launch("fd_head_pw1");
         }
         if (L.dwpw) {
-            if constexpr (std::is_same<T, float>::value) return launch_dwpw<ACT>(p, L, out, s);
+            if constexpr (std::is_same<T, float>::value) return launch_dwpw<ACT>(p, L, out, y, s);
             else return fail(FD_ERR_INVALID, "fused units are fp32 only");
         }
 #ifdef FD_EXPERIMENTS
@@ -697,6 +705,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             Pw.dp_xcd = batch >= 8 ? 1 : 0;                    // images dealt to XCDs (b mod 8); small batches: tiles dealt round-robin
             Pw.grid = dim3((unsigned)(Pw.dp_xcd ? 256 : std::min<long>(256, tiles)));
             Pw.lds = lds;
+            // the network head (32 -> 1 pointwise on the up2 of this unit's output) as the only reader: evaluated on the accumulators
+            if (i + 2 < n_layers && !(flags & FD_PLAN_KEEP_ACTIVATIONS) && KS == 5 && D.mode == 2 && N == 32 && nt == 1 && wm == 4) {
+                Layer &H = p->layers[i + 2];
+                if (H.head && H.d.src == i + 1 && H.d.skip < 0 && readers[i + 1] == 1 && H.d.cin == 32) { Pw.fuse_head = i + 2; H.fused_into = i + 1; }
+            }
         }
     }
 
@@ -775,11 +788,14 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         char buf[256];
         if (L.skipped)
             snprintf(buf, sizeof buf, "(fused into layer %d)", i + 1);
+        else if (L.fused_into >= 0 && L.head)
+            snprintf(buf, sizeof buf, "(pointwise head evaluated on the accumulators of layer %d's dwpw kernel)", L.fused_into);
         else if (L.fused_into >= 0)
             snprintf(buf, sizeof buf, "(dw k%d s%d%s evaluated in the epilogue of layer %d's pw_gemm16)", d.ksize, d.stride, d.upsample ? " on up2" : "", L.fused_into);
         else if (L.dwpw)
-            snprintf(buf, sizeof buf, "dwpw<dw k%d s%d mode%d + pw> persistent, 4 producer + 4 consumer waves; tile %dx%d px x all %d channels, C=%d in %d chunks, weights in LDS, grid=%u lds=%zu", p->layers[L.fused_dw].d.ksize,
-                     p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, L.dp_th, 1 << L.dp_tw, d.cout, d.cin, d.cin / 32, L.grid.x, L.lds);
+            snprintf(buf, sizeof buf, "dwpw<dw k%d s%d mode%d + pw> persistent, 4 producer + 4 consumer waves; tile %dx%d px x all %d channels, C=%d in %d chunks, weights in LDS, grid=%u lds=%zu%s", p->layers[L.fused_dw].d.ksize,
+                     p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, L.dp_th, 1 << L.dp_tw, d.cout, d.cin, d.cin / 32, L.grid.x, L.lds,
+                     L.fuse_head >= 0 ? " + the 32->1 head on the accumulators" : "");
         else if (L.fused_dw >= 0)
             snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
                      L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
@@ -807,7 +823,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         L.info = buf;
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
         if (L.skipped || L.fused_into >= 0) buf[0] = 0;
-        else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld);
+        else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld, L.fuse_head >= 0 ? 1 : 0);
         else if (L.fused_dw >= 0) snprintf(buf, sizeof buf, "fd_sep_unit_f32<%d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.act, d.act, L.gpw <= 5 ? 5 : (L.gpw == 6 ? 6 : 7));
         else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
@@ -1087,6 +1103,7 @@ int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_
     double b = (L.skipped || L.fused_into >= 0) ? 0.0 : L.alg_bytes, f = (L.skipped || L.fused_into >= 0) ? 0.0 : L.alg_flops;
     if (L.fused_dw >= 0) { b += plan->layers[L.fused_dw].alg_bytes; f += plan->layers[L.fused_dw].alg_flops; }
     if (L.fuse_next_dw >= 0) { b += plan->layers[L.fuse_next_dw].alg_bytes; f += plan->layers[L.fuse_next_dw].alg_flops; }
+    if (L.fuse_head >= 0) { b += plan->layers[L.fuse_head].alg_bytes; f += plan->layers[L.fuse_head].alg_flops; }
     if (algorithmic_bytes) *algorithmic_bytes = b;
     if (algorithmic_flops) *algorithmic_flops = f;
     return FD_OK;

@@ -30,12 +30,18 @@ __device__ unsigned long long fd_dwpw_probe[8][6];
 #define FD_DWPW_T(k) do { } while (0)
 #endif
 
-template <int KS, int S, int MODE, int ACT, int WM, int NT, int NLD, int ABL = 0>   // ABL: ablations of tools/microbench/dwpw.hip (0 in the product)
+// HEAD = 1 (N == 32): the unit's only reader is the network's 32 -> 1 pointwise head (decode_conv6, models.py:698,731), which is evaluated
+// on the accumulators -- a 32-lane sum per pixel -- and written 2x2 (a 1x1 conv + BN + ReLU commutes with the nearest upsampling): the
+// unit's own 51 MB output is neither written nor read back.
+struct fd_dwpw_head { const float *w, *b; float *y; int act, up; };
+template <int KS, int S, int MODE, int ACT, int WM, int NT, int NLD, int HEAD = 0, int ABL = 0>   // ABL: ablations of tools/microbench/dwpw.hip (0 in the product)
 __global__ void __launch_bounds__(512)
 fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const float *__restrict__ wdw, const float *__restrict__ bdw,
             const float *__restrict__ Wt, const float *__restrict__ bias, float *__restrict__ out,
-            int B, int Hin, int Win, int Ho, int Wo, int C, int K32, int N, int TH, int tw_shift, int tiles_x, int tiles_per_img, int xcd_mode)
+            int B, int Hin, int Win, int Ho, int Wo, int C, int K32, int N, int TH, int tw_shift, int tiles_x, int tiles_per_img, int xcd_mode,
+            const fd_dwpw_head hd)
 {
+    static_assert(!HEAD || (NT == 1 && WM == 4), "the head reads all 32 columns of a pixel from one wave");
     constexpr int P = KS / 2, NIN = 3 * S + KS, PSTR = 36, WN = 4 / WM, BM = 32 * WM, KK = KS * KS;
     static_assert(WM * WN == 4, "four consumer waves");
     FD_DYN_SMEM(smem_raw);
@@ -203,9 +209,48 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
     for (int g = 0; g < 4; ++g) h_off[g] = 0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) hold[j] = acc[j];
+    float head_w = 0.0f, head_b = 0.0f, head_v = 0.0f;
+    unsigned head_off = 0;
+    bool head_ok = false;
+    if (HEAD) { head_w = hd.w[l31]; head_b = hd.b[0]; }
     auto store_part = [&](auto PART) __attribute__((always_inline)) {
         constexpr int g = decltype(PART)::value;
         if (!pending) return;
+        if (HEAD) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v = fd_act<ACT>(hold[0][g * 4 + rr]) * head_w;
+#ifdef FD_EMU
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+#else
+                // 32-lane sum on the VALU's data-parallel-primitive path (no LDS crossbar traffic next to the producers' tap reads): quad
+                // swaps, half-row and row mirrors give every lane its 16-lane row sum; row 1 / 3 then add lane 15 of row 0 / 2
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+#endif
+                if (l31 == 16 + g * 4 + rr) head_v = v;      // lane 16 + r of each 32-lane half (rows 1 / 3 hold the totals) keeps the pixel of D register r
+            }
+            if (g == 3) {
+                // lane (16 + r, half) holds row (r&3) + 8*(r>>2) + 4*half; lane i < 32 fetches row i, so that 16 lanes cover one tile row segment
+                // (128 contiguous bytes per output row instead of 8-byte fragments)
+                const int src = 16 + ((lane & 3) | (((lane >> 3) & 3) << 2)) + (((lane >> 2) & 1) << 5);
+                head_v = __shfl(head_v, src);
+            }
+            if (g == 3 && head_ok) {
+                float v = head_v + head_b;
+                if (hd.act >= 1) v = fmaxf(v, 0.0f);
+                if (hd.act == 2) v = fminf(v, 6.0f);
+                if (hd.up) {
+                    const fd_f32x2 vv = {v, v};
+                    *reinterpret_cast<fd_f32x2 *>(hd.y + head_off) = vv;
+                    *reinterpret_cast<fd_f32x2 *>(hd.y + head_off + 2 * Wo) = vv;
+                } else hd.y[head_off] = v;
+            }
+            return;
+        }
         char *base = reinterpret_cast<char *>(out);
         if (h_full) {                                         // whole tile inside the map (workgroup-uniform): no predicates
 #pragma unroll
@@ -254,6 +299,12 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
     auto retire = [&](int k) __attribute__((always_inline)) {   // the tile's last chunk has been multiplied
         tile_origin(k, h_n, h_oy0, h_ox0);
         h_full = h_oy0 + TH <= Ho && h_ox0 + TW <= Wo && (TH << tw_shift) == BM;
+        if (HEAD) {                                           // lane i (< 32) writes the pixel of tile row i of this wave
+            const int row = wm * 32 + l31;
+            const int oy = row >> tw_shift, ox = row & (TW - 1), gy = h_oy0 + oy, gx = h_ox0 + ox;
+            head_ok = lane < 32 && oy < TH && gy < Ho && gx < Wo;
+            head_off = hd.up ? (unsigned)((h_n * 2 * Ho + 2 * gy) * 2 * Wo + 2 * gx) : (unsigned)((h_n * Ho + gy) * Wo + gx);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int row = wm * 32 + 8 * g + 4 * h;

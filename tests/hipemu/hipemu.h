@@ -190,6 +190,17 @@ inline float __shfl_xor(float v, int mask)
     return r;
 }
 
+inline float __shfl(float v, int src_lane)
+{
+    hipemu::WaveXchg &x = hipemu::wave_xchg();
+    const int l = hipemu::lane_id();
+    x.f[l][0] = v;
+    hipemu::yield(hipemu::COLLECTIVE);
+    const float r = x.f[src_lane & 63][0];
+    hipemu::yield(hipemu::COLLECTIVE);
+    return r;
+}
+
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 

@@ -100,6 +100,9 @@ def test_emulated_dwpw_units_match_oracle(b, hw):
     # channels on maps of >= 28 x 28 pixels (conv1, conv2, decode_conv5)
     cp = harness.CPlan("emu", m, x, keep=False)
     sel = [s for s in cp.info() if s.startswith("dwpw<")]
+    if hw != (32, 32):
+        # decode_conv5's unit also evaluates the network head (32 -> 1 pointwise, written 2x2) on its accumulators
+        assert sum("head on the accumulators" in s for s in sel) == 1 and any(s.startswith("(pointwise head evaluated") for s in cp.info()), cp.info()
     y2 = cp.forward(x).numpy()
     cp.close()
     assert len(sel) == {(64, 64): 2, (96, 160): 3, (32, 32): 0}[hw], sel     # (batch 9: images dealt to XCDs, a ragged last group)

@@ -307,6 +307,7 @@ def test_batch32_plan_selects_dwpw_units():
     y = plan.forward(xb)
     plan.close()
     assert sum(s.startswith("dwpw<") for s in info) == 3, info          # conv1, conv2, decode_conv5 (where the fused unit was measured to pay)
+    assert sum("head on the accumulators" in s for s in info) == 1, info   # ... and decode_conv6 (the 32 -> 1 head) rides on decode_conv5's unit
     plain = harness.CPlan("hip", m, xb, keep=False, flags=harness.capi.FD_PLAN_NO_UNIT_FUSION)
     assert not any(s.startswith("dwpw<") for s in plain.info())
     y0 = plain.forward(xb)
