@@ -38,11 +38,11 @@ template <int KS, int S, int MODE, int ACT, int WM, int NT, int NLD, int HEAD = 
 __global__ void __launch_bounds__(512)
 fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const float *__restrict__ wdw, const float *__restrict__ bdw,
             const float *__restrict__ Wt, const float *__restrict__ bias, float *__restrict__ out,
-            int B, int Hin, int Win, int Ho, int Wo, int C, int K32, int N, int TH, int tw_shift, int tiles_x, int tiles_per_img, int xcd_mode,
+            int B, int Hin, int Win, int Ho, int Wo, int C, int K32, int N, int TH, int tw_shift, int tiles_x, int tiles_per_img, int xcd_mode, int PSTR,
             const fd_dwpw_head hd)
 {
     static_assert(!HEAD || (NT == 1 && WM == 4), "the head reads all 32 columns of a pixel from one wave");
-    constexpr int P = KS / 2, NIN = 3 * S + KS, PSTR = 36, WN = 4 / WM, BM = 32 * WM, KK = KS * KS;
+    constexpr int P = KS / 2, NIN = 3 * S + KS, WN = 4 / WM, BM = 32 * WM, KK = KS * KS;
     static_assert(WM * WN == 4, "four consumer waves");
     FD_DYN_SMEM(smem_raw);
     const int nchunks = C >> 5, cshift = 31 - __builtin_clz(nchunks);      // C / 32 is a power of two (checked by the plan)

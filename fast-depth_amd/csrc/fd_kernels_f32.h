@@ -179,13 +179,13 @@ template <typename T, int K, int S, int MODE, int ACT>
 __global__ void __launch_bounds__(256)
 fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ wp,
           const float *__restrict__ bias, T *__restrict__ out, int Hin, int Win, int Ho, int Wo, int C,
-          int cbq, int TH, int TW, int tiles_x, int csplit)
+          int cbq, int TH, int TW, int tiles_x, int csplit, int PSTR)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;                       // input columns feeding 4 adjacent outputs
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4;       // PSTR: bank-conflict-free row pitch of the patch image (host: pick_patch_pitch)
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
     float *s_in = smem;                                   // [TH_in*TW_in][PSTR]
     float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]

@@ -18,9 +18,9 @@ float run(int B, int Hin, int Win, int C, int N, int TH, int TW, int iters = 30)
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(256);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, g_in, g_skip, g_w, g_w + 8192, g_w + 16384, g_w + 100000, g_out, B, Hin, Win, Ho, Wo, C, C, N, TH, tws, tiles_x, tiles_x * tiles_y, 1, fd_dwpw_head{});
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, g_in, g_skip, g_w, g_w + 8192, g_w + 16384, g_w + 100000, g_out, B, Hin, Win, Ho, Wo, C, C, N, TH, tws, tiles_x, tiles_x * tiles_y, 1, 36, fd_dwpw_head{});
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, g_in, g_skip, g_w, g_w + 8192, g_w + 16384, g_w + 100000, g_out, B, Hin, Win, Ho, Wo, C, C, N, TH, tws, tiles_x, tiles_x * tiles_y, 1, fd_dwpw_head{});
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(512), lds, 0, g_in, g_skip, g_w, g_w + 8192, g_w + 16384, g_w + 100000, g_out, B, Hin, Win, Ho, Wo, C, C, N, TH, tws, tiles_x, tiles_x * tiles_y, 1, 36, fd_dwpw_head{});
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / iters * 1e3f;
 }
