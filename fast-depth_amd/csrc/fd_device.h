@@ -76,6 +76,19 @@ __device__ __forceinline__ fd_blk3 fd_xcd_image_map2()     // grid (x, images)
 // compile-time integer as a value (selects statically indexed register sets inside generic lambdas)
 template <int N> struct fd_int { static constexpr int value = N; };
 
+// Sum over the four lanes {l, l^4, l^8, l^12} of a 16-lane row, result in all four: two row rotates on the VALU's data-parallel-primitive
+// path instead of two trips through the LDS crossbar (ds_bpermute); the emulator's butterfly adds the same pairs in the same order.
+__device__ __forceinline__ float fd_row_stride4_sum(float v)
+{
+#ifdef FD_EMU
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4);
+#else
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
+#endif
+    return v;
+}
+
 typedef float fd_f32x4 __attribute__((ext_vector_type(4)));
 typedef float fd_f32x2 __attribute__((ext_vector_type(2)));
 typedef float fd_f32x16 __attribute__((ext_vector_type(16)));

@@ -320,7 +320,10 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
     // lanes that share (lane & 3) hold the same 8 columns for different rows
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        for (int m = 4; m < 64; m <<= 1) { sg_[j] += __shfl_xor(sg_[j], m); sx_[j] += __shfl_xor(sx_[j], m); }
+    {
+        sg_[j] = fd_row_stride4_sum(sg_[j]); sx_[j] = fd_row_stride4_sum(sx_[j]);
+        for (int m = 16; m < 64; m <<= 1) { sg_[j] += __shfl_xor(sg_[j], m); sx_[j] += __shfl_xor(sx_[j], m); }
+    }
     if (lane < 4) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { red[(wm * 2 + 0) * 64 + wk * 32 + c8 + j] = sg_[j]; red[(wm * 2 + 1) * 64 + wk * 32 + c8 + j] = sx_[j]; }
@@ -354,7 +357,10 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
     long mend = mbeg + rows_per_split; if (mend > M) mend = M;
     const int Tn = (int)((mend - mbeg + BR - 1) / BR);
     // loader mapping: chunk cc = tid & 7 (8 columns), rows (tid >> 3) and (tid >> 3) + 32 of the 64-pixel step
-    const int cc = tid & 7, lr = tid >> 3;
+    // (the pixel order within a wave's 8 pixels is 0,2,4,6,1,3,5,7: lanes l and l+32 then hold the two 16-bit halves of one LDS dword --
+    // ds_write_b16 is served in the two 32-lane halves, and two lanes of one half on the same dword were a 2-way conflict: 40 % of this
+    // kernel's LDS cycles, PMC)
+    const int cc = tid & 7, lr = (tid >> 3 & ~7) + 2 * (tid >> 3 & 3) + (tid >> 5 & 1);
     const int ncol = n0 + cc * 8, kcol = k0 + cc * 8;
     const bool n_ok = ncol < N, k_ok = kcol < K;                  // N, K % 8 == 0
     float sc[8], sh[8];
