@@ -299,6 +299,25 @@ def test_dwpw_units_layerwise(b, h, w):
     cp.close()
 
 
+def test_dwpw_units_ragged_batch_dealt_to_xcds():
+    """Batch 9 (>= 8: images are dealt to the XCDs, image n on XCD n % 8, so XCD 0 owns two images and the others one) through the default
+    plan at 160 x 192 (80 x 96 / 40 x 48 maps: ragged 16- and 8-pixel tiles): output against the C oracle and against the unfused plan."""
+    models = inputs.product_models()
+    torch.manual_seed(97)
+    m = harness.randomize_bn(models.MobileNetSkipAdd((160, 192), pretrained=False), 98).eval()
+    x = torch.rand(9, 3, 160, 192, generator=torch.Generator().manual_seed(99))
+    y_ref = oracle.forward(m.state_dict(), x.numpy())
+    cp = harness.CPlan("hip", m, x.cuda(), keep=False)
+    info = cp.info()
+    y = cp.forward(x.cuda()).cpu().numpy()
+    cp.close()
+    assert sum(s.startswith("dwpw<") for s in info) == 3 and sum("head on the accumulators" in s for s in info) == 1, info
+    plain = harness.CPlan("hip", m, x.cuda(), keep=False, flags=harness.capi.FD_PLAN_NO_UNIT_FUSION)
+    y0 = plain.forward(x.cuda()).cpu().numpy()
+    plain.close()
+    assert harness.rel_err(y, y_ref) < TOL and harness.rel_err(y, y0) < 1e-5
+
+
 def test_batch32_plan_selects_dwpw_units():
     m, x, _, _ = inputs.golden_case("base_s0")
     xb = inputs.batch_variants(inputs.load_sample()[0], 32, seed=0).cuda()
