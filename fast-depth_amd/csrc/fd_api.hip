@@ -709,6 +709,8 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             if (Pw.d.op != FD_OP_PW || Pw.head || Pw.d.src != i || Pw.d.upsample || Pw.fuse_next_dw >= 0 || Pw.to_output) continue;
             const int C = D.d.cin, N = Pw.d.cout, KS = D.d.ksize, S = D.d.stride;
             if (D.d.act != Pw.d.act || D.d.act == FD_ACT_NONE || C % 32 || C > 256 || N % 32) continue;
+            // the kernel addresses its tensors with 32-bit element / byte offsets
+            if ((double)batch * D.in_h * D.in_w * C >= 2147483648.0 || (double)batch * D.out_h * D.out_w * N * 4.0 >= 4294967296.0) continue;
             int wm = 0, nld = 0;
             if (KS == 3 && S == 1 && D.mode == 0) { wm = 4; nld = 6; }
             else if (KS == 5 && S == 1 && D.mode == 2) { wm = 4; nld = 8; }

@@ -80,16 +80,16 @@ fd_pack_train_w_h16(const fd_pack_table<T> table)
 // Epilogue: z rounded to T, transposed through LDS for 16-byte NHWC stores, per-column statistics of the ROUNDED values
 // -> part[mt*2*N + {0,N} + col].
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT1>
-__global__ void __launch_bounds__(256)
+template <typename T, int ACT1, int TN = 1>   // TN = column tiles of 32 per wave: the workgroup's tile is 64 x (64*TN).  TN = 2 (N >= 128): every
+__global__ void __launch_bounds__(256)        // normalised A fragment feeds two MFMAs (the fp32 table math per fragment is this kernel's VALU load)
 fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, const T *__restrict__ Wt, T *__restrict__ out,
                      float *__restrict__ part, int M, int N, int K, int K64, int m_tiles, int n_tiles)
 {
-    constexpr int BM = 64, BN = 64, BK = 64;
+    constexpr int BM = 64, BN = 64 * TN, BK = 64;
     constexpr int ROWS = BM + BN, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
     FD_DYN_SMEM(smem);
     float *tab = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][K64]
-    float *red = tab + 2 * K64;                                   // [2][2][64]
+    float *red = tab + 2 * K64;                                   // [2][2][BN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -121,17 +121,22 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
             fd_glds16(reinterpret_cast<const float *>(src[i] + k), reinterpret_cast<float *>(dst + i * 4 * 8 * 128));
         }
     };
-    fd_f32x16 acc;
+    fd_f32x16 acc[TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     const int h = lane >> 5;
-    int a_off[4], b_off[4];
+    int a_off[4], b_off[TN][4];
     {
-        const int ra = wm * 32 + (lane & 31), rb = BM + wn * 32 + (lane & 31);
+        const int ra = wm * 32 + (lane & 31);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
-            b_off[s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
+        for (int s = 0; s < 4; ++s) a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = BM + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b_off[j][s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
         }
     }
     const int Tn = K64 / BK;
@@ -154,36 +159,44 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
                 f[j] = fd_act<ACT1>(fmaf(f[j], s0[j], t0[j]));
                 f[4 + j] = fd_act<ACT1>(fmaf(f[4 + j], s1[j], t1[j]));
             }
-            acc = fd_mfma_32x32x16(T{}, fd_pack8(T{}, f), fd_ld8(cur + b_off[s]), acc);
+            const fd_u16x8 af = fd_pack8(T{}, f);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = fd_mfma_32x32x16(T{}, af, fd_ld8(cur + b_off[j][s]), acc[j]);
         }
     }
-    // epilogue
+    // epilogue, one 32-column tile of the wave at a time
     __syncthreads();
     T *tile = reinterpret_cast<T *>(smem) + wave * 32 * 40;
     const int col = lane & 31;
     const long rbase = m0 + wm * 32 + 4 * (lane >> 5);
-    float s = 0.0f, q = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2);
-        fd_st1(tile + (rl + 4 * (lane >> 5)) * 40 + col, acc[r]);
-        const float zr = fd_ld1(tile + (rl + 4 * (lane >> 5)) * 40 + col);          // the rounded value (own write)
-        if (rbase + rl < M && n0 + wn * 32 + col < N) { s += zr; q = fmaf(zr, zr, q); }
+    for (int j = 0; j < TN; ++j) {
+        const int cw = (wn * TN + j) * 32;                        // first column of this tile within the workgroup's BN columns
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = (r & 3) + 8 * (r >> 2);
+            fd_st1(tile + (rl + 4 * (lane >> 5)) * 40 + col, acc[j][r]);
+            const float zr = fd_ld1(tile + (rl + 4 * (lane >> 5)) * 40 + col);          // the rounded value (own write)
+            if (rbase + rl < M && n0 + cw + col < N) { s += zr; q = fmaf(zr, zr, q); }
+        }
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (lane < 32) { red[(wm * 2 + 0) * BN + cw + lane] = s; red[(wm * 2 + 1) * BN + cw + lane] = q; }
+        fd_wave_lds_fence();                                      // the tile is private to this wave
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = lane + 64 * i;
+            const int row = id >> 2, c8 = (id & 3) * 8;
+            const long grow = m0 + wm * 32 + row;
+            const int gcol = n0 + cw + c8;
+            if (grow < M && gcol < N) fd_st8(out + grow * N + gcol, fd_ld8(tile + row * 40 + c8));   // N % 8 == 0 (checked by the plan)
+        }
+        fd_wave_lds_fence();
     }
-    s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-    if (lane < 32) { red[(wm * 2 + 0) * 64 + wn * 32 + lane] = s; red[(wm * 2 + 1) * 64 + wn * 32 + lane] = q; }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = lane + 64 * i;
-        const int row = id >> 2, c8 = (id & 3) * 8;
-        const long grow = m0 + wm * 32 + row;
-        const int gcol = n0 + wn * 32 + c8;
-        if (grow < M && gcol < N) fd_st8(out + grow * N + gcol, fd_ld8(tile + row * 40 + c8));   // N % 8 == 0 (checked by the plan)
-    }
-    if (tid < 64 && n0 + tid < N) {
-        part[(long)mt * 2 * N + n0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
-        part[(long)mt * 2 * N + N + n0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+    if (tid < BN && n0 + tid < N) {
+        part[(long)mt * 2 * N + n0 + tid] = red[0 * BN + tid] + red[2 * BN + tid];
+        part[(long)mt * 2 * N + N + n0 + tid] = red[1 * BN + tid] + red[3 * BN + tid];
     }
 }
 
@@ -213,15 +226,15 @@ fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__r
 // Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed
 // through LDS so that z_in / skipgrad are read and G_in is written 8 channels (16 bytes) per lane.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT_IN, int ADD_SG>
+template <typename T, int ACT_IN, int ADD_SG, int TN = 1>   // TN: 32-column tiles per wave (workgroup tile 64 x 64*TN of G_in): every dz fragment feeds TN MFMAs
 __global__ void __launch_bounds__(256)
 fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles)
 {
-    constexpr int BM = 64, BKO = 64, BR = 64;
+    constexpr int BM = 64, BKO = 64 * TN, BR = 64;
     constexpr int ROWS = BM + BKO, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
     FD_DYN_SMEM(smem);
-    float *red = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][2][64]
+    float *red = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][2][BKO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -249,17 +262,22 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
             fd_glds16(reinterpret_cast<const float *>(src[i] + n), reinterpret_cast<float *>(dst + i * 4 * 8 * 128));
         }
     };
-    fd_f32x16 acc;
+    fd_f32x16 acc[TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     const int h = lane >> 5;
-    int a_off[4], b_off[4];
+    int a_off[4], b_off[TN][4];
     {
-        const int ra = wm * 32 + (lane & 31), rb = BM + wk * 32 + (lane & 31);
+        const int ra = wm * 32 + (lane & 31);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
-            b_off[s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
+        for (int s = 0; s < 4; ++s) a_off[s] = ra * 128 + (((2 * s + h) ^ ((ra >> 1) & 7)) << 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = BM + (wk * TN + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b_off[j][s] = rb * 128 + (((2 * s + h) ^ ((rb >> 1) & 7)) << 4);
         }
     }
     const int Tn = N64 / BR;
@@ -271,67 +289,75 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
         if (t + 2 < Tn) issue(t + 2);
         const unsigned char *cur = smem + (t % 3) * STAGE;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = fd_mfma_32x32x16(T{}, fd_ld8(cur + a_off[s]), fd_ld8(cur + b_off[s]), acc);
+        for (int s = 0; s < 4; ++s) {
+            const fd_u16x8 af = fd_ld8(cur + a_off[s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = fd_mfma_32x32x16(T{}, af, fd_ld8(cur + b_off[j][s]), acc[j]);
+        }
     }
-    // epilogue: fp32 tile [32][36] per wave
+    // epilogue, one 32-column tile of the wave at a time: fp32 tile [32][36] per wave
     __syncthreads();
     float *tile = reinterpret_cast<float *>(smem) + wave * 32 * 36;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[r];
-    __syncthreads();
     const int c8 = (lane & 3) * 8;
-    const int gcol = k0 + wk * 32 + c8;
-    float sg_[8], sx_[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sg_[j] = 0.0f; sx_[j] = 0.0f; }
-    if (gcol < K) {                                               // K % 8 == 0: a chunk is entirely inside or outside
-        float sc[8], sh[8], mu[8], is[8];
+    for (int jt = 0; jt < TN; ++jt) {
+        const int cw = (wk * TN + jt) * 32;                       // first column of this tile within the workgroup's BKO columns
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sc[j] = st_in[FD_ST_SCALE * K + gcol + j]; sh[j] = st_in[FD_ST_SHIFT * K + gcol + j];
-            mu[j] = st_in[FD_ST_MEAN * K + gcol + j]; is[j] = st_in[FD_ST_INVSTD * K + gcol + j];
-        }
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[jt][r];
+        fd_wave_lds_fence();                                      // the tile is private to this wave
+        const int gcol = k0 + cw + c8;
+        float sg_[8], sx_[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (lane >> 2) + 16 * i;
-            const long grow = m0 + wm * 32 + row;
-            if (grow < M) {
-                float z[8], v[8];
-                fd_unpack8(T{}, fd_ld8(Zin + grow * K + gcol), z);
-                const fd_f32x4 v0 = fd_ld4(tile + row * 36 + c8), v1 = fd_ld4(tile + row * 36 + c8 + 4);
+        for (int j = 0; j < 8; ++j) { sg_[j] = 0.0f; sx_[j] = 0.0f; }
+        if (gcol < K) {                                           // K % 8 == 0: a chunk is entirely inside or outside
+            float sc[8], sh[8], mu[8], is[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
-                if (ADD_SG) {
-                    float g[8];
-                    fd_unpack8(T{}, fd_ld8(SG + grow * K + gcol), g);
+            for (int j = 0; j < 8; ++j) {
+                sc[j] = st_in[FD_ST_SCALE * K + gcol + j]; sh[j] = st_in[FD_ST_SHIFT * K + gcol + j];
+                mu[j] = st_in[FD_ST_MEAN * K + gcol + j]; is[j] = st_in[FD_ST_INVSTD * K + gcol + j];
+            }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += g[j];
+            for (int i = 0; i < 2; ++i) {
+                const int row = (lane >> 2) + 16 * i;
+                const long grow = m0 + wm * 32 + row;
+                if (grow < M) {
+                    float z[8], v[8];
+                    fd_unpack8(T{}, fd_ld8(Zin + grow * K + gcol), z);
+                    const fd_f32x4 v0 = fd_ld4(tile + row * 36 + c8), v1 = fd_ld4(tile + row * 36 + c8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
+                    if (ADD_SG) {
+                        float g[8];
+                        fd_unpack8(T{}, fd_ld8(SG + grow * K + gcol), g);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += g[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= fd_actmask<ACT_IN>(fmaf(z[j], sc[j], sh[j]));
+                    const fd_u16x8 packed = fd_pack8(T{}, v);
+                    fd_st8(Gin + grow * K + gcol, packed);
+                    fd_unpack8(T{}, packed, v);                   // statistics of the stored (rounded) gradient
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { sg_[j] += v[j]; sx_[j] = fmaf(v[j], (z[j] - mu[j]) * is[j], sx_[j]); }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= fd_actmask<ACT_IN>(fmaf(z[j], sc[j], sh[j]));
-                const fd_u16x8 packed = fd_pack8(T{}, v);
-                fd_st8(Gin + grow * K + gcol, packed);
-                fd_unpack8(T{}, packed, v);                       // statistics of the stored (rounded) gradient
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { sg_[j] += v[j]; sx_[j] = fmaf(v[j], (z[j] - mu[j]) * is[j], sx_[j]); }
             }
         }
-    }
-    // lanes that share (lane & 3) hold the same 8 columns for different rows
+        // lanes that share (lane & 3) hold the same 8 columns for different rows
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-    {
-        sg_[j] = fd_row_stride4_sum(sg_[j]); sx_[j] = fd_row_stride4_sum(sx_[j]);
-        for (int m = 16; m < 64; m <<= 1) { sg_[j] += __shfl_xor(sg_[j], m); sx_[j] += __shfl_xor(sx_[j], m); }
-    }
-    if (lane < 4) {
+        for (int j = 0; j < 8; ++j) {
+            sg_[j] = fd_row_stride4_sum(sg_[j]); sx_[j] = fd_row_stride4_sum(sx_[j]);
+            for (int m = 16; m < 64; m <<= 1) { sg_[j] += __shfl_xor(sg_[j], m); sx_[j] += __shfl_xor(sx_[j], m); }
+        }
+        if (lane < 4) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[(wm * 2 + 0) * 64 + wk * 32 + c8 + j] = sg_[j]; red[(wm * 2 + 1) * 64 + wk * 32 + c8 + j] = sx_[j]; }
+            for (int j = 0; j < 8; ++j) { red[(wm * 2 + 0) * BKO + cw + c8 + j] = sg_[j]; red[(wm * 2 + 1) * BKO + cw + c8 + j] = sx_[j]; }
+        }
+        fd_wave_lds_fence();                                      // the next tile overwrites the wave's LDS tile
     }
     __syncthreads();
-    if (tid < 64 && k0 + tid < K) {
-        part[(long)mt * 2 * K + k0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
-        part[(long)mt * 2 * K + K + k0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+    if (tid < BKO && k0 + tid < K) {
+        part[(long)mt * 2 * K + k0 + tid] = red[0 * BKO + tid] + red[2 * BKO + tid];
+        part[(long)mt * 2 * K + K + k0 + tid] = red[1 * BKO + tid] + red[3 * BKO + tid];
     }
 }
 
@@ -341,32 +367,38 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
 // 144 bytes, the 16-byte chunk (8 consecutive m) of row r stored at chunk position c ^ ((r >> 3) & 7): the 2-byte transposing
 // writes of a wave then spread over the banks, and a fragment is one ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT_IN>
+template <typename T, int ACT_IN, int TN = 1>   // TN: 64-column k tiles per workgroup (output tile 64 n x 64*TN k): the staged dz tile feeds TN times the MFMAs
 __global__ void __launch_bounds__(256)
 fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
                 int M, int N, int K, int k_tiles, int rows_per_split)
 {
     constexpr int BT = 64, BR = 64, PITCH = 144;
     __shared__ __attribute__((aligned(16))) unsigned char s_dz[BT * PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned char s_a[BT * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[BT * TN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int nt = blockIdx.x / k_tiles, kt = blockIdx.x - nt * k_tiles;
-    const int n0 = nt * BT, k0 = kt * BT;
+    const int n0 = nt * BT, k0 = kt * BT * TN;
     const long mbeg = (long)blockIdx.y * rows_per_split;
     long mend = mbeg + rows_per_split; if (mend > M) mend = M;
     const int Tn = (int)((mend - mbeg + BR - 1) / BR);
-    // loader mapping: chunk cc = tid & 7 (8 columns), rows (tid >> 3) and (tid >> 3) + 32 of the 64-pixel step
+    // loader mapping: chunk cc = tid & 7 (8 columns), rows lr and lr + 32 of the 64-pixel step
     // (the pixel order within a wave's 8 pixels is 0,2,4,6,1,3,5,7: lanes l and l+32 then hold the two 16-bit halves of one LDS dword --
     // ds_write_b16 is served in the two 32-lane halves, and two lanes of one half on the same dword were a 2-way conflict: 40 % of this
     // kernel's LDS cycles, PMC)
     const int cc = tid & 7, lr = (tid >> 3 & ~7) + 2 * (tid >> 3 & 3) + (tid >> 5 & 1);
-    const int ncol = n0 + cc * 8, kcol = k0 + cc * 8;
-    const bool n_ok = ncol < N, k_ok = kcol < K;                  // N, K % 8 == 0
-    float sc[8], sh[8];
+    const int ncol = n0 + cc * 8;
+    const bool n_ok = ncol < N;                                   // N, K % 8 == 0
+    int kcol[TN];
+    bool k_ok[TN];
+    float sc[TN][8], sh[TN][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = k_ok ? st_in[FD_ST_SCALE * K + kcol + j] : 0.0f; sh[j] = k_ok ? st_in[FD_ST_SHIFT * K + kcol + j] : 0.0f; }
-    fd_u16x8 rdz[2], rzi[2];
+    for (int q = 0; q < TN; ++q) {
+        kcol[q] = k0 + q * BT + cc * 8; k_ok[q] = kcol[q] < K;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[q][j] = k_ok[q] ? st_in[FD_ST_SCALE * K + kcol[q] + j] : 0.0f; sh[q][j] = k_ok[q] ? st_in[FD_ST_SHIFT * K + kcol[q] + j] : 0.0f; }
+    }
+    fd_u16x8 rdz[2], rzi[2][TN];
     const fd_u16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto load = [&](int t) {
 #pragma unroll
@@ -374,9 +406,13 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
             const long m = mbeg + (long)t * BR + lr + 32 * i;
             const bool ok = m < mend;
             const long mq = ok ? m : mend - 1;                 // branch-free: clamped row / column, unconditional loads, select
-            const fd_u16x8 vdz = fd_ld8(DZ + mq * N + (n_ok ? ncol : 0)), vzi = fd_ld8(Zin + mq * K + (k_ok ? kcol : 0));
+            const fd_u16x8 vdz = fd_ld8(DZ + mq * N + (n_ok ? ncol : 0));
             rdz[i] = (ok && n_ok) ? vdz : zero8;
-            rzi[i] = (ok && k_ok) ? vzi : zero8;
+#pragma unroll
+            for (int q = 0; q < TN; ++q) {
+                const fd_u16x8 vzi = fd_ld8(Zin + mq * K + (k_ok[q] ? kcol[q] : 0));
+                rzi[i][q] = (ok && k_ok[q]) ? vzi : zero8;
+            }
         }
     };
     auto stage = [&](int t) {
@@ -384,24 +420,28 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
         for (int i = 0; i < 2; ++i) {
             const int ml = lr + 32 * i;                           // pixel within the step
             const long m = mbeg + (long)t * BR + ml;
-            float a[8];
-            fd_unpack8(T{}, rzi[i], a);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = (m < mend && k_ok) ? fd_act<ACT_IN>(fmaf(a[j], sc[j], sh[j])) : 0.0f;
-            const fd_u16x8 pa = fd_pack8(T{}, a);
             const int pos = (((ml >> 3) ^ cc) << 4) + (ml & 7) * 2;   // rows cc*8 .. cc*8+7 all have (r >> 3) & 7 == cc
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                *reinterpret_cast<unsigned short *>(s_dz + (cc * 8 + j) * PITCH + pos) = rdz[i][j];
-                *reinterpret_cast<unsigned short *>(s_a + (cc * 8 + j) * PITCH + pos) = pa[j];
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned short *>(s_dz + (cc * 8 + j) * PITCH + pos) = rdz[i][j];
+#pragma unroll
+            for (int q = 0; q < TN; ++q) {
+                float a[8];
+                fd_unpack8(T{}, rzi[i][q], a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (m < mend && k_ok[q]) ? fd_act<ACT_IN>(fmaf(a[j], sc[q][j], sh[q][j])) : 0.0f;
+                const fd_u16x8 pa = fd_pack8(T{}, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned short *>(s_a + (q * BT + cc * 8 + j) * PITCH + pos) = pa[j];
             }
         }
     };
-    fd_f32x16 acc;
+    fd_f32x16 acc[TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int q = 0; q < TN; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
     const int hh = lane >> 5;
-    const int ra = wn * 32 + (lane & 31), rb = wk * 32 + (lane & 31);
+    const int ra = wn * 32 + (lane & 31), rb = wk * 32 + (lane & 31);   // (rb: row within one 64-row k tile of s_a)
     if (Tn > 0) load(0);
     for (int t = 0; t < Tn; ++t) {
         __syncthreads();                                          // the previous step's fragment reads are done
@@ -411,18 +451,24 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const fd_u16x8 a = fd_ld8(s_dz + ra * PITCH + (((2 * s + hh) ^ ((ra >> 3) & 7)) << 4));
-            const fd_u16x8 b = fd_ld8(s_a + rb * PITCH + (((2 * s + hh) ^ ((rb >> 3) & 7)) << 4));
-            acc = fd_mfma_32x32x16(T{}, a, b, acc);
+#pragma unroll
+            for (int q = 0; q < TN; ++q) {
+                const fd_u16x8 b = fd_ld8(s_a + (q * BT + rb) * PITCH + (((2 * s + hh) ^ ((rb >> 3) & 7)) << 4));
+                acc[q] = fd_mfma_32x32x16(T{}, a, b, acc[q]);
+            }
         }
     }
     float *o = wpart + (long)blockIdx.y * N * K;
-    const int col = k0 + wk * 32 + (lane & 31);
     const int rbn = n0 + wn * 32 + 4 * (lane >> 5);
-    if (col < K) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rbn + (r & 3) + 8 * (r >> 2);
-            if (row < N) o[(long)row * K + col] = acc[r];
+    for (int q = 0; q < TN; ++q) {
+        const int col = k0 + q * BT + wk * 32 + (lane & 31);
+        if (col < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbn + (r & 3) + 8 * (r >> 2);
+                if (row < N) o[(long)row * K + col] = acc[q][r];
+            }
         }
     }
 }

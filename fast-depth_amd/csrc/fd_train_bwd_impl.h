@@ -167,25 +167,29 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         splits = ceil_div(M, rows);
         if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
         if ((rc = fork_side(c))) return rc;
-        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+        // (two k tiles per workgroup -- fd_pw_wgrad_h16<.., 2>, the staged dz tile feeding twice the MFMAs -- measured slower: 22.3 vs 20.9 us on the
+        // 512 x 512 units, 3 instead of 5 workgroups per CU and half as many of them)
+        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN, 1>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, L.wp_off), M, N, K, k_tiles, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
         if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
     }
     {
-        const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
-        const size_t lds = (size_t)3 * 128 * 128 + 256 * 4;
+        // 64 x 128 tiles of G_in when there are >= 128 input channels and that still leaves >= 200 workgroups: every dz fragment feeds two MFMAs
+        const int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
+        const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
+        const size_t lds = (size_t)3 * (64 + 64 * tn) * 128 + (size_t)4 * 64 * tn * 4;
         const bool add = P.skip_consumer >= 0;
         dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * k_tiles));
-        if (add) {
-            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, 1>), grid, dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
-                      twt<T>(c.p, P.sg_off), twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);
-        } else {
-            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, 0>), grid, dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
-                      (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);
-        }
+#define FD_DGRAD_H16(ADDV, TNV)                                                                                                                    \
+    do {                                                                                                                                           \
+        (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>), grid, dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off), \
+                  ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);          \
+    } while (0)
+        if (add) { if (tn == 2) FD_DGRAD_H16(1, 2); else FD_DGRAD_H16(1, 1); }
+        else { if (tn == 2) FD_DGRAD_H16(0, 2); else FD_DGRAD_H16(0, 1); }
+#undef FD_DGRAD_H16
         *nblk = m_tiles;
         return check_launch("fd_pw_dgrad_h16");
     }

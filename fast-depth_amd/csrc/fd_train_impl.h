@@ -32,7 +32,7 @@ struct TLayer {
     int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling
     int chunk = 0;                                            // stem
-    int m_tiles = 0, n_tiles = 0;                             // pw
+    int m_tiles = 0, n_tiles = 0, pw_tn = 1;                  // pw (pw_tn: 32-column tiles per wave of the 16-bit forward GEMM)
     size_t lds = 0;
     dim3 grid;
     int nblk = 0;                    // reduction partials this unit's forward kernel writes
@@ -197,13 +197,14 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
                     rc = check_launch("fd_pw_gemm_train_f32");
                 } else {
                     T *wt = twt<T>(plan, L.wt_off);      // 16-bit operand copies of the master weights: made for all units at the start of the step
-                    if (P->d.act == FD_ACT_RELU6) {
-                        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, FD_ACT_RELU6_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
-                        FD_LAUNCH((fd_pw_gemm_train_h16<T, FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles);
-                    } else {
-                        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, FD_ACT_RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);
-                        FD_LAUNCH((fd_pw_gemm_train_h16<T, FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles);
-                    }
+#define FD_PWT_H16(ACTV, TNV)                                                                                                                     \
+    do {                                                                                                                                          \
+        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, ACTV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);     \
+        FD_LAUNCH((fd_pw_gemm_train_h16<T, ACTV, TNV>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles); \
+    } while (0)
+                    if (P->d.act == FD_ACT_RELU6) { if (L.pw_tn == 2) FD_PWT_H16(FD_ACT_RELU6_, 2); else FD_PWT_H16(FD_ACT_RELU6_, 1); }
+                    else { if (L.pw_tn == 2) FD_PWT_H16(FD_ACT_RELU_, 2); else FD_PWT_H16(FD_ACT_RELU_, 1); }
+#undef FD_PWT_H16
                     rc = check_launch("fd_pw_gemm_train_h16");
                 }
             }
@@ -319,10 +320,13 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample only as the 1-channel head", i);
                 L.out_h = L.in_h; L.out_w = L.in_w;
                 const long M = (long)batch * L.out_h * L.out_w;
-                L.m_tiles = ceil_div(M, 64); L.n_tiles = ceil_div(d.cout, 64);
+                // 16-bit forward GEMM: 64 x 128 tiles when there are >= 128 output channels and that still leaves >= 200 workgroups
+                L.pw_tn = (h16 && d.cout >= 128 && (long)ceil_div(M, 64) * ceil_div(d.cout, 128) >= 200) ? 2 : 1;
+                const int bn = 64 * L.pw_tn;
+                L.m_tiles = ceil_div(M, 64); L.n_tiles = ceil_div(d.cout, bn);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
                 L.k64 = (d.cin + 63) / 64 * 64; L.n64 = (d.cout + 63) / 64 * 64;
-                L.lds = h16 ? (size_t)3 * 128 * 128 + ((size_t)2 * L.k64 + 256) * 4 : (size_t)(3 * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
+                L.lds = h16 ? (size_t)3 * (64 + bn) * 128 + ((size_t)2 * L.k64 + 4 * bn) * 4 : (size_t)(3 * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
                 L.nblk = L.m_tiles;
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
                     const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
@@ -335,7 +339,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             break;
         default: FD_BAD("layer %d: unknown op", i);
         }
-        if (L.lds > 64 * 1024) FD_BAD("layer %d: LDS request %zu exceeds 64 KiB", i, L.lds);
+        // (the 16-bit pointwise forward kernel raises its dynamic-LDS limit itself; the other train kernels stay within the default 64 KiB)
+        if (L.lds > ((h16 && d.op == FD_OP_PW && !L.head) ? 160 : 64) * 1024) FD_BAD("layer %d: LDS request %zu exceeds the limit", i, L.lds);
         L.M = (long)batch * L.out_h * L.out_w;
         L.z_elems = (size_t)L.M * d.cout;
         L.n_stat = (double)L.M;
