@@ -157,10 +157,40 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
     };
     const int TWS = TW >> 2, nstrips = TH * TWS;
     const int soy = pt >> (tw_shift - 2), sox = (pt & (TWS - 1)) * 4;
+    // 3x3 units with a single channel chunk (C = 32) keep their nine taps and the bias in registers for the workgroup's life
+    constexpr bool TAPREG = KS == 3;
+    fd_f32x4 tapr[TAPREG ? KK : 1], biasr = fd_zero4();
+    const bool taps_in_regs = TAPREG && nchunks == 1;
+    if (taps_in_regs) {
+#pragma unroll
+        for (int t = 0; t < (TAPREG ? KK : 1); ++t) tapr[t] = fd_ld4(s_t + t * 32 + c4 * 4);
+        biasr = fd_ld4(s_bd + c4 * 4);
+    }
     auto depthwise = [&](int item) __attribute__((always_inline)) {
         if (pt >= nstrips) return;
         const int chunk = item & (nchunks - 1);
         const float *taps = s_t + chunk * KK * 32 + c4 * 4;
+        if (taps_in_regs) {
+            fd_f32x4 d[4] = {biasr, biasr, biasr, biasr};
+#pragma unroll
+            for (int ky = 0; ky < (TAPREG ? KS : 0); ++ky) {
+                const float *row = s_in + ((soy * S + ky) * TW_in + sox * S) * PSTR + c4 * 4;
+                fd_f32x4 r[NIN];
+#pragma unroll
+                for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] += r[j * S + kx] * tapr[TAPREG ? ky * KS + kx : 0];
+            }
+            float *A = s_a + (item & 1) * BM * 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int arow = (soy << tw_shift) + sox + j;
+                fd_st4(A + arow * 32 + ((c4 ^ ((arow >> 1) & 7)) << 2), fd_act4<ACT>(d[j]));
+            }
+            return;
+        }
         const fd_f32x4 b4 = fd_ld4(s_bd + chunk * 32 + c4 * 4);
         fd_f32x4 d[4] = {b4, b4, b4, b4};
 #pragma unroll 1
