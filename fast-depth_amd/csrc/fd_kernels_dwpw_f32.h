@@ -11,19 +11,22 @@
 // Persistent, wave-specialised workgroup (512 work-items, one per CU; measured: with ordinary workgroups all resident workgroups of a CU
 // run load -> depthwise -> MFMA -> store in lock-step and nothing overlaps):
 //   waves 0-3  PRODUCERS  stage the next 32-channel chunk of the input patch [(TH-1)S+K][(TW-1)S+K][32] (global -> registers -> LDS;
-//                         up2 / skip add / zero padding applied on the way; the loads of item i+1 are in flight while item i is
-//                         computed), then the depthwise taps: work-item = (strip of 4 pixels along x, 4 channels) -> GEMM A tile
+//                         up2 / skip add / zero padding applied on the way; two register sets: the loads of items i+1 and i+2 are in
+//                         flight while item i is computed), then the depthwise taps: work-item = (strip of 4 pixels along x, 4 channels) -> GEMM A tile
 //                         [BM][32] (double buffered, 16-byte-chunk XOR swizzle of fd_pw_gemm_f32);
 //   waves 4-7  CONSUMERS  wave (wm, wn) owns rows [32 wm, +32) x column tiles wn*NT .. +NT of the tile: 16*NT v_mfma_f32_32x32x2_f32 per
-//                         chunk on the A tile the producers finished one step earlier, and the tile's stores (bias was the
-//                         accumulators' start value: activation, one 128-byte row segment per D register).
+//                         chunk on the A tile the producers finished one step earlier; a finished tile is parked in registers and its
+//                         stores (bias was the accumulators' start value: activation, one 128-byte row segment per D register) go out a
+//                         quarter at a time between the next item's MFMAs.
 // An ITEM is (pixel tile, channel chunk); step i of a workgroup: producers commit + convolve item i while consumers multiply item i-1;
 // two workgroup barriers per step (patch committed / A tile complete), raw s_barrier so that the prefetch stays in flight.
 // Tiles are dealt so that all tiles of an image run on one XCD (workgroup b -> XCD b % 8 -> images n = b (mod 8)): patch halos hit L2.
+// The patch image's row pitch PSTR comes from the host (pick_patch_pitch, fd_api.hip): the smallest pitch for which the strips' ds_read_b128
+// are bank-conflict free.
 #pragma once
 #include "fd_device.h"
 
-#ifdef FD_DWPW_PROBE   // tools/microbench/dwpw.hip: shader-clock totals per wave of workgroup 0 (four segments of a pipeline step)
+#ifdef FD_DWPW_PROBE   // tools/microbench/dwpw.hip: shader-clock totals per wave of one workgroup (segments of a pipeline step)
 __device__ unsigned long long fd_dwpw_probe[8][6];
 #define FD_DWPW_T(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pr[k] += t_ - t0; t0 = t_; } while (0)
 #else
