@@ -8,8 +8,8 @@ Differences from the reference, all deliberate:
     so it prints launch latency);
   * any batch size (the reference validates with batch 1, main.py:40-41);
   * metrics come from ONE fused device reduction per batch (metrics.py of this package) instead of ~12 host syncs;
-  * the NYU-Depth-v2 HDF5 loader is not rebuilt (dataset absent, h5py absent; dataloaders/ depends on removed SciPy/NumPy
-    APIs): samples are `.npz` files holding `rgb` and `depth` -- either RAW frames ([480,640,3] uint8 + [480,640] float32
+  * the reference's dataloader classes are not rebuilt (dataset absent; dataloaders/ depends on removed SciPy/NumPy APIs): samples are
+    the reference's `.h5` frames (read with h5py when it is installed -- it is not in this image) or `.npz` files holding `rgb` and `depth` -- either RAW frames ([480,640,3] uint8 + [480,640] float32
     metres), which go through the reference's val_transform as ONE device gather (dataloaders/nyu.py, pinned against PIL), or
     frames already at the network resolution ([H,W,3] uint8 or float in [0,1]) -- or, by default, the reference's own shipped
     sample (deploy/data) replicated.
@@ -51,11 +51,23 @@ def parse_command(argv=None):
 def load_samples(args):
     files = []
     if args.samples:
-        files = sorted(glob.glob(os.path.join(args.samples, '*.npz'))) if os.path.isdir(args.samples) else [args.samples]
+        if os.path.isdir(args.samples):
+            files = sorted(glob.glob(os.path.join(args.samples, '*.npz')) + glob.glob(os.path.join(args.samples, '**', '*.h5'), recursive=True))
+        else:
+            files = [args.samples]
     if files:
         out = []
         for f in files:
-            z = np.load(f)
+            if f.endswith('.h5'):
+                # the reference's NYU-Depth-v2 files (dataloaders/dataloader.py:8-13 h5_loader: 'rgb' [3,480,640] uint8, 'depth' [480,640])
+                try:
+                    import h5py
+                except ImportError:
+                    raise RuntimeError("%s is an HDF5 sample but h5py is not installed; convert it to .npz (rgb [480,640,3] uint8, depth [480,640] float32)" % f)
+                with h5py.File(f, 'r') as h5f:
+                    z = {'rgb': np.transpose(np.array(h5f['rgb']), (1, 2, 0)), 'depth': np.array(h5f['depth'])}
+            else:
+                z = np.load(f)
             if z['rgb'].dtype == np.uint8 and z['rgb'].shape[:2] == (480, 640):
                 # raw NYU frame: kept as uint8 HWC; validate() runs the reference's val_transform on the GPU (dataloaders/nyu.py)
                 out.append((torch.from_numpy(z['rgb']), torch.from_numpy(z['depth'].astype(np.float32))))
