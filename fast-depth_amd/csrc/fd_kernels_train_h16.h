@@ -384,8 +384,7 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
     const int Tn = (int)((mend - mbeg + BR - 1) / BR);
     // loader mapping: chunk cc = tid & 7 (8 columns), rows lr and lr + 32 of the 64-pixel step
     // (the pixel order within a wave's 8 pixels is 0,2,4,6,1,3,5,7: lanes l and l+32 then hold the two 16-bit halves of one LDS dword --
-    // ds_write_b16 is served in the two 32-lane halves, and two lanes of one half on the same dword were a 2-way conflict: 40 % of this
-    // kernel's LDS cycles, PMC)
+    // ds_write_b16 is served in the two 32-lane halves, and two lanes of one half on the same dword are a 2-way conflict)
     const int cc = tid & 7, lr = (tid >> 3 & ~7) + 2 * (tid >> 3 & 3) + (tid >> 5 & 1);
     const int ncol = n0 + cc * 8;
     const bool n_ok = ncol < N;                                   // N, K % 8 == 0
