@@ -364,7 +364,7 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
 // ------------------------------------------------------------------------------------------------
 // Backward-weights:  wpart[split][n][k] = sum over the split's pixels m of dz[m][n] * a_in[m][k],  a_in = act_in(z_in*s+t).
 // Workgroup = 64 (n) x 64 (k) output tile, 64 pixels per step.  LDS image: dzT[64 n][64 m], aT[64 k][64 m] in T, rows of
-// 144 bytes, the 16-byte chunk (8 consecutive m) of row r stored at chunk position c ^ ((r >> 3) & 7): the 2-byte transposing
+// 192 bytes, the 16-byte chunk (8 consecutive m) of row r stored at chunk position c ^ ((r >> 3) & 7): the 2-byte transposing
 // writes of a wave then spread over the banks, and a fragment is one ds_read_b128.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ACT_IN, int TN = 1>   // TN: 64-column k tiles per workgroup (output tile 64 n x 64*TN k): the staged dz tile feeds TN times the MFMAs
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256)
 fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
                 int M, int N, int K, int k_tiles, int rows_per_split)
 {
-    constexpr int BT = 64, BR = 64, PITCH = 144;
+    constexpr int BT = 64, BR = 64, PITCH = 192;   // 192-byte rows: the transposing 2-byte writes AND the fragment ds_read_b128s are bank-conflict free (144: 2-way read conflicts, PMC)
     __shared__ __attribute__((aligned(16))) unsigned char s_dz[BT * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned char s_a[BT * TN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
