@@ -8,7 +8,9 @@
 One "step" = one inference forward of a batch of 32 synthetic 224x224 RGB frames already resident in HBM
 (BASELINE.json configs[1]: unpruned model, batch 32, fp32, 1xMI355X, HIP kernels).  With N > 1 every rank
 runs its own batch of 32 (weak scaling; inference shards over frames with no collective, SURVEY.md 8(e));
-the timed region is bracketed by barrier + torch.cuda.synchronize() and the max over ranks is taken.
+the timed region is bracketed by barrier + torch.cuda.synchronize() and the max over ranks is taken.  Setup (plan creation,
+weight packing and 40 untimed forwards that bring a freshly leased GPU up to its clocks: `config.untimed_device_wakeup_steps_before_warmup`)
+precedes the W warm-up steps; exactly K full steps are timed.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline          the kernel symbol with the largest share of device time, timed live with HIP events on the launch stream,
                     priced against the fp32 MFMA peak or HBM bandwidth (MI355X_MICROARCH.md); `traffic` from the committed PMC summary
@@ -449,6 +451,13 @@ def main():
         return
 
     # ---- headline: configs[1] ---------------------------------------------------------------------------------------------------------
+    # Device wake-up, part of setup like plan creation and weight packing: a freshly leased GPU ramps its clocks over the first tens of
+    # milliseconds of work, and a K = 20, W = 5 run (16 ms timed) would otherwise report the ramp (measured: 40.2 k instead of 41.0 k
+    # frames/s).  These forwards are untimed and come BEFORE the W warm-up steps; the timed region is still exactly K full steps.
+    PREROLL = 40
+    with torch.no_grad():
+        for _ in range(PREROLL):
+            model(x)
     elapsed = time_forward(model, x, args.steps, args.warmup)
     roof, whole, kernels, n_kernels = inference_profile(eng, x, args.profile_steps, MFMA_F32_PEAK_TFLOPS)
     ms_per_step = elapsed / args.steps * 1e3
@@ -500,7 +509,8 @@ def main():
             "config": {"workload": "configs[1]: MobileNet-NNConv5(dw)+skipadd unpruned, batch=32 per GPU, 224x224 fp32 "
                                    "inference forward, inputs resident in HBM", "batch_per_gpu": args.batch,
                        "global_batch": world * args.batch, "parallelism": "frames sharded over %d GPU(s), no collective" % world,
-                       "kernels_per_step": n_kernels, "rccl_ranks": world if dist is not None else 0},
+                       "kernels_per_step": n_kernels, "rccl_ranks": world if dist is not None else 0,
+                       "untimed_device_wakeup_steps_before_warmup": PREROLL},
             "roofline": roof,
             "whole_step": whole,
             "kernels": kernels,
