@@ -746,7 +746,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             const long tiles = (long)Pw.dp_tiles_x * ceil_div(D.out_h, bth) * batch;
             Pw.dp_xcd = batch >= 8 ? 1 : 0;                    // images dealt to XCDs (b mod 8); small batches: tiles dealt round-robin
             Pw.grid = dim3((unsigned)(Pw.dp_xcd ? 256 : std::min<long>(256, tiles)));
-            Pw.pstr = pick_patch_pitch(32, 1 << btw, ((1 << btw) - 1) * S + KS, S);
+            Pw.pstr = pick_patch_pitch(32, 1 << btw, ((1 << btw) - 1) * S + KS, S, S == 2 ? 2 : 4);
             Pw.lds = lds + (size_t)nld * 32 * (Pw.pstr - 36) * 4;
             // the network head (32 -> 1 pointwise on the up2 of this unit's output) as the only reader: evaluated on the accumulators
             if (i + 2 < n_layers && !(flags & FD_PLAN_KEEP_ACTIVATIONS) && KS == 5 && D.mode == 2 && N == 32 && nt == 1 && wm == 4) {

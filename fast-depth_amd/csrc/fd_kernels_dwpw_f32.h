@@ -45,7 +45,8 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
             const fd_dwpw_head hd)
 {
     static_assert(!HEAD || (NT == 1 && WM == 4), "the head reads all 32 columns of a pixel from one wave");
-    constexpr int P = KS / 2, NIN = 3 * S + KS, WN = 4 / WM, BM = 32 * WM, KK = KS * KS;
+    constexpr int SW = S == 2 ? 2 : 4, SWS = S == 2 ? 1 : 2;   // output pixels per depthwise strip: the stride-2 units' 64-pixel tile gives every producer work-item a 2-pixel strip
+    constexpr int P = KS / 2, NIN = (SW - 1) * S + KS, WN = 4 / WM, BM = 32 * WM, KK = KS * KS;
     static_assert(WM * WN == 4, "four consumer waves");
     FD_DYN_SMEM(smem_raw);
     const int nchunks = C >> 5, cshift = 31 - __builtin_clz(nchunks);      // C / 32 is a power of two (checked by the plan)
@@ -158,8 +159,8 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
             fd_st4(s_in + (pt + 32 * u) * PSTR + c4 * 4, v);
         }
     };
-    const int TWS = TW >> 2, nstrips = TH * TWS;
-    const int soy = pt >> (tw_shift - 2), sox = (pt & (TWS - 1)) * 4;
+    const int TWS = TW >> SWS, nstrips = TH * TWS;
+    const int soy = pt >> (tw_shift - SWS), sox = (pt & (TWS - 1)) * SW;
     // 3x3 units with a single channel chunk (C = 32) keep their nine taps and the bias in registers for the workgroup's life
     constexpr bool TAPREG = KS == 3;
     fd_f32x4 tapr[TAPREG ? KK : 1], biasr = fd_zero4();
@@ -174,7 +175,9 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
         const int chunk = item & (nchunks - 1);
         const float *taps = s_t + chunk * KK * 32 + c4 * 4;
         if (taps_in_regs) {
-            fd_f32x4 d[4] = {biasr, biasr, biasr, biasr};
+            fd_f32x4 d[SW];
+#pragma unroll
+            for (int j = 0; j < SW; ++j) d[j] = biasr;
 #pragma unroll
             for (int ky = 0; ky < (TAPREG ? KS : 0); ++ky) {
                 const float *row = s_in + ((soy * S + ky) * TW_in + sox * S) * PSTR + c4 * 4;
@@ -184,18 +187,20 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[j] += r[j * S + kx] * tapr[TAPREG ? ky * KS + kx : 0];
+                    for (int j = 0; j < SW; ++j) d[j] += r[j * S + kx] * tapr[TAPREG ? ky * KS + kx : 0];
             }
             float *A = s_a + (item & 1) * BM * 32;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < SW; ++j) {
                 const int arow = (soy << tw_shift) + sox + j;
                 fd_st4(A + arow * 32 + ((c4 ^ ((arow >> 1) & 7)) << 2), fd_act4<ACT>(d[j]));
             }
             return;
         }
         const fd_f32x4 b4 = fd_ld4(s_bd + chunk * 32 + c4 * 4);
-        fd_f32x4 d[4] = {b4, b4, b4, b4};
+        fd_f32x4 d[SW];
+#pragma unroll
+        for (int j = 0; j < SW; ++j) d[j] = b4;
 #pragma unroll 1
         for (int ky = 0; ky < (ABL == 2 ? 0 : KS); ++ky) {
             const float *row = s_in + ((soy * S + ky) * TW_in + sox * S) * PSTR + c4 * 4;
@@ -206,12 +211,12 @@ fd_dwpw_f32(const float *__restrict__ in, const float *__restrict__ skip, const 
             for (int kx = 0; kx < KS; ++kx) {
                 const fd_f32x4 w = fd_ld4(taps + (ky * KS + kx) * 32);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] += r[j * S + kx] * w;
+                for (int j = 0; j < SW; ++j) d[j] += r[j * S + kx] * w;
             }
         }
         float *A = s_a + (item & 1) * BM * 32;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SW; ++j) {
             const int arow = (soy << tw_shift) + sox + j;
             fd_st4(A + arow * 32 + ((c4 ^ ((arow >> 1) & 7)) << 2), fd_act4<ACT>(d[j]));
         }
