@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "fastdepth_hip", "libfastdepth_hip.so")
 SOURCES = [os.path.join(CSRC, "fd_api.hip")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
-         "-Wno-unused-function", "-fgpu-flush-denormals-to-zero" if False else "-DNDEBUG"]
+         "-Wno-unused-function", "-DNDEBUG"]
 
 
 def _stale():

@@ -679,6 +679,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         for (int j = 1; j < n_layers; ++j) {
             Layer &D = p->layers[j];
             if (D.d.op != FD_OP_DW || D.d.src < 0 || D.d.skip >= 0 || D.d.concat) continue;
+            if (D.d.act == FD_ACT_NONE) continue;                      // the epilogue's depthwise stage always clamps at 0 (ReLU / ReLU6)
             Layer &Pw = p->layers[D.d.src];
             if (!Pw.pw16_tm || readers[D.d.src] != 1) continue;       // the pointwise output must have no other reader (skip sources keep their tensor)
             const int hw = Pw.out_h * Pw.out_w;
@@ -793,13 +794,18 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         }
     }
     FreeList fl;
+    std::vector<char> released(n_layers, 0);
     for (int i = 0; i < n_layers; ++i) {
         Layer &L = p->layers[i];
-        if (L.to_output || L.skipped) continue;
+        // a buffer whose last reader is layer i-1 (or earlier: layers that run inside another kernel are passed over below) is free from
+        // layer i on; readers of layer i keep theirs
         if (!(flags & FD_PLAN_KEEP_ACTIVATIONS))
             for (int j = 0; j < i; ++j)
-                if (last_use[j] == i - 1 && !p->layers[j].to_output && !p->layers[j].skipped) fl.release(p->layers[j].out_off - woff, p->layers[j].out_bytes);
-        // (a buffer whose last reader is layer i-1 is free from layer i on; readers of layer i keep theirs)
+                if (!released[j] && last_use[j] >= 0 && last_use[j] <= i - 1 && !p->layers[j].to_output && !p->layers[j].skipped) {
+                    fl.release(p->layers[j].out_off - woff, p->layers[j].out_bytes);
+                    released[j] = 1;
+                }
+        if (L.to_output || L.skipped) continue;
         if (L.fused_into >= 0) continue;                     // allocated together with its producer (below)
         L.out_off = woff + fl.alloc(L.out_bytes);
         // a depthwise layer evaluated in this layer's epilogue is WRITTEN by this layer's kernel: its buffer must be live now, while this
@@ -995,12 +1001,21 @@ int fd_plan_import(const void *host_buffer, size_t bytes, int32_t batch_override
     memcpy(&h, host_buffer, sizeof h);
     if (memcmp(h.magic, kBundleMagic, 8) || h.header_bytes != sizeof h || h.desc_bytes != sizeof(fd_layer_desc))
         return fail(FD_ERR_INVALID, "not a deploy bundle of this library version");
-    if (bytes < sizeof h + (size_t)h.n_layers * sizeof(fd_layer_desc) + h.weights_bytes) return fail(FD_ERR_INVALID, "truncated deploy bundle");
-    std::vector<fd_layer_desc> descs(h.n_layers);
-    memcpy(descs.data(), static_cast<const unsigned char *>(host_buffer) + sizeof h, (size_t)h.n_layers * sizeof(fd_layer_desc));
-    // the packed weights do not depend on the batch size: a bundle exported at one batch serves any other
+    // every size in the header is file-controlled: each term is checked against what is left of the buffer (no sum that could wrap)
+    const size_t rest = bytes - sizeof h;
+    if (h.n_layers == 0 || h.n_layers > 4096 || h.n_layers > rest / sizeof(fd_layer_desc)) return fail(FD_ERR_INVALID, "truncated deploy bundle (layer table)");
+    if (h.weights_bytes > rest - (size_t)h.n_layers * sizeof(fd_layer_desc)) return fail(FD_ERR_INVALID, "truncated deploy bundle (weights)");
     fd_plan *p = nullptr;
-    int rc = fd_plan_create(descs.data(), (int32_t)h.n_layers, batch_override > 0 ? batch_override : h.batch, h.height, h.width, h.dtype, h.flags, &p);
+    int rc;
+    try {
+        std::vector<fd_layer_desc> descs(h.n_layers);
+        memcpy(descs.data(), static_cast<const unsigned char *>(host_buffer) + sizeof h, (size_t)h.n_layers * sizeof(fd_layer_desc));
+        // the packed weights do not depend on the batch size: a bundle exported at one batch serves any other
+        // (descriptors and flags go through fd_plan_create's own validation, like a caller's)
+        rc = fd_plan_create(descs.data(), (int32_t)h.n_layers, batch_override > 0 ? batch_override : h.batch, h.height, h.width, h.dtype, h.flags, &p);
+    } catch (const std::exception &e) {
+        return fail(FD_ERR_INVALID, "deploy bundle rejected: %s", e.what());          // no C++ exception crosses the C ABI
+    }
     if (rc) return rc;
     if (p->weights_bytes != h.weights_bytes) { fd_plan_destroy(p); return fail(FD_ERR_INVALID, "bundle weight layout (%llu bytes) does not match this library (%zu)", (unsigned long long)h.weights_bytes, p->weights_bytes); }
     *out_plan = p;
@@ -1016,8 +1031,9 @@ int fd_plan_import_weights(fd_plan *plan, const void *host_buffer, size_t bytes,
     memcpy(&h, host_buffer, sizeof h);
     if (memcmp(h.magic, kBundleMagic, 8) || h.weights_bytes != plan->weights_bytes || h.n_layers != plan->layers.size())
         return fail(FD_ERR_INVALID, "bundle does not belong to this plan");
+    const size_t rest = bytes - sizeof h;
+    if (h.n_layers > rest / sizeof(fd_layer_desc) || h.weights_bytes > rest - (size_t)h.n_layers * sizeof(fd_layer_desc)) return fail(FD_ERR_INVALID, "truncated deploy bundle");
     const unsigned char *w = static_cast<const unsigned char *>(host_buffer) + sizeof h + (size_t)h.n_layers * sizeof(fd_layer_desc);
-    if (bytes < (size_t)(w - static_cast<const unsigned char *>(host_buffer)) + h.weights_bytes) return fail(FD_ERR_INVALID, "truncated deploy bundle");
 #ifdef FD_EMU
     (void)stream;
     memcpy(plan->ws, w, h.weights_bytes);

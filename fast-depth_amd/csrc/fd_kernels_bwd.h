@@ -188,6 +188,52 @@ fd_l1_loss_final_f32(const float *__restrict__ part, int nblk, float inv_numel, 
     if (threadIdx.x == 0) loss[0] = f * inv_numel;
 }
 
+// ---- masked mean-L1 loss (the criterion of the upstream the reference was cut from, README.md:65: sparse-to-dense's MaskedL1Loss --
+// valid = target > 0, loss = mean over the VALID pixels of |pred - target|; NYU depth maps hold invalid zeros, the reason metrics.py:32
+// masks them too).  Pass 1 leaves per-workgroup (sum |d|, #valid) partials; pass 2: every workgroup adds the <= 1024 partial pairs in the
+// same fixed order (so all agree on the count), writes dpred = sign(d) / #valid on the valid pixels and 0 elsewhere; workgroup 0 writes the
+// loss (NaN when nothing is valid: the mean of an empty selection, as torch reports it; the gradient is all zeros then).
+__global__ void __launch_bounds__(256)
+fd_l1_masked_partial_f32(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ part, long numel)
+{
+    __shared__ float red[4][2];
+    float s = 0.0f, c = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const float t = target[i];
+        if (t > 0.0f) { s += fabsf(pred[i] - t); c += 1.0f; }
+    }
+    for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); c += __shfl_xor(c, m); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        part[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];      // <= 2^24 per workgroup slice: exact in fp32
+    }
+}
+__global__ void __launch_bounds__(256)
+fd_l1_masked_apply_f32(const float *__restrict__ pred, const float *__restrict__ target, const float *__restrict__ part, int nblk,
+                       float *__restrict__ dpred, float *__restrict__ loss, long numel)
+{
+    __shared__ double red[256][2];
+    double s = 0.0, c = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) { s += (double)part[2 * b]; c += (double)part[2 * b + 1]; }
+    red[threadIdx.x][0] = s; red[threadIdx.x][1] = c;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        for (int k = 1; k < 4; ++k) { s += red[threadIdx.x + 64 * k][0]; c += red[threadIdx.x + 64 * k][1]; }
+        red[threadIdx.x][0] = s; red[threadIdx.x][1] = c;
+    }
+    __syncthreads();
+    s = 0.0; c = 0.0;
+    for (int k = 0; k < 64; ++k) { s += red[k][0]; c += red[k][1]; }      // same order in every work-item of every workgroup
+    const float inv = c > 0.0 ? (float)(1.0 / c) : 0.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) loss[0] = c > 0.0 ? (float)(s / c) : __builtin_nanf("");
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const float t = target[i], d = pred[i] - t;
+        dpred[i] = t > 0.0f ? (d > 0.0f ? inv : (d < 0.0f ? -inv : 0.0f)) : 0.0f;
+    }
+}
+
 // ---- depth metrics (row f-2): every sum of reference metrics.py:31-55 in ONE pass, no per-scalar host synchronisation --------
 // sums[0] = #valid, [1] = sum ad^2, [2] = sum ad, [3] = sum |log10 o - log10 t|, [4] = sum ad/t, [5..7] = #(maxRatio < 1.25^k),
 // [8] = sum (1/o - 1/t)^2, [9] = sum |1/o - 1/t|;  valid = (target > 0) or (output > 0), o = 1e3*output, t = 1e3*target (mm).

@@ -384,7 +384,7 @@ int fd_depth_metrics_frames(const void *output, const void *target, int32_t n_fr
     return check_launch("fd_depth_metrics_final_f32");
 }
 
-size_t fd_l1_loss_scratch_bytes(int64_t numel) { (void)numel; return 1024 * sizeof(float); }
+size_t fd_l1_loss_scratch_bytes(int64_t numel) { (void)numel; return 2 * 1024 * sizeof(float); }   // masked form: (sum, count) per workgroup
 
 int fd_l1_loss(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream)
 {
@@ -398,6 +398,19 @@ int fd_l1_loss(const void *pred, const void *target, void *dpred, float *loss_ou
     if (rc) return rc;
     FD_LAUNCH(fd_l1_loss_final_f32, dim3(1), dim3(64), 0, s, static_cast<const float *>(scratch), nb, inv, loss_out);
     return check_launch("fd_l1_loss_final_f32");
+}
+
+int fd_l1_loss_masked(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream)
+{
+    if (!pred || !target || !dpred || !loss_out || !scratch || numel <= 0) return fail(FD_ERR_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::min<int64_t>(1024, (numel + 255) / 256);
+    FD_LAUNCH(fd_l1_masked_partial_f32, dim3(nb), dim3(256), 0, s, static_cast<const float *>(pred), static_cast<const float *>(target), static_cast<float *>(scratch), (long)numel);
+    int rc = check_launch("fd_l1_masked_partial_f32");
+    if (rc) return rc;
+    FD_LAUNCH(fd_l1_masked_apply_f32, dim3(nb), dim3(256), 0, s, static_cast<const float *>(pred), static_cast<const float *>(target), static_cast<const float *>(scratch), nb,
+              static_cast<float *>(dpred), loss_out, (long)numel);
+    return check_launch("fd_l1_masked_apply_f32");
 }
 
 int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t total_numel, float lr, float momentum, float weight_decay,

@@ -11,8 +11,8 @@ Differences from the reference, all deliberate:
   * the reference's dataloader classes are not rebuilt (dataset absent; dataloaders/ depends on removed SciPy/NumPy APIs): samples are
     the reference's `.h5` frames (read with h5py when it is installed -- it is not in this image) or `.npz` files holding `rgb` and `depth` -- either RAW frames ([480,640,3] uint8 + [480,640] float32
     metres), which go through the reference's val_transform as ONE device gather (dataloaders/nyu.py, pinned against PIL), or
-    frames already at the network resolution ([H,W,3] uint8 or float in [0,1]) -- or, by default, the reference's own shipped
-    sample (deploy/data) replicated.
+    frames already at the network resolution ([H,W,3] uint8 or float in [0,1]) -- or, by default (no --samples), `--repeat` seeded
+    synthetic NYU-shaped frames (noise images with depths in [0.7, 10] m: they exercise the loop and its printout, nothing more).
 A checkpoint is the reference's pickle ({'epoch','best_result','model'} or a bare module, main.py:49-57); without one, a seeded
 random-weight model is evaluated (useful only as a smoke test of the loop).
 """
@@ -43,7 +43,7 @@ def parse_command(argv=None):
     parser.add_argument('--gpu', default='0', type=str, metavar='N', help="gpu id")
     parser.add_argument('--batch-size', default=1, type=int)
     parser.add_argument('--samples', default='', help='directory of .npz samples or one .npz file (default: seeded synthetic NYU-shaped frames)')
-    parser.add_argument('--repeat', default=8, type=int, help='how many times the default sample is replicated')
+    parser.add_argument('--repeat', default=8, type=int, help='how many synthetic frames the default (no --samples) run evaluates')
     parser.add_argument('--dtype', default='f32', choices=['f32', 'f16', 'bf16'], help='activation storage inside the engine')
     return parser.parse_args(argv)
 

@@ -114,6 +114,8 @@ def load(path=None):
         lib.fd_l1_loss_scratch_bytes.restype = ctypes.c_size_t
         lib.fd_l1_loss.argtypes = [vp, vp, vp, vp, ctypes.c_int64, vp, vp]
         lib.fd_l1_loss.restype = ctypes.c_int
+        lib.fd_l1_loss_masked.argtypes = [vp, vp, vp, vp, ctypes.c_int64, vp, vp]
+        lib.fd_l1_loss_masked.restype = ctypes.c_int
         lib.fd_sgd_step.argtypes = [vp, i32, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i32, vp]
         lib.fd_sgd_step.restype = ctypes.c_int
     lib.fd_val_transform.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
@@ -150,7 +152,7 @@ EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_p
            "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats",
            "fd_train_plan_create", "fd_train_plan_destroy", "fd_train_plan_workspace_bytes", "fd_train_plan_bind_workspace",
            "fd_train_forward", "fd_train_backward", "fd_train_backward_range", "fd_train_layer_tensor", "fd_l1_loss_scratch_bytes",
-           "fd_l1_loss", "fd_sgd_step", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
+           "fd_l1_loss", "fd_l1_loss_masked", "fd_sgd_step", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
            "fd_depth_metrics_frames_scratch_bytes", "fd_depth_metrics_frames", "fd_plan_export_bytes", "fd_plan_export",
            "fd_plan_import", "fd_plan_import_weights", "fd_plan_shape", "fd_trace_begin", "fd_trace_end", "fd_last_error", "fd_version")
 

@@ -5,7 +5,6 @@ PyTorch is used for what the boundary leaves to the host: device memory (`torch.
 stream, parameter storage.  All arithmetic happens in libfastdepth_hip.so.
 """
 import ctypes
-import os
 
 import torch
 
@@ -55,11 +54,15 @@ class _Plan:
 class Engine:
     """One per model instance (created lazily by MobileNetSkipAdd.forward)."""
 
-    def __init__(self, model, keep_activations=False, dtype=torch.float32):
+    # extra fd_plan_create flags for every plan an Engine creates (A/B aid of tools/*.py, e.g. capi.FD_PLAN_NO_UNIT_FUSION); set in code --
+    # neither the host side nor the C ABI reads the environment
+    default_plan_flags = 0
+
+    def __init__(self, model, keep_activations=False, dtype=torch.float32, plan_flags=None):
         self.model = model
         self.layers = layers_of(model)
         self.keep = keep_activations
-        self.plan_flags = int(os.environ.get("FD_PLAN_FLAGS", "0"), 0)     # extra fd_plan_create flags (tuning experiments: FD_PLAN_STREAMK = 32, FD_PLAN_FUSE_SEPARABLE = 4)
+        self.plan_flags = Engine.default_plan_flags if plan_flags is None else int(plan_flags)
         self.plans = {}
         self.set_dtype(dtype)
 

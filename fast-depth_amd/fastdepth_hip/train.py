@@ -178,10 +178,14 @@ class TrainFunction(torch.autograd.Function):
     forwards summed into one loss are not part of this path).  The parameters go through save_for_backward so that autograd's
     version-counter check fires when one of them is edited in place between forward and backward.
 
-    Gradients are delivered without per-tensor copies: backward writes the flat gradient buffer and hands each parameter its VIEW of
-    it as `.grad` (the usual `optimizer.zero_grad(); loss.backward(); optimizer.step()` loop then costs no copy kernel at all);
-    gradients already present are accumulated into with one multi-tensor add.  Consequence: tensor hooks registered on the
-    parameters do not fire (data parallelism is TrainEngine's job, not DistributedDataParallel's)."""
+    Gradients are RETURNED to autograd (so `torch.autograd.grad`, `backward(inputs=...)`, tensor hooks and accumulation hooks all see
+    them, and a parameter with requires_grad=False gets none) and still cost no per-tensor copy in the usual
+    `optimizer.zero_grad(); loss.backward(); optimizer.step()` loop: every returned tensor is a freshly made VIEW of the flat gradient
+    buffer backward has just written, and autograd's AccumulateGrad adopts an otherwise unreferenced, layout-conforming gradient as
+    `.grad` without cloning it.  Such a `.grad` aliases the buffer, i.e. it holds this backward's value until the next backward of
+    this model overwrites it; gradients already present are accumulated into by autograd (`.grad += returned`), and where the
+    existing `.grad` IS a view of the buffer (a second backward without zero_grad) it is first moved onto a private copy, so that the
+    sum comes out as old + new."""
 
     @staticmethod
     def forward(ctx, core, x, *params):
@@ -200,27 +204,26 @@ class TrainFunction(torch.autograd.Function):
             raise capi.FastDepthError("backward of a train-mode forward whose saved activations were overwritten by a later forward "
                                       "(one outstanding forward per model: call backward before the next train-mode forward)")
         params = ctx.saved_tensors                # raises if a parameter was modified in place since forward
-        views = core.views_in_param_order
-        base = core.flat_grad.untyped_storage().data_ptr()
-        had = [(p.grad, v) for p, v in zip(params, views) if p.grad is not None]
-        aliased = [g.untyped_storage().data_ptr() == base for g, _ in had]
-        keep = core.flat_grad.clone() if any(aliased) else None      # accumulation into gradients that ARE the buffer backward overwrites
+        need = ctx.needs_input_grad[2:]
+        flat = core.flat_grad
+        base = flat.untyped_storage().data_ptr()
+        # a .grad that IS a view of the buffer (a second backward without zero_grad) would show the new value the moment the kernels write
+        # it: move those onto a private copy first, so that autograd's `.grad += returned` comes out as old + new
+        aliased = [p for p, n in zip(params, need) if n and p.grad is not None and p.grad.untyped_storage().data_ptr() == base]
+        if aliased:
+            keep = flat.clone()
+            for p in aliased:
+                start = (p.grad.data_ptr() - flat.data_ptr()) // 4
+                p.grad = keep[start:start + p.numel()].view(p.shape)
         core.backward(dy.contiguous())
-        if had:
-            off = keep.data_ptr() - core.flat_grad.data_ptr() if keep is not None else 0
-            other = []
-            for (g, v), al in zip(had, aliased):
-                if al:
-                    start = (v.data_ptr() - core.flat_grad.data_ptr()) // 4
-                    other.append(keep[start:start + v.numel()].view_as(v))
-                else:
-                    other.append(v)
-            del off
-            torch._foreach_add_([g for g, _ in had], other)
-        for p, v in zip(params, views):
-            if p.grad is None:
-                p.grad = v
-        return (None, None) + (None,) * len(params)
+        out = []
+        for v, n in zip(core.views_in_param_order, need):
+            if not n:
+                out.append(None)
+                continue
+            start = (v.data_ptr() - flat.data_ptr()) // 4
+            out.append(flat[start:start + v.numel()].view(v.shape))      # a fresh tensor object: nothing else references it
+        return (None, None) + tuple(out)
 
 
 def autograd_forward(core, x):
@@ -250,9 +253,12 @@ class TrainEngine(TrainCore):
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4, force_buckets=False,
-                 dtype=torch.float32, _library=None):
+                 dtype=torch.float32, masked_loss=False, _library=None):
         super().__init__(model, dtype, _library)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        # masked_loss: mean-L1 over the pixels with target > 0 only (the upstream train script's MaskedL1Loss, README.md:65) instead of
+        # torch.nn.L1Loss over every pixel
+        self.masked_loss = bool(masked_loss)
         self.group = process_group
         self.world = 1
         if process_group is not None:
@@ -294,8 +300,9 @@ class TrainEngine(TrainCore):
         if time_comm and on_gpu:
             ev = {k: torch.cuda.Event(enable_timing=True) for k in ("bwd0", "bwd1", "c0", "c1", "end")}
         with _device_guard(self.device):
-            capi.check(L, L.fd_l1_loss(pred.data_ptr(), target.data_ptr(), self._dpred.data_ptr(), self.loss.data_ptr(), pred.numel(),
-                                       self._scratch.data_ptr(), sp), "fd_l1_loss")
+            loss_fn = L.fd_l1_loss_masked if self.masked_loss else L.fd_l1_loss
+            capi.check(L, loss_fn(pred.data_ptr(), target.data_ptr(), self._dpred.data_ptr(), self.loss.data_ptr(), pred.numel(),
+                               self._scratch.data_ptr(), sp), "fd_l1_loss")
             if ev:
                 ev["bwd0"].record(cur)
             works = []

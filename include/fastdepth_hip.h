@@ -210,6 +210,12 @@ int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t whic
 size_t fd_l1_loss_scratch_bytes(int64_t numel);
 int fd_l1_loss(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream);
 
+/* Masked mean-L1 loss: the criterion of the upstream train script the reference was cut from (README.md:65, sparse-to-dense's
+ * MaskedL1Loss: valid = target > 0; loss = mean over the valid pixels of |pred - target|) -- NYU depth maps contain invalid zeros, the
+ * reason reference metrics.py:32 masks them as well.  dpred = sign(pred - target) / #valid on the valid pixels, 0 elsewhere; with no
+ * valid pixel the loss is NaN (mean of an empty selection) and dpred is all zeros.  Same scratch as fd_l1_loss. */
+int fd_l1_loss_masked(const void *pred, const void *target, void *dpred, float *loss_out, int64_t numel, void *scratch, void *stream);
+
 /* Fused multi-tensor SGD (torch.optim.SGD semantics: d = grad_scale*g + wd*p; buf = mom*buf + d (buf = d on the first
  * step); p -= lr*buf) over n tensors in ONE launch.  `table` is a device array of n fd_sgd_tensor records; grad_scale
  * is 1/world_size after a summing all-reduce (data-parallel mean), 1 otherwise. */

@@ -88,6 +88,13 @@ def l1_train_grads(p, x, target, bn_taps=None):
     return loss.detach(), {k: v.grad.detach().clone() for k, v in p.items() if v.requires_grad}
 
 
+def masked_l1(pred, target):
+    """MaskedL1Loss of the upstream train script the reference was cut from (README.md:65 names it; criteria.py there):
+    valid = target > 0; mean |target - pred| over the valid pixels."""
+    valid = (target > 0).detach()
+    return (target - pred)[valid].abs().mean()
+
+
 def sgd_step(params, grads, bufs, lr=0.01, momentum=0.9, weight_decay=1e-4):
     """torch.optim.SGD(lr, momentum, weight_decay) update, dampening 0, no nesterov; bufs: {key: momentum buffer or None}."""
     with torch.no_grad():

@@ -43,6 +43,19 @@ def test_emulated_l1_loss_and_sgd():
     ref = torch.nn.L1Loss()(p, tgt); ref.backward()
     assert float(loss) == pytest.approx(float(ref), rel=1e-6)
     assert torch.equal(dpred, p.grad)
+    # masked form (valid = target > 0): invalid rows / pixels, an exact tie on a valid pixel, then the all-invalid case
+    from oracle import torch_ref
+    tm = tgt.clone()
+    tm[0, 0, 5:9] = 0.0; tm[1, 0, :, ::3] = 0.0; tm[1, 0, 7, 7] = -1.0
+    dm, lm = torch.full_like(pred, float("nan")), torch.zeros(1)
+    capi.check(L, L.fd_l1_loss_masked(pred.data_ptr(), tm.data_ptr(), dm.data_ptr(), lm.data_ptr(), pred.numel(), scratch.data_ptr(), None), "fd_l1_loss_masked")
+    p = pred.clone().requires_grad_(True)
+    ref = torch_ref.masked_l1(p, tm); ref.backward()
+    assert float(lm) == pytest.approx(float(ref), rel=1e-6)
+    assert torch.equal(dm, p.grad) and float(dm[0, 0, 0, 0]) == 0.0 and float(dm[0, 0, 6].abs().max()) == 0.0
+    tz = torch.zeros_like(tm)
+    capi.check(L, L.fd_l1_loss_masked(pred.data_ptr(), tz.data_ptr(), dm.data_ptr(), lm.data_ptr(), pred.numel(), scratch.data_ptr(), None), "fd_l1_loss_masked")
+    assert torch.isnan(lm).all() and float(dm.abs().max()) == 0.0
     # SGD vs torch.optim.SGD over two steps (first step initialises the momentum buffer with d)
     params = [torch.randn(1000, generator=g), torch.randn(7, 3, generator=g)]
     ref_params = [q.clone().requires_grad_(True) for q in params]
@@ -202,3 +215,49 @@ def test_emulated_skip_concat_train_step_layer_local(dtype):
     target = 2.0 + torch.rand(2, 1, 64, 64, generator=g)
     rep = harness.local_train_parity("emu", m, x, target, torch.device("cpu"), dtype=dtype)
     assert_local_parity(rep, dtype)
+
+
+def test_autograd_function_returns_gradients():
+    """The drop-in autograd entry point (TrainFunction) hands its gradients to autograd: `.grad` adopts a view of the flat buffer (no
+    copy), a second backward accumulates (old + new), torch.autograd.grad / tensor hooks see the gradients, frozen parameters get
+    none, and a backward against a workspace that a later forward overwrote is refused."""
+    from fastdepth_hip.train import TrainCore, autograd_forward
+    L = harness.get_lib("emu")
+    m = small_model(TINY[0], TINY[1], seed=3).train()
+    m.conv3[3].weight.requires_grad_(False)                          # a frozen parameter
+    core = TrainCore(m, torch.float32, _library=L)
+    g = torch.Generator().manual_seed(2)
+    x1, x2 = torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 3, 64, 64, generator=g)
+    tgt = 2.0 + torch.rand(2, 1, 64, 64, generator=g)
+    seen = []
+    m.conv1[0].weight.register_hook(lambda gr: seen.append(gr.clone()))
+    params = [p for p in m.parameters() if p.requires_grad]
+    base = core.flat_grad.untyped_storage().data_ptr()
+    # 1) plain backward: .grad is a view of the flat buffer, the hook fired with the same values
+    loss = (autograd_forward(core, x1) - tgt).abs().mean(); loss.backward()
+    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in params)
+    assert m.conv3[3].weight.grad is None
+    assert len(seen) == 1 and torch.equal(seen[0], m.conv1[0].weight.grad)
+    g1 = [p.grad.clone() for p in params]
+    # 2) autograd.grad: returns the gradients, leaves .grad alone
+    loss = (autograd_forward(core, x2) - tgt).abs().mean()
+    got = torch.autograd.grad(loss, params)
+    assert all(t is not None for t in got)
+    g2 = [t.clone() for t in got]
+    assert any(not torch.equal(a, b) for a, b in zip(g1, g2))
+    assert all(torch.equal(p.grad, a) for p, a in zip(params, g1))   # .grad kept step 1's values (moved off the buffer), untouched by autograd.grad
+    # 3) accumulation without zero_grad: old + new
+    loss = (autograd_forward(core, x2) - tgt).abs().mean(); loss.backward()
+    for p, a, b in zip(params, g1, g2):
+        assert torch.allclose(p.grad, a + b, rtol=1e-6, atol=1e-9)
+    # 4) accumulation into a foreign .grad tensor
+    for p in params:
+        p.grad = torch.ones_like(p)
+    loss = (autograd_forward(core, x2) - tgt).abs().mean(); loss.backward()
+    for p, b in zip(params, g2):
+        assert torch.allclose(p.grad, 1.0 + b, rtol=1e-6, atol=1e-9) and p.grad.untyped_storage().data_ptr() != base
+    # 5) stale forward
+    y_old = autograd_forward(core, x1)
+    autograd_forward(core, x2)
+    with pytest.raises(capi.FastDepthError):
+        (y_old - tgt).abs().mean().backward()

@@ -1,12 +1,14 @@
 """Per-layer device time of one inference forward (HIP events, fd_forward_timed).  Measurement aid.
-usage: python tools/layer_times.py [--batch 32] [--iters 20] [--pruned]"""
+usage: python tools/layer_times.py [--batch 32] [--iters 20] [--pruned] [--dtype f16] [--plan-flags BITS]"""
 import argparse, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "fast-depth_amd")); sys.path.insert(0, REPO)
 import numpy as np, torch
 import models
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--pruned", action="store_true"); ap.add_argument("--dtype", default="f32"); a = ap.parse_args()
+ap.add_argument("--pruned", action="store_true"); ap.add_argument("--dtype", default="f32"); ap.add_argument("--plan-flags", type=lambda v: int(v, 0), default=0); a = ap.parse_args()
+from fastdepth_hip.engine import Engine
+Engine.default_plan_flags = a.plan_flags
 torch.manual_seed(0)
 m = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if a.pruned else None).eval().cuda()
 x = torch.rand(a.batch, 3, 224, 224, device="cuda")
