@@ -363,3 +363,28 @@ def test_batched_evaluation_equals_per_image_protocol(tmp_path):
             assert getattr(r, k) == pytest.approx(want[k], rel=2e-5), (i, k)
     pooled = fd_metrics.Result(); pooled.evaluate(out, tgt)
     assert abs(pooled.rmse - np.mean([r.rmse for r in per])) > 1e-6        # the two protocols really differ
+
+
+@pytest.mark.parametrize("b,streams", [(1, 1), (4, 1), (4, 2)])
+def test_forward_graph_replay_equals_eager_forward(b, streams):
+    """Engine.forward_graph (hipGraph replay; bench.py's B=1 latency line) returns bit for bit what the eager forward returns, on first
+    capture, on replay with new input CONTENTS in the same buffer, and after a parameter edit (the graph is re-captured with repacked
+    weights).  streams = 2 splits the batch over two captured streams (independent frames: same bits)."""
+    m, x, _, _ = inputs.golden_case("base_s0")
+    m = m.cuda()
+    xs = inputs.batch_variants(inputs.load_sample()[0], b, seed=3).cuda()
+    eng = m._engine()
+    with torch.no_grad():
+        want = m(xs).clone()
+        got = eng.forward_graph(xs, streams=streams).clone()
+        assert torch.equal(got, want)
+        xs.copy_(inputs.batch_variants(inputs.load_sample()[0], b, seed=5).cuda())          # same address, new frames
+        want2 = m(xs).clone()
+        got2 = eng.forward_graph(xs, streams=streams).clone()
+        assert torch.equal(got2, want2) and not torch.equal(got2, got)
+        m.conv5[3].weight.mul_(1.25)                                                        # version counter moves -> re-capture
+        want3 = m(xs).clone()
+        got3 = eng.forward_graph(xs, streams=streams).clone()
+        assert torch.equal(got3, want3) and not torch.equal(got3, got2)
+    with pytest.raises(RuntimeError):
+        eng.forward_graph(xs.cpu())

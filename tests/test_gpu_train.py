@@ -217,3 +217,46 @@ def test_train_step_layer_local_other_shape(dtype):
     tgt = 0.7 + 9 * torch.rand(3, 1, 160, 96, generator=g)
     rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
     assert_local_parity(rep, dtype)
+
+
+# ---- BASELINE.json configs[2] at its stated size: batch 32, 224x224 -- the configuration bench.py times ------------------------------------------
+# At B = 32 the kernels run grids and reduction geometries that no smaller batch selects (up to 6272 partial rows per BatchNorm reduction cut
+# into up to 98 slices with a last-arriver pass, 16-way pixel splits of the weight-gradient GEMMs, 64 x 128 bf16 tiles, whole-chip one-round
+# grids).  The fp64 single-unit references below are a few minutes of host time.
+
+def _product_plan_gradients(m, x, tgt, dtype):
+    """Gradients of the plan the product (and bench.py) uses -- no KEEP_ACTIVATIONS: ping-pong gradient buffers, dz in place over G."""
+    tp = harness.CTrainPlan("hip", m, x.cuda(), keep=False, dtype=dtype)
+    y = tp.forward(x.cuda()).cpu()
+    grads = tp.backward(torch.sign(y - tgt) / y.numel())
+    flat = torch.cat([g[k].flatten().cpu() for g in grads for k in ("conv_weight", "bn_weight", "bn_bias")])
+    tp.close()
+    return y, flat
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_train_step_layer_local_parity_batch32(dtype):
+    """configs[2] parity AT batch 32: every unit's forward and backward kernels on their own stored inputs vs the fp64 single-unit autograd
+    reference (harness.local_train_parity; fp32 plan at fp32 accuracy, bf16-stored tensors within one rounding), and the product plan
+    (no KEEP_ACTIVATIONS) reproduces the checked plan's prediction and all 114 gradient tensors bit for bit."""
+    from test_emu_train import assert_local_parity
+    m = _model(seed=23)
+    x, tgt = _batch(32, seed=9)
+    torch.set_num_threads(min(64, torch.get_num_threads() * 4))
+    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
+    assert_local_parity(rep, dtype)
+    tp = harness.CTrainPlan("hip", m, x.cuda(), keep=True, dtype=dtype)
+    y_keep = tp.forward(x.cuda()).cpu()
+    gk = tp.backward(torch.sign(y_keep - tgt) / y_keep.numel())
+    flat_keep = torch.cat([g[k].flatten().cpu() for g in gk for k in ("conv_weight", "bn_weight", "bn_bias")])
+    tp.close()
+    y, flat = _product_plan_gradients(m, x, tgt, dtype)
+    assert torch.equal(y, y_keep) and torch.equal(flat, flat_keep)
+
+
+def test_train_forward_backward_parity_batch32():
+    """configs[2]'s size, fp32 plan end to end against the fp64 oracle (mask-consistent backward, all 114 gradient tensors)."""
+    m = _model(seed=24)
+    x, tgt = _batch(32, seed=10)
+    rep = harness.train_parity_report("hip", m, x, tgt, torch.device("cuda"))
+    harness.assert_train_parity(rep, tol=2e-3)
