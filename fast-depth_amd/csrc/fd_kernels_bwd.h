@@ -57,10 +57,8 @@ __device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__
     const int c = bx * 64 + lane;
     const int r0 = by * rps;
     int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-#pragma unroll 4
-        for (int b = r0 + wave; b < r1; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+    double s, q;
+    fd_sum_partial_rows(part, r0, r1, wave, C, c, c < C, s, q);
     sh[wave][lane][0] = s; sh[wave][lane][1] = q;
     __syncthreads();
     if (wave == 0) {
@@ -616,19 +614,21 @@ fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
 //   MODE 2: as MODE 1, and skipgrad_out = din at full resolution                   (input was up2(a_in) + a_skip)
 // plus the producer's BN partials  part[blk*2*C + {0,C} + c].
 // ------------------------------------------------------------------------------------------------
+// (body: bm = logical (tile, channel block, image) of this workgroup, grid_x = tiles per image -- the plain kernel passes fd_xcd_image_map() /
+// gridDim.x, the paired launch fd_dw_bwd its own numbering)
 template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
-__global__ void __launch_bounds__(256)
-fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
+__device__ __forceinline__ void
+fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
     // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
-    const fd_blk3 bm = fd_xcd_image_map();                 // all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2
+    // (bm: all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2)
     const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
     const int c0 = bm.y * CB, n = bm.z;
     const int iy0 = ty * TH, ix0 = tx * TW;
@@ -810,13 +810,24 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
     if (tid < lanes_c) {
         fd_f32x4 a = fd_zero4(), b = fd_zero4();
         for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
-        const long blk = (long)bm.z * gridDim.x + bm.x;
+        const long blk = (long)bm.z * grid_x + bm.x;
         if (c0 + tid * 4 < Cp) {
             fd_st4(part + blk * 2 * Cp + c0 + tid * 4, a);
             fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, b);
         }
     }
 }
+template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
+                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
+{
+    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit,
+                                                    fd_xcd_image_map(), (int)gridDim.x);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Depthwise backward-weights: dW[c][ky][kx] = sum over (n, oy, ox) of dz[oy][ox][c] * in[oy*S-P+ky][ox*S-P+kx][c].
@@ -825,11 +836,11 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
 // shares are summed through LDS once per workgroup, which writes wpart[blk][K*K][C].
 // ------------------------------------------------------------------------------------------------
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
-__global__ void __launch_bounds__(256)
-fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
+__device__ __forceinline__ void
+fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
-                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit)
+                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
@@ -842,7 +853,6 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
     // a workgroup walks `tpw` horizontally adjacent tiles and keeps its tap sums in registers across them: one workgroup
     // reduction and one partial row per `tpw` tiles
     const int groups_x = (tiles_x + tpw - 1) / tpw;
-    const fd_blk3 bm = fd_xcd_image_map();                 // all tile groups / channel blocks of an image on one XCD
     const int ty = bm.x / groups_x, tgx = bm.x - ty * groups_x;
     const int c0 = bm.y * CB, n = bm.z;
     const int oy0 = ty * TH;
@@ -971,7 +981,7 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
         for (int kx = 0; kx < K; ++kx) fd_st4(red + ((pg * K * K + ky * K + kx) * lanes_c + c4) * 4, acc[kx]);
     }
     __syncthreads();
-    const long blk = (long)bm.z * gridDim.x + bm.x;
+    const long blk = (long)bm.z * grid_x + bm.x;
     for (int i = tid; i < K * K * lanes_c; i += 256) {
         const int t = i >> cbq, cc = i & (lanes_c - 1);
         if (c0 + cc * 4 < C) {
@@ -981,6 +991,65 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
         }
     }
 }
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
+__global__ void __launch_bounds__(256)
+fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
+                const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
+                const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
+                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit)
+{
+    fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(zin, st1, zskip, st2, G, Z, coef, wpart, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, tpw, csplit,
+                                                fd_xcd_image_map(), (int)gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch for BOTH backward kernels of a depthwise unit ("horizontal" pairing).  They are independent of each other (both read G, z and
+// the unit's saved input; one writes the producer's gradient, the other the weight-gradient partials), and as two launches on one stream
+// they serialise: on the 14x14 / 7x7 maps each is a single round of workgroups bound by its own load -> LDS -> taps -> store latency
+// (12-13 us for ~2 us of HBM time), and every launch pays its ramp and its tail.  Here the 1-D grid is dealt in groups of eight images:
+// first the backward-data workgroups of the group, then its weight-gradient workgroups -- workgroup b still runs on XCD b % 8, so all work
+// of an image stays on one XCD and the second role finds G / z in that XCD's L2.  LDS and registers are those of the larger role.
+// ------------------------------------------------------------------------------------------------
+struct fd_pair_blk { int role; fd_blk3 b; };
+__device__ __forceinline__ fd_pair_blk fd_pair_map(unsigned b, unsigned per0, unsigned per1, unsigned nimg)
+{
+    const unsigned per = per0 + per1;
+    const unsigned grp = b / (8u * per);
+    unsigned rem = b - grp * 8u * per;
+    const unsigned m = nimg - grp * 8u < 8u ? nimg - grp * 8u : 8u;   // images in this group (the last one may be short)
+    fd_pair_blk r;
+    r.role = rem >= m * per0;
+    if (r.role) rem -= m * per0;
+    r.b.z = (int)(grp * 8u + rem % m); r.b.x = (int)(rem / m); r.b.y = 0;
+    return r;
+}
+template <typename T> struct fd_dw_bwd_args {
+    const T *G, *Z, *Zin, *Zskip, *SG;
+    T *Gin, *SGout;
+    const float *coef, *w, *st_in, *st_skip;
+    float *part, *wpart;
+    int Hin, Win, Ho, Wo, C, cbq, csplit;
+    int d_th, d_tw, d_tiles_x, d_gx, d_gy;             // backward-data: INPUT-space tiles; grid (d_gx tiles, d_gy channel blocks) per image
+    int w_th, w_tw, w_tiles_x, w_tpw, w_gx, w_gy;      // backward-weights: OUTPUT-space tiles, tpw of them per workgroup
+    int B;
+};
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_dw_bwd(const fd_dw_bwd_args<T> a)
+{
+    const fd_pair_blk pb = fd_pair_map(blockIdx.x, (unsigned)(a.d_gx * a.d_gy), (unsigned)(a.w_gx * a.w_gy), (unsigned)a.B);
+    fd_blk3 bm = pb.b;
+    if (pb.role == 0) {
+        bm.y = bm.x / a.d_gx; bm.x -= bm.y * a.d_gx;
+        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+                                                      a.d_th, a.d_tw, a.d_tiles_x, a.csplit, bm, a.d_gx);
+    } else {
+        bm.y = bm.x / a.w_gx; bm.x -= bm.y * a.w_gx;
+        fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+                                                    a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, bm, a.w_gx);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps -- a [Cout x P] x [P x 27] matrix

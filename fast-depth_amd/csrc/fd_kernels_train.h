@@ -382,6 +382,23 @@ fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const fl
     }
 }
 
+// Sum of the partial rows r0 + wave, r0 + wave + 16, ... (< r1) of columns c (first sum) and C + c (second sum) of a [rows][2C] buffer, in
+// row order, in double: eight rows' loads are in flight at a time (a single-level finalisation of up to 256 rows is two such batches per wave).
+__device__ __forceinline__ void fd_sum_partial_rows(const float *__restrict__ part, int r0, int r1, int wave, int C, int c, bool ok, double &s, double &q)
+{
+    s = 0.0; q = 0.0;
+    if (!ok) return;
+    int b = r0 + wave;
+    for (; b + 16 * 7 < r1; b += 16 * 8) {
+        float vs[8], vq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { vs[u] = part[(long)(b + 16 * u) * 2 * C + c]; vq[u] = part[(long)(b + 16 * u) * 2 * C + C + c]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += (double)vs[u]; q += (double)vq[u]; }
+    }
+    for (; b < r1; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Two-level deterministic reduction in ONE launch ("last arriver").  The rows of a partial buffer (up to 6272 workgroups of
 // the producer) are cut into gridDim.y slices of `rps` rows; workgroup (x, y) sums slice y for the 64 columns of block x (16
@@ -453,10 +470,8 @@ fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, dou
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * rps;
     int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-#pragma unroll 4
-        for (int b = r0 + wave; b < r1; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
+    double s, q;
+    fd_sum_partial_rows(part, r0, r1, wave, C, c, c < C, s, q);
     sh[wave][lane][0] = s; sh[wave][lane][1] = q;
     __syncthreads();
     if (wave == 0) {

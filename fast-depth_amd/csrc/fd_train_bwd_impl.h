@@ -145,6 +145,70 @@ int launch_dw_wgrad(BwdCtx &c, int i)
     return launch_dw_wgrad_acts<T, FD_ACT_RELU6_, FD_ACT_RELU_>(c, i);
 }
 
+// Both backward kernels of a depthwise unit in ONE launch (fd_dw_bwd); returns FD_OK with *paired = false when this unit's combination of
+// kernel size / stride / input composition / activations has no paired instance (the caller then launches the two kernels one after the other).
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG>
+int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
+{
+    TLayer &L = c.p->layers[i];
+    TLayer &P = c.p->layers[L.d.src];
+    const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
+    const int cb = 4 << L.cbq;
+    fd_dw_bwd_args<T> a{};
+    a.G = twt<T>(c.p, L.g_off); a.Z = twt<T>(c.p, L.z_off); a.Zin = twt<T>(c.p, P.z_off);
+    a.Zskip = Kp ? twt<T>(c.p, Kp->z_off) : nullptr; a.SG = ADD_SG ? twt<T>(c.p, P.sg_off) : nullptr;
+    a.Gin = twt<T>(c.p, P.g_off); a.SGout = Kp ? twt<T>(c.p, Kp->sg_off) : nullptr;
+    a.coef = tws(c.p, L.coef_off); a.w = c.params[i].conv_weight; a.st_in = tws(c.p, P.st_off); a.st_skip = Kp ? tws(c.p, Kp->st_off) : nullptr;
+    a.part = tws(c.p, c.p->part_off); a.wpart = tws(c.p, L.wp_off);
+    a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.B = c.p->B;
+    // backward-data geometry (launch_dw_dgrad)
+    a.d_th = 8; a.d_tw = 16;
+    a.d_tiles_x = ceil_div(L.in_w, a.d_tw);
+    a.d_gx = a.d_tiles_x * ceil_div(L.in_h, a.d_th); a.d_gy = ceil_div(L.d.cin, cb);
+    const int ph = (a.d_th - 1 + K / 2) / S + (K - 1) / S + 3, pw = (a.d_tw - 1 + K / 2) / S + (K - 1) / S + 3;
+    const size_t lds_d = dw_bwd_lds(ph, pw, cb, K);
+    // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
+    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.grid.x * L.grid.y * L.grid.z / 1536)));
+    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
+    const int groups_x = ceil_div(L.tiles_x, tpw);
+    tpw = ceil_div(L.tiles_x, groups_x);
+    a.w_th = L.th; a.w_tw = L.tw; a.w_tiles_x = L.tiles_x; a.w_tpw = tpw; a.w_gx = groups_x * L.tiles_y; a.w_gy = (int)L.grid.y;
+    const int th_in = (L.th - 1) * S + K, tw_in = (L.tw - 1) * S + K;
+    const size_t lds_w = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cb + 4), (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
+    const size_t lds = std::max(lds_d, lds_w);
+    if (lds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 64 KiB", lds);
+    const int wblk = a.w_gx * c.p->B, kk = K * K;
+    if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+    const long total = (long)c.p->B * ((long)a.d_gx * a.d_gy + (long)a.w_gx * a.w_gy);
+    FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG>), dim3((unsigned)total), dim3(256), lds, c.s, a);
+    int rc = check_launch("fd_dw_bwd");
+    if (rc) return rc;
+    *nblk_out = a.d_gx * c.p->B;
+    return defer_weights(c, a.wpart, wblk, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
+}
+
+template <typename T>
+int dispatch_dw_bwd_pair(BwdCtx &c, int i, int *nblk, bool *paired)
+{
+    const TLayer &L = c.p->layers[i];
+    const TLayer &P = c.p->layers[L.d.src];
+    const int a1 = P.d.act, a2 = L.d.skip >= 0 ? c.p->layers[L.d.skip].d.act : FD_ACT_RELU6;
+    const bool add = P.skip_consumer >= 0 && L.mode == 0;
+    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
+    *paired = true;
+    if (a1 == FD_ACT_RELU6 && !add) {
+        if (key == 310) return launch_dw_bwd_pair<T, 3, 1, 0, FD_ACT_RELU6_, FD_ACT_RELU6_, 0>(c, i, nblk);
+        if (key == 320) return launch_dw_bwd_pair<T, 3, 2, 0, FD_ACT_RELU6_, FD_ACT_RELU6_, 0>(c, i, nblk);
+        if (key == 510) return launch_dw_bwd_pair<T, 5, 1, 0, FD_ACT_RELU6_, FD_ACT_RELU6_, 0>(c, i, nblk);
+    }
+    if (a1 == FD_ACT_RELU6 && add && key == 320) return launch_dw_bwd_pair<T, 3, 2, 0, FD_ACT_RELU6_, FD_ACT_RELU6_, 1>(c, i, nblk);
+    if (a1 == FD_ACT_RELU && key == 511) return launch_dw_bwd_pair<T, 5, 1, 1, FD_ACT_RELU_, FD_ACT_RELU6_, 0>(c, i, nblk);
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6 && key == 512) return launch_dw_bwd_pair<T, 5, 1, 2, FD_ACT_RELU_, FD_ACT_RELU6_, 0>(c, i, nblk);
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6 && key == 513) return launch_dw_bwd_pair<T, 5, 1, 3, FD_ACT_RELU_, FD_ACT_RELU6_, 0>(c, i, nblk);
+    *paired = false;                                          // an unusual combination (sibling / custom plans): the two separate kernels cover it
+    return FD_OK;
+}
+
 template <typename T, int ACT_IN>
 int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
 {
@@ -297,6 +361,14 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             break;
         }
         case FD_OP_DW: {
+            if (!(plan->flags & FD_PLAN_NO_BWD_PAIRING) && !plan->concurrent_wgrad) {
+                bool paired = false;
+                if ((rc = dispatch_dw_bwd_pair<T>(c, i, &nblk, &paired))) return rc;
+                if (paired) {
+                    if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+                    break;
+                }
+            }
             if ((rc = launch_dw_wgrad<T>(c, i))) return rc;
             const TLayer &P = plan->layers[d.src];
             const bool add = P.skip_consumer >= 0 && L.mode == 0;

@@ -83,12 +83,13 @@ namespace {
 inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
 template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reinterpret_cast<T *>(p->ws + off); }
 
-// Launch geometry of the fused two-level reductions (fd_two_level_tail): up to 64 partial rows are finalised by a single
-// workgroup per 64 columns; more rows are cut into slices of 64 that the grid's y dimension sums first.
+// Launch geometry of the fused two-level reductions (fd_two_level_tail): up to 256 partial rows are finalised by a single
+// workgroup per 64 columns (16 rows per wave, all loads of 8 rows in flight: cheaper than slices + arrival counter + second level, which is
+// three more dependent round trips -- the 14x14 / 7x7 units have 25 ... 98 rows); more rows are cut into slices that the grid's y dimension sums first.
 struct RedGeom { int rps; dim3 grid; };
 inline RedGeom red_geom(int nrows, long width)
 {
-    if (nrows <= 64) return RedGeom{nrows, dim3((unsigned)ceil_div(width, 64), 1)};
+    if (nrows <= 256) return RedGeom{nrows, dim3((unsigned)ceil_div(width, 64), 1)};
     const int rps = std::max(64, ceil_div(nrows, 128));       // at most 128 slices (fd_two_level_tail: 8 per wave)
     return RedGeom{rps, dim3((unsigned)ceil_div(width, 64), (unsigned)ceil_div(nrows, rps))};
 }

@@ -29,6 +29,7 @@ FD_PLAN_CONCURRENT_WGRAD = 128
 FD_PLAN_NO_EPILOGUE_FUSION = 512
 FD_PLAN_NO_UNIT_FUSION = 1024
 FD_PLAN_FORCE_UNIT_FUSION = 2048
+FD_PLAN_NO_BWD_PAIRING = 4096
 
 
 class LayerDesc(ctypes.Structure):

@@ -148,7 +148,8 @@ def assert_local_parity(rep, dtype):
 
 @pytest.mark.parametrize("name,plan,dtype,flags", [("tiny", TINY, torch.float32, 0), ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_WGRAD_TILE_ROWS),
                                                    ("ragged", RAGGED, torch.bfloat16, 0), ("tiny_wide", TINY, torch.float32, 0),
-                                                   ("tiny_sat6", TINY, torch.float32, 0), ("ragged_sat6", RAGGED, torch.bfloat16, 0)])
+                                                   ("tiny_sat6", TINY, torch.float32, 0), ("ragged_sat6", RAGGED, torch.bfloat16, 0),
+                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_NO_BWD_PAIRING), ("ragged", RAGGED, torch.bfloat16, capi.FD_PLAN_NO_BWD_PAIRING)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     """Every unit's forward and backward kernels on their own stored inputs against an fp64 single-unit autograd reference
     (harness.local_train_parity): the rigorous check of the bf16 train plan, whose end-to-end
@@ -157,7 +158,8 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     if name.endswith("sat6"):
         harness.saturate_encoder(m)
     g = torch.Generator().manual_seed(9)
-    h, w = (96, 160) if name == "tiny_wide" else (64, 64)    # tiny_wide: > 64 partial rows per reduction -> the sliced (last-arriver) path
+    h, w = (160, 224) if name == "tiny_wide" else (64, 64)   # tiny_wide: > 256 partial rows per reduction (280 for conv1.3 / decode_conv5.1) -> the sliced (last-arriver) path
+    # (default plans launch a unit's backward-data and backward-weights kernels as one paired launch; FD_PLAN_NO_BWD_PAIRING: one after the other)
     x = torch.rand(2, 3, h, w, generator=g)
     target = 2.0 + torch.rand(2, 1, h, w, generator=g)
     rep = harness.local_train_parity("emu", m, x, target, torch.device("cpu"), dtype=dtype, flags=flags)

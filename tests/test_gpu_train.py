@@ -260,3 +260,36 @@ def test_train_forward_backward_parity_batch32():
     x, tgt = _batch(32, seed=10)
     rep = harness.train_parity_report("hip", m, x, tgt, torch.device("cuda"))
     harness.assert_train_parity(rep, tol=2e-3)
+
+
+def test_masked_l1_loss_on_device_and_in_the_engine():
+    """fd_l1_loss_masked (valid = target > 0: the upstream train script's criterion, README.md:65) vs its torch restatement on depth maps with
+    invalid rows / pixels; TrainEngine(masked_loss=True) reports it and trains on it."""
+    from fastdepth_hip import capi
+    from fastdepth_hip.engine import lib
+    from fastdepth_hip.train import TrainEngine
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    pred = (torch.rand(4, 1, 224, 224, generator=g) * 5).cuda()
+    tgt = torch.rand(4, 1, 224, 224, generator=g) * 5 + 0.5
+    tgt[:, :, :17] = 0.0; tgt[1, 0, :, ::5] = 0.0; tgt[2] = 0.0
+    tgt = tgt.cuda()
+    pred[0, 0, 100, :8] = tgt[0, 0, 100, :8]                                   # exact ties on valid pixels: gradient 0
+    dm, lm = torch.full_like(pred, float("nan")), torch.zeros(1, device="cuda")
+    scratch = torch.empty(L.fd_l1_loss_scratch_bytes(pred.numel()), dtype=torch.uint8, device="cuda")
+    capi.check(L, L.fd_l1_loss_masked(pred.data_ptr(), tgt.data_ptr(), dm.data_ptr(), lm.data_ptr(), pred.numel(), scratch.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "fd_l1_loss_masked")
+    p = pred.detach().cpu().double().requires_grad_(True)
+    ref = torch_ref.masked_l1(p, tgt.cpu().double()); ref.backward()
+    assert float(lm) == pytest.approx(float(ref), rel=1e-6)
+    assert torch.allclose(dm.cpu().double(), p.grad, rtol=1e-6, atol=0) and float(dm[2].abs().max()) == 0.0 and float(dm[0, 0, 100, 0]) == 0.0
+    x, t2 = _batch(4, seed=3)
+    t2[:, :, :40] = 0.0
+    base = _model(seed=31)
+    pr = torch_ref.params_from_state(base.state_dict(), torch.float32, requires_grad=True)
+    want = torch_ref.masked_l1(torch_ref.forward(pr, x, train=True), t2)
+    eng = TrainEngine(copy.deepcopy(base).cuda().train(), lr=0.01, masked_loss=True)
+    l0 = float(eng.step(x.cuda(), t2.cuda()))
+    assert l0 == pytest.approx(float(want), rel=1e-4)
+    l1 = float(eng.step(x.cuda(), t2.cuda()))
+    assert np.isfinite(l1) and l1 < l0
