@@ -147,7 +147,8 @@ def inference_profile(eng, x, steps, mfma_peak_tflops):
 
 # kernel families of the train step whose launches move a unit's activations once (fwd 1x + bwd 2x the inference bytes);
 # everything else (BatchNorm finalisation, partial reductions, operand packing) is overhead with no algorithmic traffic of its own
-_TRAIN_MAJOR = ("gemm_train", "dwconv_train", "stem_train", "head_train", "dgrad", "wgrad", "head_bwd<")
+_TRAIN_MAJOR = ("gemm_train", "dwconv_train", "stem_train", "head_train", "dgrad", "wgrad", "head_bwd<", "fd_dw_bwd<", "fd_pw_bwd_")
+_TRAIN_PAIRED = ("head_bwd<", "fd_dw_bwd<", "fd_pw_bwd_")       # one launch = a unit's backward-data AND backward-weights pass
 
 
 def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes):
@@ -170,7 +171,7 @@ def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes):
             e["launches"] += 1; e["ms"] += r.ms
             raw = r.kernel.decode()
             if any(t in raw for t in _TRAIN_MAJOR) and r.layer >= 0:
-                mult = 2.0 if "head_bwd<" in raw else 1.0          # the head's backward kernel is its dgrad and wgrad in one
+                mult = 2.0 if any(t in raw for t in _TRAIN_PAIRED) else 1.0
                 e["bytes"] += mult * stats[r.layer][3]; e["flops"] += mult * stats[r.layer][4]
             elif "sgd" in raw:
                 e["bytes"] += 5.0 * param_bytes                     # grad read, param read+write, momentum read+write

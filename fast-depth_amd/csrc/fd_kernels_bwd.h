@@ -407,11 +407,11 @@ fd_head_bwd(const float *__restrict__ g, const float *__restrict__ zlow, const f
 // consecutive lanes = consecutive k).
 // ------------------------------------------------------------------------------------------------
 template <int ACT_IN, int ADD_SG>
-__global__ void __launch_bounds__(256)
-fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+__device__ __forceinline__ void              // blk: linear workgroup number (blockIdx.x of the plain kernel; the paired launch fd_pw_bwd_f32 passes its own)
+fd_pw_dgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
                 const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part,
-                int M, int N, int K, int m_tiles, int k_tiles)
+                int M, int N, int K, int m_tiles, int k_tiles, const unsigned blk)
 {
     constexpr int BM = 64, BKO = 64, BR = 32;                 // output tile 64 x 64, reduction step 32
     constexpr int STAGE = 2 * BM * BR + BR * BKO;             // floats: G, Z, W tiles
@@ -422,7 +422,7 @@ fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
     float *red = tab + 4 * N32;                                // [2][2][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blk & 7, slot = blk >> 3;
     const int kt = slot % k_tiles, mt = (slot / k_tiles) * 8 + xcd;
     if (mt >= m_tiles) return;
     const long m0 = (long)mt * BM;
@@ -518,6 +518,16 @@ fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
         part[(long)mt * 2 * K + K + k0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
     }
 }
+template <int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
+                const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part,
+                int M, int N, int K, int m_tiles, int k_tiles)
+{
+    fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, part, M, N, K, m_tiles, k_tiles, blockIdx.x);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Pointwise backward-weights GEMM:  dW[N][K] = sum_m dz[m][n] * a_in[m][k],  a_in = act_in(z_in*s+t).
@@ -529,19 +539,19 @@ fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
 // LDS per stage: G [32 m][64 n], Z [32 m][64 n], Zin [32 m][64 k]  (256-byte rows, LDS-DMA, 3-stage ring).
 // ------------------------------------------------------------------------------------------------
 template <int ACT_IN>
-__global__ void __launch_bounds__(256)
-fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+__device__ __forceinline__ void              // (bx, by) = (output tile, pixel split): blockIdx of the plain kernel
+fd_pw_wgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
-                int M, int N, int K, int k_tiles, int rows_per_split)
+                int M, int N, int K, int k_tiles, int rows_per_split, const int bx, const int by)
 {
     constexpr int BR = 32, BT = 64, STAGE = 3 * BR * BT;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int nt = blockIdx.x / k_tiles, kt = blockIdx.x - nt * k_tiles;
+    const int nt = bx / k_tiles, kt = bx - nt * k_tiles;
     const int n0 = nt * BT, k0 = kt * BT;
-    const long mbeg = (long)blockIdx.y * rows_per_split;
+    const long mbeg = (long)by * rows_per_split;
     long mend = mbeg + rows_per_split; if (mend > M) mend = M;
     const int T = (int)((mend - mbeg + BR - 1) / BR);
     // LDS-DMA: each tile is 32 rows x 16 chunks; a wave instruction covers 4 rows -> 8 groups per tile, 2 per wave
@@ -593,7 +603,7 @@ fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
         }
     }
     // partial tile: wpart[split][n][k]
-    float *o = wpart + (long)blockIdx.y * N * K;
+    float *o = wpart + (long)by * N * K;
     const int col = k0 + wk * 32 + (lane & 31);
     const int rb = n0 + wn * 32 + 4 * (lane >> 5);
     if (col < K) {
@@ -604,6 +614,32 @@ fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const 
         }
     }
 }
+template <int ACT_IN>
+__global__ void __launch_bounds__(256)
+fd_pw_wgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
+                int M, int N, int K, int k_tiles, int rows_per_split)
+{
+    fd_pw_wgrad_f32_body<ACT_IN>(G, Z, coef, Zin, st_in, wpart, M, N, K, k_tiles, rows_per_split, blockIdx.x, blockIdx.y);
+}
+// Both backward GEMMs of a pointwise unit in one launch (see fd_dw_bwd below for why): the backward-data workgroups first, then the
+// tiles x splits weight-gradient workgroups.
+template <int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_pw_bwd_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
+              const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
+              const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part, float *__restrict__ wpart,
+              int M, int N, int K, int m_tiles, int k_tiles, int n_dgrad, int tiles_w, int rows_per_split)
+{
+    if ((int)blockIdx.x < n_dgrad) {
+        fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, part, M, N, K, m_tiles, k_tiles, blockIdx.x);
+    } else {
+        const int b = (int)blockIdx.x - n_dgrad;
+        const int by = b / tiles_w;
+        fd_pw_wgrad_f32_body<ACT_IN>(G, Z, coef, Zin, st_in, wpart, M, N, K, k_tiles, rows_per_split, b - by * tiles_w, by);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Depthwise backward-data.  din[y][x][c] = sum_{ky,kx} dz[(y+P-ky)/S][(x+P-kx)/S][c] * w[c][ky][kx]  (terms with a

@@ -226,10 +226,11 @@ fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__r
 // Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed
 // through LDS so that z_in / skipgrad are read and G_in is written 8 channels (16 bytes) per lane.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT_IN, int ADD_SG, int TN = 1>   // TN: 32-column tiles per wave (workgroup tile 64 x 64*TN of G_in): every dz fragment feeds TN MFMAs
-__global__ void __launch_bounds__(256)
-fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
-                const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles)
+template <typename T, int ACT_IN, int ADD_SG, int TN>   // TN: 32-column tiles per wave (workgroup tile 64 x 64*TN of G_in): every dz fragment feeds TN MFMAs
+__device__ __forceinline__ void                       // blk: linear workgroup number (blockIdx.x of the plain kernel; the paired launch fd_pw_bwd_h16 passes its own)
+fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
+                const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles,
+                const unsigned blk)
 {
     constexpr int BM = 64, BKO = 64 * TN, BR = 64;
     constexpr int ROWS = BM + BKO, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
@@ -237,7 +238,7 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
     float *red = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][2][BKO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = blk & 7, slot = blk >> 3;
     const int kt = slot % k_tiles, mt = (slot / k_tiles) * 8 + xcd;
     if (mt >= m_tiles) return;
     const long m0 = (long)mt * BM;
@@ -361,25 +362,35 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
     }
 }
 
+template <typename T, int ACT_IN, int ADD_SG, int TN = 1>
+__global__ void __launch_bounds__(256)
+fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
+                const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles)
+{
+    fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, part, M, N, K, N64, m_tiles, k_tiles, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward-weights:  wpart[split][n][k] = sum over the split's pixels m of dz[m][n] * a_in[m][k],  a_in = act_in(z_in*s+t).
 // Workgroup = 64 (n) x 64 (k) output tile, 64 pixels per step.  LDS image: dzT[64 n][64 m], aT[64 k][64 m] in T, rows of
 // 192 bytes, the 16-byte chunk (8 consecutive m) of row r stored at chunk position c ^ ((r >> 3) & 7): the 2-byte transposing
 // writes of a wave then spread over the banks, and a fragment is one ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int ACT_IN, int TN = 1>   // TN: 64-column k tiles per workgroup (output tile 64 n x 64*TN k): the staged dz tile feeds TN times the MFMAs
-__global__ void __launch_bounds__(256)
-fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
-                int M, int N, int K, int k_tiles, int rows_per_split)
+#define FD_PW_WGRAD_H16_LDS(TN_) ((size_t)64 * (1 + (TN_)) * 192)
+template <typename T, int ACT_IN, int TN>   // TN: 64-column k tiles per workgroup (output tile 64 n x 64*TN k): the staged dz tile feeds TN times the MFMAs
+__device__ __forceinline__ void             // (bx, by) = (output tile, pixel split): blockIdx of the plain kernel; dynamic LDS: FD_PW_WGRAD_H16_LDS(TN) bytes
+fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
+                int M, int N, int K, int k_tiles, int rows_per_split, const int bx, const int by)
 {
     constexpr int BT = 64, BR = 64, PITCH = 192;   // 192-byte rows: the transposing 2-byte writes AND the fragment ds_read_b128s are bank-conflict free (144: 2-way read conflicts, PMC)
-    __shared__ __attribute__((aligned(16))) unsigned char s_dz[BT * PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned char s_a[BT * TN * PITCH];
+    FD_DYN_SMEM(smem_w);
+    unsigned char *s_dz = smem_w;                          // [BT][PITCH]
+    unsigned char *s_a = smem_w + BT * PITCH;              // [BT * TN][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int nt = blockIdx.x / k_tiles, kt = blockIdx.x - nt * k_tiles;
+    const int nt = bx / k_tiles, kt = bx - nt * k_tiles;
     const int n0 = nt * BT, k0 = kt * BT * TN;
-    const long mbeg = (long)blockIdx.y * rows_per_split;
+    const long mbeg = (long)by * rows_per_split;
     long mend = mbeg + rows_per_split; if (mend > M) mend = M;
     const int Tn = (int)((mend - mbeg + BR - 1) / BR);
     // loader mapping: chunk cc = tid & 7 (8 columns), rows lr and lr + 32 of the 64-pixel step
@@ -457,7 +468,7 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
             }
         }
     }
-    float *o = wpart + (long)blockIdx.y * N * K;
+    float *o = wpart + (long)by * N * K;
     const int rbn = n0 + wn * 32 + 4 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < TN; ++q) {
@@ -469,5 +480,33 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
                 if (row < N) o[(long)row * K + col] = acc[q][r];
             }
         }
+    }
+}
+template <typename T, int ACT_IN, int TN = 1>
+__global__ void __launch_bounds__(256)
+fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
+                int M, int N, int K, int k_tiles, int rows_per_split)
+{
+    fd_pw_wgrad_h16_body<T, ACT_IN, TN>(DZ, Zin, st_in, wpart, M, N, K, k_tiles, rows_per_split, blockIdx.x, blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch for BOTH backward GEMMs of a pointwise unit (they share the operand dz and are independent of each other; as two launches on one
+// stream they serialise, and on the 14x14 / 7x7 maps each is a single round of workgroups bound by its own latency chain).  1-D grid: the
+// backward-data workgroups first (their partial rows feed the BatchNorm finalisation that follows on the critical path), then the
+// n_w = tiles x splits weight-gradient workgroups.  LDS (dynamic) and registers are those of the larger role.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT_IN, int ADD_SG, int TN>
+__global__ void __launch_bounds__(256)
+fd_pw_bwd_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
+              const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, float *__restrict__ wpart,
+              int M, int N, int K, int N64, int m_tiles, int k_tiles_d, int n_dgrad, int k_tiles_w, int tiles_w, int rows_per_split)
+{
+    if ((int)blockIdx.x < n_dgrad) {
+        fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, part, M, N, K, N64, m_tiles, k_tiles_d, blockIdx.x);
+    } else {
+        const int b = (int)blockIdx.x - n_dgrad;
+        const int by = b / tiles_w;
+        fd_pw_wgrad_h16_body<T, ACT_IN, 1>(DZ, Zin, st_in, wpart, M, N, K, k_tiles_w, rows_per_split, b - by * tiles_w, by);
     }
 }

@@ -224,37 +224,57 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         FD_LAUNCH((fd_bn_bwd_apply_h16<T>), dim3((unsigned)std::min<long>(4096, ceil_div(chunks, 256))), dim3(256), 0, c.s, Gsrc, G, twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), chunks, N);
         if ((rc = check_launch("fd_bn_bwd_apply_h16"))) return rc;
     }
+    // weight gradient: output tiles x pixel splits
+    const int n_tiles = ceil_div(N, 64), k_tiles_w = ceil_div(K, 64);
+    int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_H16, (long)n_tiles * k_tiles_w), ceil_div(M, 256)));
+    const int rows = ceil_div(ceil_div(M, splits), 64) * 64;
+    splits = ceil_div(M, rows);
+    if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
+    // backward data: 64 x 128 tiles of G_in when there are >= 128 input channels and that still leaves >= 200 workgroups: every dz fragment feeds two MFMAs
+    const bool pair = !(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING)) && !c.p->concurrent_wgrad;
+    int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
+    if (pair && (c.p->flags & FD_PLAN_TUNE_PW_PAIR_TN1)) tn = 1;
+    const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
+    const size_t lds_d = (size_t)3 * (64 + 64 * tn) * 128 + (size_t)4 * 64 * tn * 4;
+    const bool add = P.skip_consumer >= 0;
+    const unsigned n_dgrad = (unsigned)((m_tiles + 7) / 8 * 8 * k_tiles);
+    *nblk = m_tiles;
+    if (pair) {
+        const size_t lds = std::max(lds_d, FD_PW_WGRAD_H16_LDS(1));
+        const int tiles_w = n_tiles * k_tiles_w;
+#define FD_PWBWD_H16(ADDV, TNV)                                                                                                                    \
+    do {                                                                                                                                           \
+        (void)hipFuncSetAttribute((const void *)fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+        FD_LAUNCH((fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>), dim3(n_dgrad + (unsigned)(tiles_w * splits)), dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), \
+                  tws(c.p, P.st_off), ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), tws(c.p, L.wp_off), M, N, K, L.n64, \
+                  m_tiles, k_tiles, (int)n_dgrad, k_tiles_w, tiles_w, rows);                                                                       \
+    } while (0)
+        if (add) { if (tn == 2) FD_PWBWD_H16(1, 2); else FD_PWBWD_H16(1, 1); }
+        else { if (tn == 2) FD_PWBWD_H16(0, 2); else FD_PWBWD_H16(0, 1); }
+#undef FD_PWBWD_H16
+        if ((rc = check_launch("fd_pw_bwd_h16"))) return rc;
+        return defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
+    }
     {
-        const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
-        int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_H16, (long)n_tiles * k_tiles), ceil_div(M, 256)));
-        int rows = ceil_div(ceil_div(M, splits), 64) * 64;
-        splits = ceil_div(M, rows);
-        if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
         if ((rc = fork_side(c))) return rc;
         // (two k tiles per workgroup -- fd_pw_wgrad_h16<.., 2>, the staged dz tile feeding twice the MFMAs -- measured slower: 22.3 vs 20.9 us on the
         // 512 x 512 units, 3 instead of 5 workgroups per CU and half as many of them)
-        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN, 1>), dim3(n_tiles * k_tiles, splits), dim3(256), 0, c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
-                  tws(c.p, L.wp_off), M, N, K, k_tiles, rows);
+        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN, 1>), dim3(n_tiles * k_tiles_w, splits), dim3(256), FD_PW_WGRAD_H16_LDS(1), c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+                  tws(c.p, L.wp_off), M, N, K, k_tiles_w, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
         if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
     }
     {
-        // 64 x 128 tiles of G_in when there are >= 128 input channels and that still leaves >= 200 workgroups: every dz fragment feeds two MFMAs
-        const int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
-        const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
-        const size_t lds = (size_t)3 * (64 + 64 * tn) * 128 + (size_t)4 * 64 * tn * 4;
-        const bool add = P.skip_consumer >= 0;
-        dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * k_tiles));
+        dim3 grid(n_dgrad);
 #define FD_DGRAD_H16(ADDV, TNV)                                                                                                                    \
     do {                                                                                                                                           \
-        (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>), grid, dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off), \
+        (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);    \
+        FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>), grid, dim3(256), lds_d, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off), \
                   ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);          \
     } while (0)
         if (add) { if (tn == 2) FD_DGRAD_H16(1, 2); else FD_DGRAD_H16(1, 1); }
         else { if (tn == 2) FD_DGRAD_H16(0, 2); else FD_DGRAD_H16(0, 1); }
 #undef FD_DGRAD_H16
-        *nblk = m_tiles;
         return check_launch("fd_pw_dgrad_h16");
     }
 }
@@ -266,39 +286,54 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     TLayer &P = c.p->layers[L.d.src];
     const int M = (int)L.M, N = L.d.cout, K = L.d.cin;
     const float *G = tws(c.p, L.g_off), *Z = tws(c.p, L.z_off), *coef = tws(c.p, L.coef_off);
-    // --- weights: dW[N][K], reduction over M split across workgroups
+    // weights: dW[N][K], reduction over M split across workgroups;  data: G_src[M][K], 64 x 64 tiles (both kernels tile K by 64)
+    const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64), m_tiles = ceil_div(M, 64);
+    int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_F32, (long)n_tiles * k_tiles), ceil_div(M, 256)));
+    const int rows = ceil_div(ceil_div(M, splits), 64) * 64;
+    splits = ceil_div(M, rows);
+    if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
+    const size_t lds_w = (size_t)FD_BWD_STAGES * 3 * 32 * 64 * 4;
+    const int N32 = (N + 31) / 32 * 32;
+    const size_t lds_d = ((size_t)FD_BWD_STAGES * (2 * 64 * 32 + 32 * 64) + 4 * N32 + 256) * 4;
+    const bool add = P.skip_consumer >= 0;
+    const unsigned n_dgrad = (unsigned)((m_tiles + 7) / 8 * 8 * k_tiles);
+    *nblk = m_tiles;
+    int rc;
+    if (!(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING)) && !c.p->concurrent_wgrad) {
+        const size_t lds = std::max(lds_w, lds_d);
+        const int tiles_w = n_tiles * k_tiles;
+        const dim3 grid(n_dgrad + (unsigned)(tiles_w * splits));
+        if (add) {
+            (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 1>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), tws(c.p, c.p->part_off), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+        } else {
+            (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 0>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
+                      (const float *)nullptr, tws(c.p, P.g_off), tws(c.p, c.p->part_off), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+        }
+        if ((rc = check_launch("fd_pw_bwd_f32"))) return rc;
+        return defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
+    }
     {
-        const int n_tiles = ceil_div(N, 64), k_tiles = ceil_div(K, 64);
-        int splits = std::max(1, std::min(ceil_div(FD_WGRAD_TARGET_WGS_F32, (long)n_tiles * k_tiles), ceil_div(M, 256)));
-        int rows = ceil_div(ceil_div(M, splits), 64) * 64;
-        splits = ceil_div(M, rows);
-        if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
-        const size_t lds = (size_t)FD_BWD_STAGES * 3 * 32 * 64 * 4;
-        (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
         { int frc = fork_side(c); if (frc) return frc; }
-        FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds, c.ws, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
+        FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds_w, c.ws, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, L.wp_off), M, N, K, k_tiles, rows);
-        int rc = check_launch("fd_pw_wgrad_f32");
-        if (rc) return rc;
+        if ((rc = check_launch("fd_pw_wgrad_f32"))) return rc;
         if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
     }
-    // --- data: G_src[M][K]
     {
-        const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64);
-        const int N32 = (N + 31) / 32 * 32;
-        const size_t lds = ((size_t)FD_BWD_STAGES * (2 * 64 * 32 + 32 * 64) + 4 * N32 + 256) * 4;
-        const bool add = P.skip_consumer >= 0;
-        dim3 grid((unsigned)((m_tiles + 7) / 8 * 8 * k_tiles));
+        dim3 grid(n_dgrad);
         if (add) {
-            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 1>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
+            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+            FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 1>), grid, dim3(256), lds_d, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
                       tws(c.p, P.sg_off), tws(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, m_tiles, k_tiles);
         } else {
-            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 0>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
+            (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+            FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 0>), grid, dim3(256), lds_d, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
                       (const float *)nullptr, tws(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, m_tiles, k_tiles);
         }
-        *nblk = m_tiles;
         return check_launch("fd_pw_dgrad_f32");
     }
 }

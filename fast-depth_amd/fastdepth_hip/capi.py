@@ -30,6 +30,8 @@ FD_PLAN_NO_EPILOGUE_FUSION = 512
 FD_PLAN_NO_UNIT_FUSION = 1024
 FD_PLAN_FORCE_UNIT_FUSION = 2048
 FD_PLAN_NO_BWD_PAIRING = 4096
+FD_PLAN_TUNE_NO_PW_PAIRING = 65536
+FD_PLAN_TUNE_PW_PAIR_TN1 = 131072
 
 
 class LayerDesc(ctypes.Structure):

@@ -40,12 +40,14 @@ class _device_guard:
 
 
 class _TrainPlan:
+    default_flags = 0           # extra fd_train_plan_create flags for every plan (A/B aid of tools/*.py, e.g. capi.FD_PLAN_NO_BWD_PAIRING); set in code
+
     def __init__(self, layers, batch, height, width, device, dtype=torch.float32, L=None):
         self.L = L = L or lib()
         n = len(layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in layers])
         handle = ctypes.c_void_p()
-        capi.check(L, L.fd_train_plan_create(descs, n, batch, height, width, capi.DTYPE_OF[dtype], 0, ctypes.byref(handle)), "fd_train_plan_create")
+        capi.check(L, L.fd_train_plan_create(descs, n, batch, height, width, capi.DTYPE_OF[dtype], _TrainPlan.default_flags, ctypes.byref(handle)), "fd_train_plan_create")
         self.handle = handle
         nbytes = L.fd_train_plan_workspace_bytes(handle)
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)

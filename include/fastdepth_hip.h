@@ -59,6 +59,8 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_NO_UNIT_FUSION 1024u   /* never run a depthwise + pointwise unit of a large map as one kernel (fd_dwpw_f32): A/B measurements, tests of the unfused kernels */
 #define FD_PLAN_FORCE_UNIT_FUSION 2048u /* fd_dwpw_f32 for every eligible depthwise + pointwise pair whatever the map size: lets small test shapes exercise that kernel */
 #define FD_PLAN_NO_BWD_PAIRING 4096u   /* train plans: launch a unit's backward-data and backward-weights kernels one after the other instead of as one paired launch (A/B measurements, tests of the separate kernels) */
+#define FD_PLAN_TUNE_NO_PW_PAIRING 65536u  /* tuning aid (train plans): pair only the depthwise units' backward kernels, not the pointwise GEMMs */
+#define FD_PLAN_TUNE_PW_PAIR_TN1 131072u   /* tuning aid (16-bit train plans): the paired pointwise backward launch uses 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
 /* The three flags below select experiments that were measured no faster than the default path; they exist only in
  * libraries built with -DFD_EXPERIMENTS (the emulator test build), the product library rejects them. */
