@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=10, help="instrumented steps for the per-kernel roofline")
     ap.add_argument("--extra-steps", type=int, default=30, help="timed steps for each entry of `other_configs`; 0 disables")
     ap.add_argument("--train-steps", type=int, default=20, help="timed train steps per plan (`train_step`, `train_step_bf16`); 0 disables")
+    ap.add_argument("--grad-exchange", default="f32", choices=["f32", "bf16"], help="dtype of the data-parallel gradient all-reduce (bf16: 7.92 MB instead of 15.84 MB)")
     ap.add_argument("--only", default="", choices=["", "infer", "train_f32", "train_bf16", "f16", "bf16", "pruned_f16"],
                     help="run ONE configuration's timed loop and nothing else (one rocprofv3 invocation per configuration: tools/gpu_round.sh)")
     return ap.parse_args()
@@ -92,13 +93,43 @@ def layerwise_bound_ms(stats, mfma_peak_tflops):
     """sum over layers of max(bytes / HBM, flops / MFMA): the roofline that bounds the step.  The pointwise GEMMs are
     priced against `mfma_peak_tflops`, everything else (VALU work) against the fp32 vector peak, which equals the fp32 MFMA peak."""
     t = 0.0
-    for name, sym, info, nbytes, flops in stats:
+    for st in stats:
+        name, sym, info, nbytes, flops = st[:5]
         peak = mfma_peak_tflops if "pw_gemm" in sym else MFMA_F32_PEAK_TFLOPS
         t += max(nbytes / (HBM_PEAK_GBS * 1e9), flops / (peak * 1e12))
     return t * 1e3
 
 
-def roofline_of(entry, sym, mfma_peak_tflops, total_ms):
+def fused_plan_bound_ms(stats, mfma_peak_tflops):
+    """The same sum over the plan's LAUNCHES, each priced with the bytes it actually has to move (fd_plan_layer_traffic: a fused launch
+    keeps its intermediate tensors on chip) and all the flops it performs: the bound of the plan as built, without credit for bytes that
+    fusion removed.  Launches with a pointwise GEMM inside are priced against the MFMA peak (their depthwise part is a few percent of the flops)."""
+    t = 0.0
+    for name, sym, info, nbytes, flops, needed in stats:
+        if not sym:
+            continue
+        peak = mfma_peak_tflops if ("pw_gemm" in sym or "dwpw" in sym) else MFMA_F32_PEAK_TFLOPS
+        t += max(needed / (HBM_PEAK_GBS * 1e9), flops / (peak * 1e12))
+    return t * 1e3
+
+
+_PMC = None
+
+
+def pmc_traffic(cfg, name):
+    """Per-launch HBM bytes of a kernel symbol (inference configurations) or kernel family (train steps) from the committed rocprofv3 --pmc
+    summary profiles/pmc_traffic.json ({configuration: {kernel: {"bytes_per_launch", "launches_per_step"}}}, written by tools/archive_round.py)."""
+    global _PMC
+    if _PMC is None:
+        try:
+            _PMC = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        except Exception:
+            _PMC = {}
+    e = (_PMC.get(cfg) or {}).get(name)
+    return e
+
+
+def roofline_of(entry, sym, mfma_peak_tflops, total_ms, cfg="infer"):
     """entry: {"launches", "ms", "bytes", "flops"} summed over the launches of one kernel symbol / family in ONE step."""
     t_s = entry["ms"] / 1e3
     hbm_time, mfma_time = entry["bytes"] / (HBM_PEAK_GBS * 1e9), entry["flops"] / (mfma_peak_tflops * 1e12)
@@ -107,42 +138,51 @@ def roofline_of(entry, sym, mfma_peak_tflops, total_ms):
     else:
         roof = {"bound": "hbm", "achieved": round(entry["bytes"] / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    roof["traffic"] = None
-    traffic_file = os.path.join(REPO, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from rocprofv3 --pmc passes, if collected
-    if os.path.exists(traffic_file):
-        try:
-            roof["traffic"] = json.load(open(traffic_file)).get(sym)
-        except Exception:
-            pass
+    e = pmc_traffic(cfg, sym)                                # per-launch HBM bytes from the rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE), if collected
+    roof["traffic"] = round(e["bytes_per_launch"], 1) if e else None
     roof.update({"kernel": sym, "launches_per_step": entry["launches"], "avg_launch_us": round(entry["ms"] * 1e3 / entry["launches"], 2),
                  "share_of_device_time": round(entry["ms"] / total_ms, 4),
                  "algorithmic_per_launch": {"bytes": entry["bytes"] / entry["launches"], "flops": entry["flops"] / entry["launches"]}})
     return roof
 
 
-def inference_profile(eng, x, steps, mfma_peak_tflops):
-    """Per-kernel device time of the inference forward (HIP events on the launch stream, fd_forward_timed), aggregated by kernel symbol."""
+def inference_profile(eng, x, steps, mfma_peak_tflops, cfg="infer"):
+    """Per-kernel device time of the inference forward (HIP events on the launch stream, fd_forward_timed), aggregated by kernel symbol.
+    Per kernel: `GBps` = the bytes its launches have to move (fd_plan_layer_traffic) / time; `GBps_unfused_units` = the SURVEY 8(d) bytes of
+    the reference units a launch replaces / time (what `roofline.achieved` uses for HBM-bound kernels: the per-unit convention)."""
     import numpy as np
-    stats = eng.layer_stats(x)
+    stats = eng.layer_stats(x, traffic=True)
     acc = np.zeros(len(stats))
     for _ in range(max(steps, 1)):
         _, ms = eng.forward_timed(x)
         acc += np.array(ms)
     acc /= max(steps, 1)
     by_sym = {}
-    for (name, sym, info, nbytes, flops), ms in zip(stats, acc):
+    for (name, sym, info, nbytes, flops, needed), ms in zip(stats, acc):
         if not sym:                  # a depthwise layer evaluated in its producer's epilogue: no launch of its own (its algorithmic work is
             continue                 # credited to the producer's launch by fd_plan_layer_stats)
-        e = by_sym.setdefault(sym, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
-        e["launches"] += 1; e["ms"] += float(ms); e["bytes"] += nbytes; e["flops"] += flops
+        e = by_sym.setdefault(sym, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0, "needed": 0.0})
+        e["launches"] += 1; e["ms"] += float(ms); e["bytes"] += nbytes; e["flops"] += flops; e["needed"] += needed
     total_ms = float(acc.sum())
     dom_sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-    kernels = [{"kernel": s, "launches": e["launches"], "ms_per_step": round(e["ms"], 4),
-                "GBps": round(e["bytes"] / (e["ms"] / 1e3) / 1e9, 1), "TFLOPs": round(e["flops"] / (e["ms"] / 1e3) / 1e12, 2)}
-               for s, e in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])]
+    kernels = []
+    for s, e in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"]):
+        k = {"kernel": s, "launches": e["launches"], "ms_per_step": round(e["ms"], 4), "GBps": round(e["needed"] / (e["ms"] / 1e3) / 1e9, 1),
+             "GBps_unfused_units": round(e["bytes"] / (e["ms"] / 1e3) / 1e9, 1), "TFLOPs": round(e["flops"] / (e["ms"] / 1e3) / 1e12, 2)}
+        t = pmc_traffic(cfg, s)
+        if t:
+            k["GBps_pmc"] = round(t["bytes_per_launch"] * e["launches"] / (e["ms"] / 1e3) / 1e9, 1)
+        kernels.append(k)
     whole = {"algorithmic_GB": round(sum(s[3] for s in stats) / 1e9, 4), "algorithmic_GFLOP": round(sum(s[4] for s in stats) / 1e9, 3),
-             "device_ms_sum_of_kernels": round(total_ms, 4), "roofline_bound_ms": round(layerwise_bound_ms(stats, mfma_peak_tflops), 4)}
-    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms), whole, kernels, sum(1 for st in stats if st[1])
+             "needed_GB_fused_plan": round(sum(s[5] for s in stats) / 1e9, 4),
+             "device_ms_sum_of_kernels": round(total_ms, 4), "roofline_bound_ms": round(layerwise_bound_ms(stats, mfma_peak_tflops), 4),
+             "fused_plan_bound_ms": round(fused_plan_bound_ms(stats, mfma_peak_tflops), 4)}
+    pm = [pmc_traffic(cfg, s) for s in by_sym]
+    if all(pm):
+        whole["pmc_traffic_GB"] = round(sum(t["bytes_per_launch"] * e["launches"] for t, e in zip(pm, by_sym.values())) / 1e9, 4)
+    roof = roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms, cfg)
+    roof["needed_bytes_per_launch"] = dom["needed"] / dom["launches"]
+    return roof, whole, kernels, sum(1 for st in stats if st[1])
 
 
 # kernel families of the train step whose launches move a unit's activations once (SURVEY.md 8(d): fwd 1x + bwd 2x the inference bytes);
@@ -151,7 +191,7 @@ _TRAIN_MAJOR = ("gemm_train", "dwconv_train", "stem_train", "head_train", "dgrad
 _TRAIN_PAIRED = ("head_bwd<", "fd_dw_bwd<", "fd_pw_bwd_")       # one launch = a unit's backward-data AND backward-weights pass
 
 
-def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes):
+def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes, cfg="train_bf16"):
     """Per-kernel-family device time of the fused train step (fd_trace: HIP events around every launch), with the algorithmic bytes /
     flops of the unit each launch belongs to."""
     import ctypes
@@ -190,7 +230,18 @@ def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes):
     whole = {"algorithmic_GB": round(alg_bytes / 1e9, 4), "algorithmic_GFLOP": round(alg_flops / 1e9, 3), "device_ms_sum_of_kernels": round(total_ms, 4),
              "launches_per_step": round(sum(e["launches"] for e in fam.values()), 1),
              "roofline_bound_ms": round(3.0 * layerwise_bound_ms(stats, mfma_peak_tflops) + 5.0 * param_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
-    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms), whole, kernels
+    pm = {f: pmc_traffic(cfg, f) for f in fam}
+    if any(pm.values()):                                    # counter traffic of the whole step (families without a PMC record are small: listed)
+        whole["pmc_traffic_GB"] = round(sum(t["bytes_per_launch"] * fam[f]["launches"] for f, t in pm.items() if t) / 1e9, 4)
+        whole["pmc_traffic_over_algorithmic"] = round(whole["pmc_traffic_GB"] / whole["algorithmic_GB"], 3)
+        missing = [f for f, t in pm.items() if not t]
+        if missing:
+            whole["families_without_pmc_record"] = missing
+        for k in kernels:
+            t = pm.get(k["kernel"])
+            if t:
+                k["GBps_pmc"] = round(t["bytes_per_launch"] * fam[k["kernel"]]["launches"] / (fam[k["kernel"]]["ms"] / 1e3) / 1e9, 1)
+    return roofline_of(dom, dom_sym, mfma_peak_tflops, total_ms, cfg), whole, kernels
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
@@ -203,6 +254,7 @@ def cpu_baseline(budget_s):
     t_start = time.time()
     kind, module, fwd = "port", None, None
     if os.path.isdir(REFERENCE):
+        sys.dont_write_bytecode = True                 # importing the reference must not leave __pycache__ in its (read-only) tree
         # the reference's own packages are called `models` / `imagenet` like the product's drop-ins: swap them in sys.modules for the
         # duration of the import only (the reference's module objects stay alive through `module`)
         names = ("torchvision", "torchvision.models", "models", "imagenet", "imagenet.mobilenet")
@@ -226,6 +278,35 @@ def cpu_baseline(budget_s):
                 sys.modules.pop(k, None)
                 if saved[k] is not None:
                     sys.modules[k] = saved[k]
+    traced = None
+    if module is None:
+        # the GPU boxes have no /root/reference: replay the TorchScript traces of the reference's own module that oracle/make_ref_trace.py
+        # made where the reference is present (oracle/_ref/, git-ignored, travels with the snapshot) -- the reference's operator graph on
+        # the same ATen CPU kernels, eager == traced bit for bit at trace time
+        ev_p, tr_p = (os.path.join(REPO, "oracle", "_ref", "reference_module_%s.pt" % k) for k in ("eval", "train"))
+        if os.path.exists(ev_p) and os.path.exists(tr_p):
+            try:
+                traced = (torch.jit.load(ev_p), torch.jit.load(tr_p))
+                kind = "reference"
+            except Exception:
+                traced = None
+    if traced is not None:
+        class Traced:                                      # the two traces behind the small part of nn.Module's surface the timing loops use
+            def __init__(self):
+                self.cur = traced[0]
+
+            def eval(self):
+                self.cur = traced[0]
+
+            def train(self):
+                self.cur = traced[1]
+
+            def parameters(self):
+                return traced[1].parameters()
+
+            def __call__(self, x):
+                return self.cur(x)
+        module = Traced()
     if module is None:
         from oracle import torch_ref
         import models
@@ -289,7 +370,8 @@ def cpu_baseline(budget_s):
     best = max(rows, key=lambda r: r["fps"])
     b32 = max([r for r in rows if r["batch"] == 32] or [best], key=lambda r: r["fps"])
     b1 = max([r for r in rows if r["batch"] == 1] or [best], key=lambda r: r["fps"])
-    what = ("/root/reference models.MobileNetSkipAdd, unmodified (torchvision stub only)" if kind == "reference"
+    what = ("TorchScript trace of /root/reference's models.MobileNetSkipAdd (oracle/make_ref_trace.py: the reference's own operator graph, eager == traced bit for bit)" if traced is not None
+            else "/root/reference models.MobileNetSkipAdd, unmodified (torchvision stub only)" if kind == "reference"
             else "oracle/torch_ref.py (the ATen CPU conv / batch_norm / hardtanh / upsample / add kernels the reference dispatches to)")
     return {"value": best["fps"], "unit": "frames/s", "cores": threads, "kind": kind,
             "sample": "%s, fp32 eval + no_grad on %d of %d host threads: best of B in {1, 8, 32} x {contiguous, channels_last}, 2 warm-ups + median of "
@@ -393,7 +475,7 @@ def main():
         tm.decode_conv6[1].bias.data.fill_(2.8)
         tm = tm.to(dev).train()
         return TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
-                           force_buckets=force_dist, dtype=dtype)
+                           force_buckets=force_dist, dtype=dtype, grad_exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32)
 
     gt = torch.Generator().manual_seed(1)
     tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=gt)).to(dev)     # synthetic depth, U[0.7, 10) m
@@ -414,7 +496,7 @@ def main():
         res = {"metric": "frames/sec (224x224) train step: fwd + L1 loss + bwd + gradient all-reduce + SGD(momentum, wd)",
                "value": round(world * args.batch * steps / t_el, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": 3,
                "ms_per_step": round(t_el / steps * 1e3, 4), "dtype": tag, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
-               "parallelism": ("dp%d: RCCL all-reduce of the 15.84 MB fp32 gradient vector in %d buckets on a side stream, overlapped with backward" % (world, len(teng.buckets)))
+               "parallelism": ("dp%d: RCCL all-reduce of the %s gradient vector in %d buckets (cut by finish time) on a side stream, overlapped with backward" % (world, "7.92 MB bf16" if args.grad_exchange == "bf16" else "15.84 MB fp32", len(teng.buckets)))
                               if teng.use_comm else "single GPU"}
         if teng.use_comm:        # how long the collectives take and how much of them backward hides (3 instrumented steps, synchronising)
             cs = []
@@ -429,7 +511,7 @@ def main():
             stats = eng.layer_stats(x)                      # algorithmic bytes / flops per unit at this storage type
             eng.set_dtype(torch.float32)
             peak = MFMA_F32_PEAK_TFLOPS if dtype == torch.float32 else MFMA_H16_PEAK_TFLOPS
-            roof, whole, kernels = train_profile(teng, x, tgt, stats, 3, peak, 4.0 * teng.total)
+            roof, whole, kernels = train_profile(teng, x, tgt, stats, 3, peak, 4.0 * teng.total, "train_f32" if dtype == torch.float32 else "train_bf16")
             res["roofline"], res["whole_step"], res["kernels"] = roof, whole, kernels[:12]
             res["whole_step"]["frac_of_roofline"] = round(whole["roofline_bound_ms"] / res["ms_per_step"], 4)
         return res
@@ -463,6 +545,7 @@ def main():
     roof, whole, kernels, n_kernels = inference_profile(eng, x, args.profile_steps, MFMA_F32_PEAK_TFLOPS)
     ms_per_step = elapsed / args.steps * 1e3
     whole["frac_of_roofline"] = round(whole["roofline_bound_ms"] / ms_per_step, 4)
+    whole["frac_of_fused_plan_bound"] = round(whole["fused_plan_bound_ms"] / ms_per_step, 4)
 
     # ---- the train step (BASELINE.json metric: "fwd + train-step"): fp32 plan and bf16 plan (configs[2]; configs[3] at N = 8) ---------
     train, train_bf16 = None, None
@@ -481,16 +564,18 @@ def main():
         x64 = torch.rand(64, 3, 224, 224, generator=g).to(dev)
         pm.set_compute_dtype(torch.float16)
         dt = time_forward(pm, x64, args.extra_steps, 5) / args.extra_steps
-        r64, w64, _, _ = inference_profile(pm._engine(), x64, 3, MFMA_H16_PEAK_TFLOPS)
+        r64, w64, _, _ = inference_profile(pm._engine(), x64, 3, MFMA_H16_PEAK_TFLOPS, "pruned_f16")
         w64["frac_of_roofline"] = round(w64["roofline_bound_ms"] / (dt * 1e3), 4)
+        w64["frac_of_fused_plan_bound"] = round(w64["fused_plan_bound_ms"] / (dt * 1e3), 4)
         extras.append({"config": "configs[4]: pruned plan (mobilenet-nnconv5dw-skipadd-pruned), batch=64, fp16 storage / fp32 accumulate, inference",
                        "value": round(64 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f16", "roofline": r64, "whole_step": w64})
         del pm
         for dtype, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
             model.set_compute_dtype(dtype)
             dt = time_forward(model, x, args.extra_steps, 5) / args.extra_steps
-            r16, w16, _, _ = inference_profile(eng, x, 3, MFMA_H16_PEAK_TFLOPS)
+            r16, w16, _, _ = inference_profile(eng, x, 3, MFMA_H16_PEAK_TFLOPS, tag)
             w16["frac_of_roofline"] = round(w16["roofline_bound_ms"] / (dt * 1e3), 4)
+            w16["frac_of_fused_plan_bound"] = round(w16["fused_plan_bound_ms"] / (dt * 1e3), 4)
             extras.append({"config": "unpruned, batch=32, %s storage / fp32 accumulate, inference" % tag, "value": round(args.batch / dt, 1),
                            "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": tag, "roofline": r16, "whole_step": w16})
         model.set_compute_dtype(torch.float32)

@@ -1168,6 +1168,26 @@ int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_
     return FD_OK;
 }
 
+int fd_plan_layer_traffic(const fd_plan *plan, int32_t layer, double *needed_bytes)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size() || !needed_bytes) return fail(FD_ERR_INVALID, "bad layer index / null output");
+    // what the launch of this layer must move: the stored inputs it reads + the outputs it writes + its weights.  An intermediate tensor that a
+    // fused launch keeps on chip (the pointwise output consumed by a depthwise epilogue, the depthwise output inside fd_dwpw_f32, decode_conv5's
+    // output under the head) is neither written nor read: both passes of it leave the sum of the units' algorithmic bytes.
+    const Layer &L = plan->layers[layer];
+    const double esz = plan->dtype == FD_F32 ? 4.0 : 2.0;
+    auto out_b = [&](const Layer &X) { return (double)plan->B * X.out_h * X.out_w * X.d.cout * (X.to_output ? 4.0 : esz); };
+    double b = (L.skipped || L.fused_into >= 0) ? 0.0 : L.alg_bytes;
+    if (L.fused_dw >= 0) { const Layer &D = plan->layers[L.fused_dw]; b += D.alg_bytes - 2.0 * out_b(D); }
+    if (L.fuse_next_dw >= 0) {
+        const Layer &D = plan->layers[L.fuse_next_dw];
+        b += D.alg_bytes - ((plan->flags & FD_PLAN_KEEP_ACTIVATIONS) ? 1.0 : 2.0) * out_b(L);     // (KEEP_ACTIVATIONS plans still store the pointwise output)
+    }
+    if (L.fuse_head >= 0) { const Layer &H = plan->layers[L.fuse_head]; b += H.alg_bytes - 2.0 * out_b(L); }
+    *needed_bytes = b;
+    return FD_OK;
+}
+
 }  // extern "C"
 
 #include "fd_train_impl.h"

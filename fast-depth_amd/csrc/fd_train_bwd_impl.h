@@ -233,7 +233,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     // backward data: 64 x 128 tiles of G_in when there are >= 128 input channels and that still leaves >= 200 workgroups: every dz fragment feeds two MFMAs
     const bool pair = !(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING)) && !c.p->concurrent_wgrad;
     int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
-    if (pair && (c.p->flags & FD_PLAN_TUNE_PW_PAIR_TN1)) tn = 1;
+    if (pair && !(c.p->flags & FD_PLAN_TUNE_PW_PAIR_TN2)) tn = 1;   // paired launch: 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74: the weight-gradient workgroups share it) -- measured 554 vs 583 us per bf16 step
     const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
     const size_t lds_d = (size_t)3 * (64 + 64 * tn) * 128 + (size_t)4 * 64 * tn * 4;
     const bool add = P.skip_consumer >= 0;
@@ -460,6 +460,18 @@ int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t 
     FD_LAUNCH(fd_val_transform_u8, dim3((unsigned)std::min<long>(4096, ceil_div(total, 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
               static_cast<const unsigned char *>(rgb_u8), depth, ymap_device, xmap_device, x_out, depth_out, n, height, width, out_h, out_w);
     return check_launch("fd_val_transform_u8");
+}
+
+int fd_cast_gradients(const void *src, void *dst, int64_t numel, int32_t to_bf16, void *stream)
+{
+    if (!src || !dst || numel <= 0) return fail(FD_ERR_INVALID, "fd_cast_gradients: null/empty argument");
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;       // 16-byte fp32 side / 8-byte bf16 side accesses
+    const long n4 = al ? (long)(numel >> 2) : 0;
+    const unsigned nb = (unsigned)std::min<long>(2048, ceil_div((long)std::max<int64_t>(numel / 4, 1), 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (to_bf16) FD_LAUNCH(fd_cast_f32_bf16, dim3(nb), dim3(256), 0, s, static_cast<const float *>(src), static_cast<fd_bf16 *>(dst), n4, (long)numel);
+    else FD_LAUNCH(fd_cast_bf16_f32, dim3(nb), dim3(256), 0, s, static_cast<const fd_bf16 *>(src), static_cast<float *>(dst), n4, (long)numel);
+    return check_launch("fd_cast_gradients");
 }
 
 size_t fd_depth_metrics_scratch_bytes(void) { return (size_t)1024 * 10 * sizeof(double); }

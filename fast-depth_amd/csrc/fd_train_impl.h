@@ -295,7 +295,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);
             L.mode = d.upsample ? (d.skip >= 0 ? (concat ? 3 : 2) : 1) : 0;
             L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
-            const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
+            const int cb_max = (flags & FD_PLAN_TUNE_DW_CB16) ? 16 : 32;
+            const int cb = d.cin >= cb_max ? cb_max : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);
             L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : 16);
             L.th = std::min(L.out_h, 8);

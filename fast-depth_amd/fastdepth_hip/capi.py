@@ -31,7 +31,8 @@ FD_PLAN_NO_UNIT_FUSION = 1024
 FD_PLAN_FORCE_UNIT_FUSION = 2048
 FD_PLAN_NO_BWD_PAIRING = 4096
 FD_PLAN_TUNE_NO_PW_PAIRING = 65536
-FD_PLAN_TUNE_PW_PAIR_TN1 = 131072
+FD_PLAN_TUNE_PW_PAIR_TN2 = 131072
+FD_PLAN_TUNE_DW_CB16 = 262144
 
 
 class LayerDesc(ctypes.Structure):
@@ -95,6 +96,8 @@ def load(path=None):
     lib.fd_plan_algorithmic_flops.restype = ctypes.c_double
     lib.fd_plan_layer_stats.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.fd_plan_layer_stats.restype = ctypes.c_int
+    lib.fd_plan_layer_traffic.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
+    lib.fd_plan_layer_traffic.restype = ctypes.c_int
     if hasattr(lib, "fd_train_plan_create"):
         lib.fd_train_plan_create.argtypes = [ctypes.POINTER(LayerDesc), i32, i32, i32, i32, i32, u32, ctypes.POINTER(vp)]
         lib.fd_train_plan_create.restype = ctypes.c_int
@@ -121,6 +124,8 @@ def load(path=None):
         lib.fd_l1_loss_masked.restype = ctypes.c_int
         lib.fd_sgd_step.argtypes = [vp, i32, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i32, vp]
         lib.fd_sgd_step.restype = ctypes.c_int
+        lib.fd_cast_gradients.argtypes = [vp, vp, ctypes.c_int64, i32, vp]
+        lib.fd_cast_gradients.restype = ctypes.c_int
     lib.fd_val_transform.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.fd_val_transform.restype = ctypes.c_int
     lib.fd_depth_metrics_scratch_bytes.argtypes = []
@@ -152,10 +157,10 @@ def load(path=None):
 
 EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_plan_bind_workspace",
            "fd_plan_pack_weights", "fd_forward", "fd_forward_timed", "fd_layer_output", "fd_plan_num_kernels", "fd_plan_kernel_info", "fd_plan_kernel_symbol",
-           "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats",
+           "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats", "fd_plan_layer_traffic",
            "fd_train_plan_create", "fd_train_plan_destroy", "fd_train_plan_workspace_bytes", "fd_train_plan_bind_workspace",
            "fd_train_forward", "fd_train_backward", "fd_train_backward_range", "fd_train_layer_tensor", "fd_l1_loss_scratch_bytes",
-           "fd_l1_loss", "fd_l1_loss_masked", "fd_sgd_step", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
+           "fd_l1_loss", "fd_l1_loss_masked", "fd_sgd_step", "fd_cast_gradients", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
            "fd_depth_metrics_frames_scratch_bytes", "fd_depth_metrics_frames", "fd_plan_export_bytes", "fd_plan_export",
            "fd_plan_import", "fd_plan_import_weights", "fd_plan_shape", "fd_trace_begin", "fd_trace_end", "fd_last_error", "fd_version")
 

@@ -158,16 +158,20 @@ class Engine:
             capi.check(L, L.fd_forward_timed(plan.handle, x.data_ptr(), y.data_ptr(), stream, ms, n), "fd_forward_timed")
         return y, list(ms)
 
-    def layer_stats(self, x):
-        """[(layer name, kernel symbol, kernel info, algorithmic bytes, algorithmic flops)] for x's plan."""
+    def layer_stats(self, x, traffic=False):
+        """[(layer name, kernel symbol, kernel info, algorithmic bytes, algorithmic flops)] for x's plan; with traffic=True a sixth
+        field: the bytes the layer's launch has to move (a fused launch keeps its intermediate tensors on chip)."""
         L = lib()
         plan = self.plan_for(x)
         out = []
         for i, l in enumerate(self.layers):
-            b, f = ctypes.c_double(), ctypes.c_double()
+            b, f, nb = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             capi.check(L, L.fd_plan_layer_stats(plan.handle, i, ctypes.byref(b), ctypes.byref(f)), "fd_plan_layer_stats")
-            out.append((l.name, L.fd_plan_kernel_symbol(plan.handle, i).decode(), L.fd_plan_kernel_info(plan.handle, i).decode(),
-                        b.value, f.value))
+            row = (l.name, L.fd_plan_kernel_symbol(plan.handle, i).decode(), L.fd_plan_kernel_info(plan.handle, i).decode(), b.value, f.value)
+            if traffic:
+                capi.check(L, L.fd_plan_layer_traffic(plan.handle, i, ctypes.byref(nb)), "fd_plan_layer_traffic")
+                row += (nb.value,)
+            out.append(row)
         return out
 
     # ---- hipGraph replay, optionally with the batch split over several streams --------------------------------------------

@@ -247,6 +247,30 @@ def make_buckets(layer_bytes, n_buckets):
     return buckets
 
 
+def make_buckets_by_finish(layer_bytes, fractions=(0.9,)):
+    """Buckets chosen by WHEN their bytes are finished rather than by equal bytes.  Backward runs from the head down; in this network the
+    decoder and the early encoder layers take most of the TIME (large maps) and hold almost none of the gradient BYTES -- 86 % of them belong to
+    conv7..conv13 / decode_conv1 and are complete about half-way through backward.  One cut right after the layer at
+    which the cumulative bytes (in backward order) reach `fractions[0]` of the total puts the bulk of the exchange under the second half of
+    backward and leaves a small, latency-bound bucket for the end; every bucket costs a reduction launch, a stream hop and a collective
+    launch, so fewer is better (measured: 4 equal-byte buckets cost +0.30 ms per step before a byte crosses xGMI).
+    Returns [(from_layer, to_layer)] with from >= to."""
+    n = len(layer_bytes)
+    total = float(sum(layer_bytes))
+    cuts, acc, k = [], 0.0, 0
+    for i in range(n - 1, 0, -1):                          # a cut after layer i means the next bucket starts at i-1 (so i >= 1)
+        acc += layer_bytes[i]
+        if k < len(fractions) and acc >= fractions[k] * total:
+            cuts.append(i)
+            k += 1
+    buckets, start = [], n - 1
+    for c in cuts:
+        buckets.append((start, c))
+        start = c - 1
+    buckets.append((start, 0))
+    return buckets
+
+
 class TrainEngine(TrainCore):
     """Fused train step with SGD(momentum, weight decay) and optional data parallelism.
 
@@ -254,9 +278,15 @@ class TrainEngine(TrainCore):
     step is: local forward/backward on this rank's sub-batch; the flat gradient buffer is all-reduced (sum) bucket by bucket
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
-    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=4, force_buckets=False,
-                 dtype=torch.float32, masked_loss=False, _library=None):
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=None, force_buckets=False,
+                 dtype=torch.float32, masked_loss=False, grad_exchange_dtype=torch.float32, _library=None):
+        """n_buckets: None (default) = two buckets cut by finish time (make_buckets_by_finish); an integer = that many buckets of roughly
+        equal bytes (make_buckets).  grad_exchange_dtype: torch.float32 (default: the 15.84 MB fp32 vector is all-reduced in place) or
+        torch.bfloat16 (every bucket is converted to bfloat16, all-reduced as 7.92 MB, converted back: half the bytes over xGMI for one
+        rounding of every summand and of the sum)."""
         super().__init__(model, dtype, _library)
+        if grad_exchange_dtype not in (torch.float32, torch.bfloat16):
+            raise capi.FastDepthError("grad_exchange_dtype must be float32 or bfloat16")
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         # masked_loss: mean-L1 over the pixels with target > 0 only (the upstream train script's MaskedL1Loss, README.md:65) instead of
         # torch.nn.L1Loss over every pixel
@@ -276,15 +306,36 @@ class TrainEngine(TrainCore):
         self.sgd_table = torch.tensor(rec, dtype=torch.int64).to(self.device)
         self.layer_bytes = [4 * (self.layer_span[i][1] - self.layer_span[i][0]) for i in range(self.n)]
         self.use_comm = process_group is not None and (self.world > 1 or force_buckets)     # force_buckets: exercise the path on 1 rank
-        self.buckets = make_buckets(self.layer_bytes, n_buckets if self.use_comm else 1)
+        if not self.use_comm:
+            self.buckets = [(self.n - 1, 0)]
+        elif n_buckets is None:
+            self.buckets = make_buckets_by_finish(self.layer_bytes)
+        else:
+            self.buckets = make_buckets(self.layer_bytes, n_buckets)
+        self.exchange_dtype = grad_exchange_dtype
+        self.flat_grad16 = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) if (self.use_comm and grad_exchange_dtype == torch.bfloat16) else None
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_comm and self.device.type == "cuda") else None
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dpred = None
         self._scratch = torch.empty(self.L.fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
         self.last_comm_us = None                  # set by step(time_comm=True): device time of the all-reduces / of the whole step
 
-    def bucket_slice(self, from_layer, to_layer):
-        return self.flat_grad[self.layer_span[from_layer][0]:self.layer_span[to_layer][1]]
+    def bucket_slice(self, from_layer, to_layer, buf=None):
+        return (self.flat_grad if buf is None else buf)[self.layer_span[from_layer][0]:self.layer_span[to_layer][1]]
+
+    def _exchange(self, from_layer, to_layer, stream_ptr):
+        """The summing all-reduce of one finished bucket, issued on the CURRENT stream (the caller switched to the communication stream);
+        returns the work handle.  bfloat16 exchange: convert, all-reduce the 16-bit copy, convert back -- all in stream order."""
+        g32 = self.bucket_slice(from_layer, to_layer)
+        if self.flat_grad16 is None:
+            return self.dist.all_reduce(g32, group=self.group, async_op=True)
+        g16 = self.bucket_slice(from_layer, to_layer, self.flat_grad16)
+        L = self.L
+        capi.check(L, L.fd_cast_gradients(g32.data_ptr(), g16.data_ptr(), g32.numel(), 1, stream_ptr), "fd_cast_gradients")
+        w = self.dist.all_reduce(g16, group=self.group, async_op=True)
+        w.wait()                                   # stream-ordered on the GPU (no host sync); on the CPU (tests) it blocks
+        capi.check(L, L.fd_cast_gradients(g16.data_ptr(), g32.data_ptr(), g32.numel(), 0, stream_ptr), "fd_cast_gradients")
+        return w
 
     def step(self, x, target, time_comm=False):
         """One train step on this rank's (x, target); returns the local mean-L1 loss as a 1-element GPU tensor.
@@ -318,9 +369,9 @@ class TrainEngine(TrainCore):
                         with torch.cuda.stream(self.comm_stream):
                             if ev and bi == 0:
                                 ev["c0"].record(self.comm_stream)
-                            works.append(self.dist.all_reduce(self.bucket_slice(from_layer, to_layer), group=self.group, async_op=True))
+                            works.append(self._exchange(from_layer, to_layer, self.comm_stream.cuda_stream))
                     else:
-                        works.append(self.dist.all_reduce(self.bucket_slice(from_layer, to_layer), group=self.group, async_op=True))
+                        works.append(self._exchange(from_layer, to_layer, None))
             if ev:
                 ev["bwd1"].record(cur)
             if self.use_comm:

@@ -60,7 +60,8 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_FORCE_UNIT_FUSION 2048u /* fd_dwpw_f32 for every eligible depthwise + pointwise pair whatever the map size: lets small test shapes exercise that kernel */
 #define FD_PLAN_NO_BWD_PAIRING 4096u   /* train plans: launch a unit's backward-data and backward-weights kernels one after the other instead of as one paired launch (A/B measurements, tests of the separate kernels) */
 #define FD_PLAN_TUNE_NO_PW_PAIRING 65536u  /* tuning aid (train plans): pair only the depthwise units' backward kernels, not the pointwise GEMMs */
-#define FD_PLAN_TUNE_PW_PAIR_TN1 131072u   /* tuning aid (16-bit train plans): the paired pointwise backward launch uses 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74) */
+#define FD_PLAN_TUNE_PW_PAIR_TN2 131072u   /* tuning aid (16-bit train plans): the paired pointwise backward launch keeps the 64 x 128 backward-data tiles of the unpaired kernel (74 KB of LDS per workgroup instead of 49) */
+#define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
 /* The three flags below select experiments that were measured no faster than the default path; they exist only in
  * libraries built with -DFD_EXPERIMENTS (the emulator test build), the product library rejects them. */
@@ -160,6 +161,11 @@ double fd_plan_algorithmic_flops(const fd_plan *plan);
 /* The same two figures for one layer's kernel launch. */
 int fd_plan_layer_stats(const fd_plan *plan, int32_t layer, double *algorithmic_bytes, double *algorithmic_flops);
 
+/* HBM bytes the launch of fused layer `layer` has to move (stored inputs + outputs + weights): equals the algorithmic bytes of
+ * fd_plan_layer_stats for an unfused launch; a fused launch does not move the intermediate tensors it keeps on chip.  0 for a layer that
+ * runs inside another layer's launch.  (bench.py prices per-kernel bandwidth and the fused-plan roofline bound with it.) */
+int fd_plan_layer_traffic(const fd_plan *plan, int32_t layer, double *needed_bytes);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Train step (NOT in the reference tree -- README.md:65 names the upstream it was stripped from; defined in
  * SURVEY.md section 3(4) as: module in .train() -> L1 loss -> backward -> SGD(momentum, weight decay), data-parallel
@@ -225,6 +231,11 @@ int fd_l1_loss_masked(const void *pred, const void *target, void *dpred, float *
 typedef struct fd_sgd_tensor { float *param; const float *grad; float *momentum_buf; int64_t numel; } fd_sgd_tensor;
 int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t total_numel, float lr, float momentum,
                 float weight_decay, float grad_scale, int32_t first_step, void *stream);
+
+/* Data-parallel gradient exchange in 16 bits (optional; SURVEY.md 8(e): 7.92 MB instead of 15.84 MB over xGMI): converts `numel` values of
+ * a bucket of the flat gradient vector fp32 -> bfloat16 (to_bf16 != 0, round to nearest even) before the summing all-reduce, or bfloat16 ->
+ * fp32 after it.  The collective itself stays the host's (torch.distributed / RCCL), as for the fp32 exchange. */
+int fd_cast_gradients(const void *src, void *dst, int64_t numel, int32_t to_bf16, void *stream);
 
 /* Depth metrics (reference metrics.py:31-55 Result.evaluate): one fused reduction over output/target
  * (fp32, any shape, `numel` elements) producing the 10 sums from which every metric follows:

@@ -197,6 +197,73 @@ def test_train_engine_dp_world2_matches_shard_averaged_oracle(tmp_path):
     assert (num / den) ** 0.5 < 0.05, (num / den) ** 0.5
 
 
+def _engine_worker_bf16(rank, world, port, out):
+    """As _engine_worker, with the default buckets (two, cut by finish time) and the 16-bit gradient exchange."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import harness
+    from fastdepth_hip.train import TrainEngine
+    m, x, tgt = _dp_case()
+    m.train()
+    eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=dist.group.WORLD, grad_exchange_dtype=torch.bfloat16, _library=harness.get_lib("emu"))
+    assert eng.use_comm and len(eng.buckets) == 2 and eng.flat_grad16 is not None
+    per = x.shape[0] // world
+    loss = float(eng.step(x[rank * per:(rank + 1) * per], tgt[rank * per:(rank + 1) * per]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, {"after1": {k: v.clone() for k, v in m.state_dict().items()}, "grad": eng.flat_grad.clone(), "loss": loss})
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_train_engine_dp_world2_bf16_gradient_exchange(tmp_path):
+    """The optional 16-bit exchange (7.92 MB instead of 15.84 MB): every rank ends with the SAME gradient vector, equal to
+    bf16(bf16(g_0) + bf16(g_1)) of the two shards' local gradients (what a bfloat16 summing all-reduce of converted buckets yields),
+    i.e. within two roundings of the fp32 sum; the SGD step then applies half of it."""
+    import copy
+    import harness
+    from fastdepth_hip import capi
+    from fastdepth_hip.train import TrainEngine
+    out = str(tmp_path / "dp_bf16.pt")
+    mp.spawn(_engine_worker_bf16, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert torch.equal(r[0]["grad"], r[1]["grad"])
+    base, x, tgt = _dp_case()
+    for k, _ in base.named_parameters():
+        assert torch.equal(r[0]["after1"][k], r[1]["after1"][k]), k
+    L = harness.get_lib("emu")
+    local = []
+    for rank in range(2):
+        eng = TrainEngine(copy.deepcopy(base).train(), _library=L)
+        xs, ts = x[2 * rank:2 * rank + 2], tgt[2 * rank:2 * rank + 2]
+        pred = eng.forward(xs)
+        dpred, loss = torch.empty_like(pred), torch.zeros(1)
+        scratch = torch.empty(L.fd_l1_loss_scratch_bytes(pred.numel()), dtype=torch.uint8)
+        capi.check(L, L.fd_l1_loss(pred.data_ptr(), ts.contiguous().data_ptr(), dpred.data_ptr(), loss.data_ptr(), pred.numel(), scratch.data_ptr(), None), "fd_l1_loss")
+        eng.backward(dpred)
+        local.append(eng.flat_grad.clone())
+    want = (local[0].bfloat16() + local[1].bfloat16()).float()            # bf16 + bf16 -> bf16 (one rounding), as the collective computes it
+    assert torch.equal(r[0]["grad"], want)
+    exact = local[0] + local[1]
+    assert float((want - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())
+
+
+def test_make_buckets_by_finish_time():
+    from fastdepth_hip.train import make_buckets_by_finish
+    from oracle import inputs
+    models = inputs.product_models()
+    from fastdepth_hip.plan import layers_of
+    ls = layers_of(models.MobileNetSkipAdd((224, 224), pretrained=False))
+    nbytes = [4 * (l.conv.weight.numel() + 2 * l.bn.weight.numel()) for l in ls]
+    b = make_buckets_by_finish(nbytes)
+    assert len(b) == 2 and b[0][0] == 37 and b[-1][1] == 0 and b[0][1] == b[1][0] + 1
+    first = sum(nbytes[i] for i in range(b[0][1], 38))
+    assert 0.9 * sum(nbytes) <= first < 0.97 * sum(nbytes)                # the bulk goes first, a small latency-bound bucket is left for the end
+    assert ls[b[0][1]].name == "conv7.3"
+    assert make_buckets_by_finish([4, 4, 4], fractions=(0.3, 0.6)) == [(2, 2), (1, 1), (0, 0)]
+    assert make_buckets_by_finish([8], fractions=(0.5,)) == [(0, 0)]
+
+
 def test_make_buckets_covers_real_network():
     from fastdepth_hip.train import make_buckets
     from oracle import inputs

@@ -33,5 +33,24 @@ for d in glob.glob(os.path.join(src, "pmc_*")):
     w.writerow(["kernel", "counter", "launches", "mean_value_per_launch"])
     for (k, c), v in sorted(acc.items()):
         w.writerow([k, c, len(v), sum(v) / len(v)])
-s = json.load(open(os.path.join(src, "profile_summary.json")))
-json.dump({k: v for k, v in s["traffic_per_launch_bytes"].get("infer", {}).items() if k.startswith("fd_")}, open("profiles/pmc_traffic.json", "w"), indent=1)
+# profiles/pmc_traffic.json: per-launch HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE
+# reports half the bytes of wide coalesced reads) per configuration -- inference configurations keyed by kernel symbol, train steps keyed by
+# kernel FAMILY (the name before the template arguments: what bench.py's fd_trace aggregates by), launch-weighted.
+traffic = {}
+for cfg in ("infer", "train_f32", "train_bf16", "f16", "bf16", "pruned_f16"):
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(dst, cfg, "pmc_%s_per_kernel.csv" % ctr)
+        if not os.path.exists(f):
+            continue
+        for r in csv.DictReader(open(f)):
+            if not r["kernel"].startswith("fd_") or r["counter"] != ctr:
+                continue
+            name = r["kernel"].split("<")[0] if cfg.startswith("train") else r["kernel"]
+            e = per.setdefault(name, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+            e[ctr][0] += float(r["mean_value_per_launch"]) * int(r["launches"]); e[ctr][1] += int(r["launches"])
+    if per:
+        traffic[cfg] = {k: {"bytes_per_launch": (2.0 * e["FETCH_SIZE"][0] / max(e["FETCH_SIZE"][1], 1) + e["WRITE_SIZE"][0] / max(e["WRITE_SIZE"][1], 1)) * 1024.0,
+                            "launches_in_pmc_run": e["FETCH_SIZE"][1]} for k, e in sorted(per.items())}
+if traffic:
+    json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
