@@ -384,7 +384,7 @@ def test_forward_graph_replay_equals_eager_forward(b, streams):
         assert torch.equal(eager(), want), "the eager forward is not reproducible run to run"
         got = eng.forward_graph(xs, streams=streams).clone()
         assert torch.equal(got, want), (float((got - want).abs().max()), int((got != want).sum()))
-        xs.copy_(inputs.batch_variants(inputs.load_sample()[0], b, seed=5).cuda())          # same address, new frames
+        xs.copy_(torch.flip(xs, dims=(3,)) * 0.9 + 0.05)                                    # same address, new frames
         want2 = eager()
         got2 = eng.forward_graph(xs, streams=streams).clone()
         assert torch.equal(got2, want2) and not torch.equal(got2, got)
