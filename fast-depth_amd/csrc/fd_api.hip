@@ -8,6 +8,7 @@
 #include "fd_kernels_f32.h"
 #include "fd_kernels_gemm16_f32.h"
 #include "fd_kernels_h16.h"
+#include "fd_kernels_gemm16_h16.h"
 // Off-by-default experiments (stream-K GEMM, fused depthwise+pointwise unit, side-stream weight gradients: all measured no faster, DESIGN.md
 // section 3) are compiled only with -DFD_EXPERIMENTS: the product library does not contain them; the emulator test build does.
 #ifdef FD_EXPERIMENTS
@@ -440,9 +441,36 @@ int launch_pw_t(const fd_plan *plan, const Layer &L, const float *A, const void 
     return launch_pw<ACT>(plan, L, A, static_cast<const float *>(wp), bias, out, M, s);
 }
 template <int ACT, typename T>
-int launch_pw_t(const fd_plan *, const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s)
+int launch_pw_t(const fd_plan *plan, const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s)
 {
     const int K = L.d.cin;
+    if (L.pw16_tm) {                                         // fd_pw_gemm16_h16: whole frames per workgroup, optionally with the consuming depthwise layer
+        fd_dwfuse fz{};
+        int fdw = 0;
+        if (L.fuse_next_dw >= 0) {
+            const Layer &D = plan->layers[L.fuse_next_dw];
+            fz.w = reinterpret_cast<const float *>(plan->ws + D.w_off); fz.b = reinterpret_cast<const float *>(plan->ws + D.b_off);
+            fz.out = reinterpret_cast<float *>(plan->ws + D.out_off);        // (T-typed: the kernel casts)
+            fz.H = L.out_h; fz.W = L.out_w; fz.S = D.d.stride; fz.up = D.d.upsample;
+            fz.hi = D.d.act == FD_ACT_RELU6 ? 6.0f : __builtin_inff();
+            fz.store_pw = (plan->flags & FD_PLAN_KEEP_ACTIVATIONS) ? 1 : 0;
+            fdw = D.d.ksize;
+        }
+#define FD_PW16H_LAUNCH(TMV, FD_) \
+        do { (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_h16<T, TMV, 4, ACT, FD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+             FD_LAUNCH((fd_pw_gemm16_h16<T, TMV, 4, ACT, FD_>), L.grid, dim3(512), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz, (int)((plan->flags >> 20) & 7)); } while (0)
+#define FD_PW16H_CASE(TMV) \
+    case TMV: if (fdw == 3) FD_PW16H_LAUNCH(TMV, 3); else if (fdw == 5) FD_PW16H_LAUNCH(TMV, 5); else FD_PW16H_LAUNCH(TMV, 0); break;
+        switch (L.pw16_tm) {
+            FD_PW16H_CASE(13)
+            FD_PW16H_CASE(7)
+            FD_PW16H_CASE(4)
+        default: return fail(FD_ERR_INVALID, "no 16-bit gemm16 instance for TM=%d", L.pw16_tm);
+        }
+#undef FD_PW16H_CASE
+#undef FD_PW16H_LAUNCH
+        return check_launch("fd_pw_gemm16_h16");
+    }
     FD_LAUNCH((fd_pw_gemm_h16<T, ACT>), L.grid, dim3(256), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, (K + 63) / 64 * 64,
               L.m_tiles, L.n_tiles);
     return check_launch("fd_pw_gemm_h16");
@@ -621,11 +649,13 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
                 L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));   // 1-D, XCD-aware mapping inside the kernel
-                if (dtype == FD_F32 && !(flags & FD_PLAN_NO_GEMM16)) {
+                if ((dtype == FD_F32 || (flags & FD_PLAN_FORCE_GEMM16)) && !(flags & FD_PLAN_NO_GEMM16)) {
+                    // (16-bit plans take fd_pw_gemm16_h16 where a depthwise consumer fuses behind it -- decided in the fusion pass below --
+                    // or, with FD_PLAN_FORCE_GEMM16, everywhere: tests)
                     const Pw16Cfg c16 = choose_pw16(M, d.cout, d.cin, (flags & FD_PLAN_FORCE_GEMM16) != 0);
                     if (c16.tm) {
                         L.pw16_tm = c16.tm; L.pw16_stride = c16.stride;
-                        L.lds = (size_t)3 * (c16.tm * 16 + 64) * 32 * 4;
+                        L.lds = (size_t)(dtype == FD_F32 ? 3 : 4) * (c16.tm * 16 + 64) * 32 * 4;   // (128-byte rows in both kernels; the 16-bit one runs a 4-stage ring)
                         L.m_tiles = ceil_div(M, c16.stride); L.n_tiles = ceil_div(d.cout, 64);
                         L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
                     }
@@ -670,7 +700,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     // ---- fusion: a depthwise layer whose producer is a gemm16 pointwise layer with WHOLE frames per workgroup is evaluated in that
     // kernel's epilogue (fd_pw_gemm16_f32<..., FDW>): depthwise convolution is per channel, so a workgroup that holds 64 channels of a
     // few complete frames holds everything the consumer needs for those channels and frames.
-    if (dtype == FD_F32 && !(flags & FD_PLAN_NO_EPILOGUE_FUSION)) {
+    if (!(flags & FD_PLAN_NO_EPILOGUE_FUSION)) {
         std::vector<int> readers(n_layers, 0);
         for (int i = 0; i < n_layers; ++i) {
             if (p->layers[i].d.src >= 0) ++readers[p->layers[i].d.src];
@@ -681,14 +711,37 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             if (D.d.op != FD_OP_DW || D.d.src < 0 || D.d.skip >= 0 || D.d.concat) continue;
             if (D.d.act == FD_ACT_NONE) continue;                      // the epilogue's depthwise stage always clamps at 0 (ReLU / ReLU6)
             Layer &Pw = p->layers[D.d.src];
-            if (!Pw.pw16_tm || readers[D.d.src] != 1) continue;       // the pointwise output must have no other reader (skip sources keep their tensor)
+            if (Pw.d.op != FD_OP_PW || Pw.head || readers[D.d.src] != 1) continue;       // the pointwise output must have no other reader (skip sources keep their tensor)
             const int hw = Pw.out_h * Pw.out_w;
-            if (Pw.pw16_stride % hw || D.d.cin % 4) continue;         // whole frames per workgroup
+            int tm = Pw.pw16_tm, stride = Pw.pw16_stride, m_tiles = Pw.m_tiles, n_tiles = Pw.n_tiles;
+            size_t lds = Pw.lds;
+            // (measured at batch 32 / 64, fp16: the fused launch takes 11-12.6 us where the pointwise GEMM + the depthwise launch took 18 on the 14x14
+            // maps; on the 7x7 maps (6.6 + 5.4 us unfused) and where the grid needs a second round of workgroups (pruned plan at batch 64) it is
+            // no faster, so those keep the first-generation kernels unless FD_PLAN_FORCE_EPILOGUE_FUSION asks for every eligible pair: tests)
+            const bool want_all = (flags & FD_PLAN_FORCE_EPILOGUE_FUSION) != 0;
+            const bool h16_pick = dtype != FD_F32 && !(flags & (FD_PLAN_NO_GEMM16 | FD_PLAN_FORCE_GEMM16)) && hw <= 208 &&
+                                  (want_all || (hw >= 128 && (long)batch * ceil_div(Pw.d.cout, 64) <= 272));
+            if (h16_pick) {
+                // 16-bit plans: a pointwise layer of a small map (a frame is at most 13 row tiles) followed by a fusable depthwise layer moves to
+                // fd_pw_gemm16_h16 with WHOLE frames per workgroup -- as many (4, 2, 1) as still leave a full round of workgroups
+                n_tiles = ceil_div(Pw.d.cout, 64);
+                int f = 1;
+                for (int cand : {4, 2}) if (cand * hw <= 208 && (long)ceil_div(batch, cand) * n_tiles >= 256) { f = cand; break; }
+                stride = f * hw; tm = stride <= 64 ? 4 : (stride <= 112 ? 7 : 13);
+                lds = (size_t)4 * (tm * 16 + 64) * 128;
+                m_tiles = ceil_div((long)batch * hw, stride);
+            }
+            if (!tm) continue;
+            if (stride % hw || D.d.cin % 4) continue;                 // whole frames per workgroup
             if (D.d.upsample && D.d.stride != 1) continue;
             {   // the zero-bordered frame image (+ one dump row) must fit the kernel's LDS ring
                 const int P = D.d.upsample ? (D.d.ksize / 2 + 1) / 2 : D.d.ksize / 2;
-                const long img_rows = (long)(Pw.pw16_stride / hw) * (Pw.out_h + 2 * P) * (Pw.out_w + 2 * P) + 1;
-                if ((size_t)img_rows * 68 * 4 > Pw.lds) continue;
+                const long img_rows = (long)(stride / hw) * (Pw.out_h + 2 * P) * (Pw.out_w + 2 * P) + 1;
+                if ((size_t)img_rows * 68 * 4 > lds) continue;
+            }
+            if (h16_pick) {
+                Pw.pw16_tm = tm; Pw.pw16_stride = stride; Pw.lds = lds; Pw.m_tiles = m_tiles; Pw.n_tiles = n_tiles;
+                Pw.grid = dim3((unsigned)((m_tiles + 7) / 8 * 8 * n_tiles));
             }
             Pw.fuse_next_dw = j;
             D.fused_into = D.d.src;
@@ -878,6 +931,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
+        else if (L.pw16_tm && dtype != FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm16_h16<%s, %d, 4, %d, %d>", tn, L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0, %d>", L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_%sf32<%d, %d, %d, %d, %d>", L.sk ? "sk_" : "", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);

@@ -57,6 +57,8 @@ __device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__
     const int c = bx * 64 + lane;
     const int r0 = by * rps;
     int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
+    float sc_c = 0.0f, mean_c = 0.0f, invstd_c = 0.0f;       // the unit's forward table: requested before the row sums (independent of them)
+    if (wave == 0 && c < C) { sc_c = st[FD_ST_SCALE * C + c]; mean_c = st[FD_ST_MEAN * C + c]; invstd_c = st[FD_ST_INVSTD * C + c]; }
     double s, q;
     fd_sum_partial_rows(part, r0, r1, wave, C, c, c < C, s, q);
     sh[wave][lane][0] = s; sh[wave][lane][1] = q;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__
     if (wave == 0 && c < C) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
-        const double sc = st[FD_ST_SCALE * C + c], mean = st[FD_ST_MEAN * C + c], invstd = st[FD_ST_INVSTD * C + c];
+        const double sc = sc_c, mean = mean_c, invstd = invstd_c;
         coef[FD_CF_A * C + c] = (float)sc;
         coef[FD_CF_C1 * C + c] = (float)(s / n);
         coef[FD_CF_MU * C + c] = (float)mean;

@@ -470,6 +470,10 @@ fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, dou
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * rps;
     int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
+    // the affine parameters and running statistics do not depend on the reduction: requested first, so that their latency runs under the row sums
+    // (this launch sits between every producer and its consumer: its dependent round trips are the train step's most repeated cost)
+    float g_c = 0.0f, b_c = 0.0f, rm_c = 0.0f, rv_c = 0.0f;
+    if (wave == 0 && c < C) { g_c = gamma[c]; b_c = beta[c]; rm_c = run_mean[c]; rv_c = run_var[c]; }
     double s, q;
     fd_sum_partial_rows(part, r0, r1, wave, C, c, c < C, s, q);
     sh[wave][lane][0] = s; sh[wave][lane][1] = q;
@@ -485,13 +489,13 @@ fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, dou
         double var = q / n - mean * mean;
         if (var < 0.0) var = 0.0;
         const double invstd = 1.0 / sqrt(var + (double)eps);
-        const double sc = (double)gamma[c] * invstd;
+        const double sc = (double)g_c * invstd;
         st[FD_ST_SCALE * C + c] = (float)sc;
-        st[FD_ST_SHIFT * C + c] = (float)((double)beta[c] - mean * sc);
+        st[FD_ST_SHIFT * C + c] = (float)((double)b_c - mean * sc);
         st[FD_ST_MEAN * C + c] = (float)mean;
         st[FD_ST_INVSTD * C + c] = (float)invstd;
-        run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
-        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * var * (n_unbiased / (n_unbiased - 1.0)));
+        run_mean[c] = (float)((1.0 - momentum) * rm_c + momentum * mean);
+        run_var[c] = (float)((1.0 - momentum) * rv_c + momentum * var * (n_unbiased / (n_unbiased - 1.0)));
         if (c == 0 && nbt) nbt[0] += 1;                       // nn.BatchNorm2d.num_batches_tracked (one finalising workgroup owns channel 0)
     }
 }

@@ -48,6 +48,14 @@ int defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C,
     return FD_OK;
 }
 
+// input rows per backward-data tile: balanced over the map (14 -> 7 + 7 instead of 8 + 6: both tiles full, smaller patches, one more workgroup per
+// CU); the upsampled modes produce 2 x 2 blocks per low-resolution pixel and need an even count
+inline int dw_dgrad_rows(const fd_train_plan *p, const TLayer &L)
+{
+    if (p->flags & FD_PLAN_TUNE_DW_TH8) return 8;
+    const int th = ceil_div(L.in_h, ceil_div(L.in_h, 8));
+    return L.mode != 0 ? (th + 1) / 2 * 2 : th;
+}
 inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size_t)ph * pw * (cb + 4), (size_t)2048) + (size_t)k * k * cb) * 4; }
 
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
@@ -65,7 +73,7 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
     TLayer &L = c.p->layers[i];
     TLayer &P = c.p->layers[L.d.src];
     const int cb = 4 << L.cbq;
-    const int TH = 8, TW = 16;
+    const int TH = dw_dgrad_rows(c.p, L), TW = 16;
     const int tiles_x = ceil_div(L.in_w, TW), tiles_y = ceil_div(L.in_h, TH);
     const int ph = (TH - 1 + K / 2) / S + (K - 1) / S + 3, pw = (TW - 1 + K / 2) / S + (K - 1) / S + 3;   // upper bound of the dz patch
     const size_t lds = dw_bwd_lds(ph, pw, cb, K);
@@ -162,7 +170,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.part = tws(c.p, c.p->part_off); a.wpart = tws(c.p, L.wp_off);
     a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.B = c.p->B;
     // backward-data geometry (launch_dw_dgrad)
-    a.d_th = 8; a.d_tw = 16;
+    a.d_th = dw_dgrad_rows(c.p, L); a.d_tw = 16;
     a.d_tiles_x = ceil_div(L.in_w, a.d_tw);
     a.d_gx = a.d_tiles_x * ceil_div(L.in_h, a.d_th); a.d_gy = ceil_div(L.d.cin, cb);
     const int ph = (a.d_th - 1 + K / 2) / S + (K - 1) / S + 3, pw = (a.d_tw - 1 + K / 2) / S + (K - 1) / S + 3;

@@ -30,9 +30,11 @@ FD_PLAN_NO_EPILOGUE_FUSION = 512
 FD_PLAN_NO_UNIT_FUSION = 1024
 FD_PLAN_FORCE_UNIT_FUSION = 2048
 FD_PLAN_NO_BWD_PAIRING = 4096
+FD_PLAN_FORCE_EPILOGUE_FUSION = 8192
 FD_PLAN_TUNE_NO_PW_PAIRING = 65536
 FD_PLAN_TUNE_PW_PAIR_TN2 = 131072
 FD_PLAN_TUNE_DW_CB16 = 262144
+FD_PLAN_TUNE_DW_TH8 = 524288
 
 
 class LayerDesc(ctypes.Structure):

@@ -56,11 +56,13 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_WGRAD_TILE_ROWS 8u  /* train plans: depthwise weight-gradient workgroups always walk a whole row of tiles (default: only when that still leaves >= ~1536 workgroups); lets small test shapes exercise the tile loop */
 #define FD_PLAN_FORCE_GEMM16 16u     /* every fp32 pointwise layer with cout % 4 == 0 runs on fd_pw_gemm16_f32 (16x16x4 MFMA, one workgroup per CU), whatever its shape: lets small test shapes exercise that kernel; default: only where one round of workgroups covers the layer */
 #define FD_PLAN_NO_EPILOGUE_FUSION 512u /* never evaluate a depthwise layer in the epilogue of its pointwise producer (A/B measurements, tests of the unfused kernels) */
+#define FD_PLAN_FORCE_EPILOGUE_FUSION 8192u /* 16-bit plans: fd_pw_gemm16_h16 + fused depthwise consumer for every eligible pair (default: only where it was measured to pay: 14x14 maps, one round of workgroups); lets small test shapes exercise the kernel */
 #define FD_PLAN_NO_UNIT_FUSION 1024u   /* never run a depthwise + pointwise unit of a large map as one kernel (fd_dwpw_f32): A/B measurements, tests of the unfused kernels */
 #define FD_PLAN_FORCE_UNIT_FUSION 2048u /* fd_dwpw_f32 for every eligible depthwise + pointwise pair whatever the map size: lets small test shapes exercise that kernel */
 #define FD_PLAN_NO_BWD_PAIRING 4096u   /* train plans: launch a unit's backward-data and backward-weights kernels one after the other instead of as one paired launch (A/B measurements, tests of the separate kernels) */
 #define FD_PLAN_TUNE_NO_PW_PAIRING 65536u  /* tuning aid (train plans): pair only the depthwise units' backward kernels, not the pointwise GEMMs */
 #define FD_PLAN_TUNE_PW_PAIR_TN2 131072u   /* tuning aid (16-bit train plans): the paired pointwise backward launch keeps the 64 x 128 backward-data tiles of the unpaired kernel (74 KB of LDS per workgroup instead of 49) */
+#define FD_PLAN_TUNE_DW_TH8 524288u        /* tuning aid (train plans): depthwise tiles of 8 rows with a ragged last tile (round 1/2) instead of balanced row counts */
 #define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
 /* The three flags below select experiments that were measured no faster than the default path; they exist only in

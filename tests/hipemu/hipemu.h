@@ -279,6 +279,42 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_u16x8 a, hipemu_u16x8 
     return hipemu_mfma_32x32x16_generic(av, bv, c);
 }
 
+/* v_mfma_f32_16x16x32_{f16,bf16} (gfx950): lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15], j = 0..7; D[(l>>4)*4+r][l&15]
+ * (C/D layout: cdna_hip_programming.md, "Fragment layout"; any k numbering common to A and B gives the same sums). */
+inline hipemu_f32x4 hipemu_mfma_16x16x32_generic(const float (&av)[8], const float (&bv)[8], hipemu_f32x4 c)
+{
+    hipemu::WaveXchg &x = hipemu::wave_xchg();
+    const int l = hipemu::lane_id();
+    for (int j = 0; j < 8; ++j) { x.f[l][j] = av[j]; x.f[l][8 + j] = bv[j]; }
+    hipemu::yield(hipemu::COLLECTIVE);
+    hipemu_f32x4 d;
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc = fmaf(x.f[row + 16 * (k >> 3)][k & 7], x.f[col + 16 * (k >> 3)][8 + (k & 7)], acc);
+        d[r] = acc;
+    }
+    hipemu::yield(hipemu::COLLECTIVE);
+    return d;
+}
+inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_f16(hipemu_u16x8 a, hipemu_u16x8 b, hipemu_f32x4 c)
+{
+    float av[8], bv[8];
+    const hipemu_f16x8 ha = __builtin_bit_cast(hipemu_f16x8, a), hb = __builtin_bit_cast(hipemu_f16x8, b);
+    for (int j = 0; j < 8; ++j) { av[j] = (float)ha[j]; bv[j] = (float)hb[j]; }
+    return hipemu_mfma_16x16x32_generic(av, bv, c);
+}
+inline hipemu_f32x4 hipemu_mfma_f32_16x16x32_bf16(hipemu_u16x8 a, hipemu_u16x8 b, hipemu_f32x4 c)
+{
+    float av[8], bv[8];
+    for (int j = 0; j < 8; ++j) {
+        unsigned ua = (unsigned)a[j] << 16, ub = (unsigned)b[j] << 16;
+        memcpy(&av[j], &ua, 4); memcpy(&bv[j], &ub, 4);
+    }
+    return hipemu_mfma_16x16x32_generic(av, bv, c);
+}
+
 /* ---- host runtime shim: synchronous, "device" memory is host memory ---- */
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
     hipemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })

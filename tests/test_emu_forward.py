@@ -217,3 +217,38 @@ def test_emulated_skip_concat_sibling_forward():
     y = plan.forward(x)
     plan.close()
     assert harness.rel_err(y.numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("name,plan,b,hw,flags", [("tiny", TINY, 2, (64, 64), harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION), ("tiny5", TINY, 5, (64, 64), harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION),
+                                                  ("ragged", RAGGED, 2, (64, 64), harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION),
+                                                  ("ragged_forced", RAGGED, 2, (32, 96), harness.capi.FD_PLAN_FORCE_GEMM16),
+                                                  ("tiny_forced", TINY, 3, (64, 64), harness.capi.FD_PLAN_FORCE_GEMM16)])
+def test_emulated_16bit_gemm16_and_fused_epilogues(name, plan, b, hw, flags, dtype, ulp):
+    """fd_pw_gemm16_h16 (16x16x32 MFMA, whole frames per workgroup, depthwise consumer in the epilogue) against the first-generation 16-bit
+    kernels (fd_pw_gemm_h16 + separate depthwise launches) on the same plan: both round the pointwise output to the storage type before the
+    depthwise layer reads it, so every stored tensor agrees to the last bit or two of the storage type (the k-halves are summed in a different
+    order).  FORCE_EPILOGUE_FUSION picks the kernel wherever a depthwise consumer fuses behind it (maps of <= 208 pixels; product plans: only where
+    it was measured to pay); FORCE_GEMM16 puts it on every pointwise layer (ragged M / N / K, strides that are not whole frames: no fusion there)."""
+    m = small_model(plan[0], plan[1], seed=21).eval()
+    x = torch.rand(b, 3, hw[0], hw[1], generator=torch.Generator().manual_seed(8))
+    cap = harness.capi
+    new = harness.CPlan("emu", m, x, dtype=dtype, flags=flags)
+    old = harness.CPlan("emu", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_GEMM16 | cap.FD_PLAN_NO_EPILOGUE_FUSION)
+    y_new, y_old = new.forward(x), old.forward(x)
+    info = new.info()
+    used = [s for s in info if s.startswith("pw_gemm16")]
+    fused = [s for s in info if "evaluated in the epilogue" in s]
+    assert not any(s.startswith("pw_gemm16") for s in old.info())
+    if flags == cap.FD_PLAN_FORCE_GEMM16:
+        assert len(used) == 18, info
+    else:
+        assert len(used) >= 6 and len(fused) == len(used), info           # picked exactly where a consumer fuses
+        if name.startswith("tiny"):
+            assert {s.split("(dw ")[1].split(" evaluated")[0] for s in fused} >= {"k3 s1", "k3 s2", "k5 s1", "k5 s1 on up2"}, fused
+    n = len(new.layers)
+    for i in range(n - 1):
+        a, r = new.tap(i).double(), old.tap(i).double()
+        assert float((a - r).abs().max()) <= 2.5 * ulp * max(float(r.abs().max()), 1e-30), (i, info[i])
+    assert harness.rel_err(y_new.numpy(), y_old.numpy()) < 4 * ulp
+    new.close(); old.close()

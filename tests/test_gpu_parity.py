@@ -394,3 +394,36 @@ def test_forward_graph_replay_equals_eager_forward(b, streams):
         assert torch.equal(got3, want3) and not torch.equal(got3, got2)
     with pytest.raises(RuntimeError):
         eng.forward_graph(xs.cpu())
+
+
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("pruned,b,flags", [(False, 32, 0), (False, 32, harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION), (True, 64, harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION),
+                                            (True, 5, harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION), (False, 3, harness.capi.FD_PLAN_FORCE_GEMM16), (True, 2, harness.capi.FD_PLAN_FORCE_GEMM16)])
+def test_16bit_gemm16_fused_epilogues_vs_first_generation_kernels(pruned, b, flags, dtype, ulp):
+    """fd_pw_gemm16_h16 (whole frames per workgroup, depthwise consumers in the GEMM epilogue: 9 launches and their round trips fewer per
+    forward) at BASELINE's sizes -- unpruned batch 32 and the pruned plan at batch 64 (configs[4]: irregular channel counts) -- against the
+    first-generation 16-bit kernels on the same plan, layer by layer: identical rounding points, so every stored tensor agrees to the last
+    bit or two of the storage type.  FORCE_GEMM16: the kernel on every pointwise layer (ragged M, strides that are not whole frames)."""
+    models = inputs.product_models()
+    torch.manual_seed(11)
+    m = harness.randomize_bn(models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None), 12).eval()
+    x = inputs.batch_variants(inputs.load_sample()[0], b, seed=4).cuda()
+    cap = harness.capi
+    new = harness.CPlan("hip", m, x, dtype=dtype, flags=flags)
+    old = harness.CPlan("hip", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_GEMM16 | cap.FD_PLAN_NO_EPILOGUE_FUSION)
+    y_new, y_new2, y_old = new.forward(x), new.forward(x), old.forward(x)
+    assert torch.equal(y_new, y_new2)
+    info = new.info()
+    used = [s for s in info if s.startswith("pw_gemm16")]
+    fused = [s for s in info if "evaluated in the epilogue" in s]
+    if flags == cap.FD_PLAN_FORCE_GEMM16:
+        assert len(used) == 18, info
+    elif flags:
+        assert len(used) == 9 and len(fused) == 9, info               # conv6.3 ... conv13.3, decode_conv1.1, each with the next depthwise layer
+    else:
+        assert len(used) == 6 and len(fused) == 6, info               # the product's pick at batch 32: conv6.3 ... conv11.3 (14x14 maps, one round of workgroups)
+    for i in range(len(new.layers) - 1):
+        a, r = new.tap(i).double(), old.tap(i).double()
+        assert float((a - r).abs().max()) <= 2.5 * ulp * max(float(r.abs().max()), 1e-30), (i, info[i])
+    assert harness.rel_err(y_new.cpu().numpy(), y_old.cpu().numpy()) < 4 * ulp
+    new.close(); old.close()

@@ -149,8 +149,10 @@ def test_skip_concat_sibling_train_step_layer_local():
         rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype)
         assert_local_parity(rep, dtype)
     eng = TrainEngine(copy.deepcopy(m).cuda().train(), lr=0.01)
-    l0 = float(eng.step(x.cuda(), tgt.cuda())); l1 = float(eng.step(x.cuda(), tgt.cuda()))
-    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0
+    losses = [float(eng.step(x.cuda(), tgt.cuda())) for _ in range(6)]
+    # (plumbing check: SGD with momentum on a randomly initialised net need not descend on every single step -- the second loss sits within
+    # 1 % of the first and its side depends on rounding; over a few steps it must go down)
+    assert all(np.isfinite(losses)) and min(losses[1:]) < losses[0] and losses[-1] < losses[0], losses
 
 
 def test_bf16_train_step_end_to_end():
