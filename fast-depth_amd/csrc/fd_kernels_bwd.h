@@ -678,9 +678,14 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
     const int cg = c0 + c4 * 4;
     const bool c_ok = cg < C;
-    for (int i = tid; i < K * K * CB; i += 256) {
-        const int t = i / CB, cc = i - t * CB;
-        s_w[t * CB + cc] = (c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
+    // the taps of this channel block (w[c][tap] -> s_w[tap][c]): requested now, written to LDS after the patch loads have been issued, so that the two
+    // global round trips overlap instead of following each other (a workgroup's life is a chain of such latencies, not arithmetic)
+    constexpr int NWREG = (K * K * 32 + 255) / 256;
+    float wreg[NWREG];
+#pragma unroll
+    for (int j = 0; j < NWREG; ++j) {
+        const int i = tid + 256 * j, t = i / CB, cc = i - t * CB;
+        wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
     fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
     if (c_ok) { cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg); }
@@ -709,6 +714,8 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             if (px < npx) fd_st4(s_dz + px * PSTR + c4 * 4, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : fd_zero4());
         }
     }
+#pragma unroll
+    for (int j = 0; j < NWREG; ++j) { const int i = tid + 256 * j; if (i < K * K * CB) s_w[i] = wreg[j]; }
     __syncthreads();
 
     // producer's tables.  MODE 3 (concatenating consumer): channels [0, csplit) belong to the low-resolution producer (pitch
@@ -754,7 +761,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
                 sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
             }
             fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
-#pragma unroll 1
+#pragma unroll FD_TAPROW_UNROLL(K)
             for (int a = 0; a < K; ++a) {
                 const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
                 fd_f32x4 r[K + 3];
@@ -840,18 +847,12 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             ssum += v; ssx += v * ((z - mu) * is);
         }
     }
-    __syncthreads();
-    float *red = smem;                                     // [npt][lanes_c][8]
-    fd_st4(red + (pt * lanes_c + c4) * 8, ssum);
-    fd_st4(red + (pt * lanes_c + c4) * 8 + 4, ssx);
-    __syncthreads();
-    if (tid < lanes_c) {
-        fd_f32x4 a = fd_zero4(), b = fd_zero4();
-        for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
+    float *red = smem;
+    if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
         const long blk = (long)bm.z * grid_x + bm.x;
         if (c0 + tid * 4 < Cp) {
-            fd_st4(part + blk * 2 * Cp + c0 + tid * 4, a);
-            fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, b);
+            fd_st4(part + blk * 2 * Cp + c0 + tid * 4, ssum);
+            fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, ssx);
         }
     }
 }
@@ -1086,6 +1087,320 @@ fd_dw_bwd(const fd_dw_bwd_args<T> a)
         fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
                                                     a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, bm, a.w_gx);
     }
+}
+
+template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG>
+__device__ __forceinline__ void
+fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
+                const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
+                const T *__restrict__ Zskip, const float *__restrict__ st_skip,
+                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part, float *__restrict__ wpart,
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, const fd_blk3 bm, const int grid_x)
+{
+    constexpr int P = K / 2;
+    FD_DYN_SMEM(smem_raw);
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
+    // (bm: all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2)
+    const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
+    const int c0 = bm.y * CB, n = bm.z;
+    const int iy0 = ty * TH, ix0 = tx * TW;
+    const int oyb = (iy0 + P - (K - 1) >= 0) ? (iy0 + P - (K - 1)) / S : -((-(iy0 + P - (K - 1)) + S - 1) / S);
+    const int oxb = (ix0 + P - (K - 1) >= 0) ? (ix0 + P - (K - 1)) / S : -((-(ix0 + P - (K - 1)) + S - 1) / S);
+    const int PH = (iy0 + TH - 1 + P) / S - oyb + 1, PW = (ix0 + TW - 1 + P) / S - oxb + 1;
+    // the positions the OWNED outputs (those whose receptive field starts in this tile: rows [iy0 / S, (iy0 + TH) / S)) read of the unit's forward input
+    const int OTH = TH / S, OTW = TW / S, oy0 = iy0 / S, ox0 = ix0 / S;
+    const int TH_in = (OTH - 1) * S + K, TW_in = (OTW - 1) * S + K;
+    const int jy0 = oy0 * S - P, jx0 = ox0 * S - P;       // input position of patch pixel (0, 0)
+    float *s_dz = smem;                                   // [PH*PW][PSTR]        dz of every output that touches the tile (0 outside the image)
+    float *s_in = smem + PH * PW * PSTR;                  // [TH_in*TW_in][PSTR]  the activated forward input under the owned outputs (0 = padding)
+    float *s_w = s_in + TH_in * TW_in * PSTR;             // [K*K][CB]
+    const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
+    const int cg = c0 + c4 * 4;
+    const bool c_ok = cg < C;
+    // the taps of this channel block (w[c][tap] -> s_w[tap][c]): requested now, written to LDS after the patch loads have been issued, so that the two
+    // global round trips overlap instead of following each other (a workgroup's life is a chain of such latencies, not arithmetic)
+    constexpr int NWREG = (K * K * 32 + 255) / 256;
+    float wreg[NWREG];
+#pragma unroll
+    for (int j = 0; j < NWREG; ++j) {
+        const int i = tid + 256 * j, t = i / CB, cc = i - t * CB;
+        wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
+    }
+    fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
+    if (c_ok) { cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg); }
+    const int npx = PH * PW;
+    constexpr int U = 8;
+    fd_px_walk wk(pt, npt, PW);
+    for (int base = pt; base < npx; base += npt * U) {
+        fd_f32x4 g[U], z[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            const int py = wk.iy, pxx = wk.ix;
+            wk.next();
+            const int oy = oyb + py, ox = oxb + pxx;
+            ok[u] = px < npx && c_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+            {   // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
+                const int qy = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), qx = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+                const long o = (((long)n * Ho + qy) * Wo + qx) * C + (c_ok ? cg : 0);
+                g[u] = fd_ld4(G + o); z[u] = fd_ld4(Z + o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int px = base + u * npt;
+            if (px < npx) fd_st4(s_dz + px * PSTR + c4 * 4, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : fd_zero4());
+        }
+    }
+    {   // ---- the forward input patch, re-created on load as in fd_dwconv_train: act(z_in * s + t), nearest x2, + / cat skip ----
+        const bool from_skip = MODE == 3 && cg >= csplit;
+        const int C1w = MODE == 3 ? csplit : C, C2w = MODE == 3 ? C - csplit : C, clw = from_skip ? cg - csplit : cg;
+        fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
+        if (c_ok) {
+            if (from_skip) { s1 = fd_ld4(st_skip + FD_ST_SCALE * C2w + clw); t1 = fd_ld4(st_skip + FD_ST_SHIFT * C2w + clw); }
+            else { s1 = fd_ld4(st_in + FD_ST_SCALE * C1w + clw); t1 = fd_ld4(st_in + FD_ST_SHIFT * C1w + clw); }
+            if (MODE == 2) { s2 = fd_ld4(st_skip + FD_ST_SCALE * C + cg); t2 = fd_ld4(st_skip + FD_ST_SHIFT * C + cg); }
+        }
+        const int npx_in = TH_in * TW_in;
+        constexpr int UI = 4;
+        fd_px_walk wi(pt, npt, TW_in);
+        for (int base = pt; base < npx_in; base += npt * UI) {
+            fd_f32x4 v[UI], sk[UI];
+            bool oki[UI];
+#pragma unroll
+            for (int u = 0; u < UI; ++u) {
+                const int px = base + u * npt;
+                const int iy = wi.iy, ix = wi.ix;
+                wi.next();
+                const int gy = jy0 + iy, gx = jx0 + ix;
+                sk[u] = fd_zero4();
+                oki[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+                const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
+                const int ql = c_ok ? clw : 0, qg = c_ok ? cg : 0;
+                if (MODE == 0) {
+                    v[u] = fd_ld4(Zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                } else {
+                    const int Hs = Hin >> 1, Ws = Win >> 1;
+                    if (from_skip) v[u] = fd_ld4(Zskip + (((long)n * Hin + qy) * Win + qx) * C2w + ql);
+                    else v[u] = fd_ld4(Zin + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C1w + ql);
+                    if (MODE == 2) sk[u] = fd_ld4(Zskip + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UI; ++u) {
+                const int px = base + u * npt;
+                if (px < npx_in) {
+                    fd_f32x4 av = fd_zero4();
+                    if (oki[u]) {
+                        av = from_skip ? fd_bn_act4<ACT2>(v[u], s1, t1) : fd_bn_act4<ACT_IN>(v[u], s1, t1);
+                        if (MODE == 2) av += fd_bn_act4<ACT2>(sk[u], s2, t2);
+                    }
+                    fd_st4(s_in + px * PSTR + c4 * 4, av);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NWREG; ++j) { const int i = tid + 256 * j; if (i < K * K * CB) s_w[i] = wreg[j]; }
+    __syncthreads();
+
+    // producer's tables.  MODE 3 (concatenating consumer): channels [0, csplit) belong to the low-resolution producer (pitch
+    // csplit: 2x2 sum, mask, BN partials as in MODE 1), the rest to the skip tensor (pitch C - csplit: full-resolution gradient
+    // into its skip-gradient buffer, masked later by the skip source's own consumer)
+    const bool to_skip = MODE == 3 && cg >= csplit;
+    const int Cp = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = to_skip ? cg - csplit : cg;
+    fd_f32x4 sc = fd_zero4(), sh = fd_zero4(), mu = fd_zero4(), is = fd_zero4();
+    if (c_ok && !to_skip) { sc = fd_ld4(st_in + FD_ST_SCALE * Cp + cg); sh = fd_ld4(st_in + FD_ST_SHIFT * Cp + cg); mu = fd_ld4(st_in + FD_ST_MEAN * Cp + cg); is = fd_ld4(st_in + FD_ST_INVSTD * Cp + cg); }
+    fd_f32x4 ssum = fd_zero4(), ssx = fd_zero4();
+    auto din_at = [&](int iy, int ix) {                    // gradient w.r.t. the conv input at tile-local (iy, ix)
+        fd_f32x4 acc = fd_zero4();
+        const int gy = iy0 + iy, gx = ix0 + ix;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int ny = gy + P - ky;
+            if (S == 2 && (ny & 1)) continue;
+            const int py = (S == 2 ? (ny >> 1) : ny) - oyb;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int nx = gx + P - kx;
+                if (S == 2 && (nx & 1)) continue;
+                const int pxx = (S == 2 ? (nx >> 1) : nx) - oxb;
+                acc += fd_ld4(s_dz + (py * PW + pxx) * PSTR + c4 * 4) * fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+            }
+        }
+        return acc;
+    };
+    if (MODE == 0 && S == 1) {
+        // stride 1: din = correlation of the dz patch with the FLIPPED taps -- same strip scheme as the forward kernel: 4 adjacent
+        // positions share K + 3 patch vectors per tap row (13 LDS reads per 20 FMAs instead of 40)
+        const int TWS = TW >> 2;
+        for (int st = pt; st < TH * TWS; st += npt) {
+            const int iy = st / TWS, ix = (st - iy * TWS) * 4;
+            const int gy = iy0 + iy;
+            if (!c_ok || gy >= Hin) continue;
+            fd_f32x4 z[4], sgv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                      // requested before the tap loop; clamped column, validity re-checked at the store
+                const int gx = ix0 + ix + j, qx = gx < Win ? gx : Win - 1;
+                const long o = (((long)n * Hin + gy) * Win + qx) * C + cg;
+                z[j] = fd_ld4(Zin + o);
+                sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
+            }
+            fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
+#pragma unroll FD_TAPROW_UNROLL(K)
+            for (int a = 0; a < K; ++a) {
+                const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
+                fd_f32x4 r[K + 3];
+#pragma unroll
+                for (int i = 0; i < K + 3; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+                for (int b = 0; b < K; ++b) {
+                    const fd_f32x4 wv = fd_ld4(s_w + ((K - 1 - a) * K + (K - 1 - b)) * CB + c4 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += r[j + b] * wv;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = ix0 + ix + j;
+                if (gx >= Win) continue;
+                const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
+                fd_f32x4 v = acc[j];
+                if (ADD_SG) v += sgv[j];
+                v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z[j] * sc + sh));
+                fd_st4(Gin + o, v);
+                ssum += v; ssx += v * ((z[j] - mu) * is);
+            }
+        }
+    } else if (MODE == 0) {
+        for (int p = pt; p < TH * TW; p += npt) {
+            const int iy = p / TW, ix = p - iy * TW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            if (!c_ok || gy >= Hin || gx >= Win) continue;
+            const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
+            const fd_f32x4 z = fd_ld4(Zin + o);                 // requested before the tap loop: the latency hides behind the LDS work
+            fd_f32x4 sgv = fd_zero4();
+            if (ADD_SG) sgv = fd_ld4(SG + o);
+            fd_f32x4 v = din_at(iy, ix);
+            if (ADD_SG) v += sgv;
+            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
+            fd_st4(Gin + o, v);
+            ssum += v; ssx += v * ((z - mu) * is);
+        }
+    } else {
+        const int TH2 = TH >> 1, TW2 = TW >> 1, Hs = Hin >> 1, Ws = Win >> 1;
+        for (int p = pt; p < TH2 * TW2; p += npt) {
+            const int ly = p / TW2, lx = p - ly * TW2;
+            const int gy = iy0 + 2 * ly, gx = ix0 + 2 * lx;     // top-left full-res position of the 2x2 block
+            if (!c_ok || gy >= Hin || gx >= Win) continue;
+            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * Cp + (to_skip ? 0 : cg);
+            const fd_f32x4 z = fd_ld4(Zin + ol);                // requested before the tap loop (unused by the lanes that feed the skip tensor)
+            fd_f32x4 d00, d01, d10, d11;
+            if (S == 1) {
+                // the four positions of the block read a (K+1) x (K+1) window of the dz patch: walk it row by row, every row feeds
+                // the block's upper row with tap row ky = K-1-r and its lower row with ky = K-r (one pass over LDS, few registers)
+                d00 = fd_zero4(); d01 = fd_zero4(); d10 = fd_zero4(); d11 = fd_zero4();
+                const int pyb = gy + P - (K - 1) - oyb, pxb = gx + P - (K - 1) - oxb;
+#pragma unroll 1
+                for (int r = 0; r <= K; ++r) {
+                    fd_f32x4 v[K + 1];
+                    const float *row = s_dz + ((pyb + r) * PW + pxb) * PSTR + c4 * 4;
+#pragma unroll
+                    for (int c = 0; c <= K; ++c) v[c] = fd_ld4(row + c * PSTR);
+                    if (r < K) {
+                        const float *wr = s_w + (K - 1 - r) * K * CB + c4 * 4;
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d00 += v[K - 1 - kx] * wv; d01 += v[K - kx] * wv; }
+                    }
+                    if (r > 0) {
+                        const float *wr = s_w + (K - r) * K * CB + c4 * 4;
+#pragma unroll
+                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d10 += v[K - 1 - kx] * wv; d11 += v[K - kx] * wv; }
+                    }
+                }
+            } else {
+                d00 = din_at(2 * ly, 2 * lx); d01 = din_at(2 * ly, 2 * lx + 1); d10 = din_at(2 * ly + 1, 2 * lx); d11 = din_at(2 * ly + 1, 2 * lx + 1);
+            }
+            if (MODE == 2 || to_skip) {
+                const long o = (((long)n * Hin + gy) * Win + gx) * C2 + cl;
+                fd_st4(SGout + o, d00); fd_st4(SGout + o + C2, d01);
+                fd_st4(SGout + o + (long)Win * C2, d10); fd_st4(SGout + o + (long)Win * C2 + C2, d11);
+                if (to_skip) continue;
+            }
+            fd_f32x4 v = (d00 + d01) + (d10 + d11);
+            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
+            fd_st4(Gin + ol, v);
+            ssum += v; ssx += v * ((z - mu) * is);
+        }
+    }
+    // ---- backward-weights from the same two patches: work-item = (channel group c4, tap row ky, pixel group pg) owns the K taps of row ky (K
+    // accumulators) and walks the owned output strips pg, pg + ngroups, ...; the pixel groups meet once, through LDS, below ----
+    constexpr int NIN = 3 * S + K;
+    const int ngroups = npt / K, ky_w = pt % K, pg = pt / K;
+    const bool worker = pg < ngroups;
+    fd_f32x4 wacc[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) wacc[t] = fd_zero4();
+    if (worker) {
+        const int OTWS = OTW >> 2, nstrips = OTH * OTWS;
+        for (int s = pg; s < nstrips; s += ngroups) {
+            const int oy = s / OTWS, ox = (s - oy * OTWS) * 4;
+            const float *row = s_in + ((oy * S + ky_w) * TW_in + ox * S) * PSTR + c4 * 4;
+            const float *dzp = s_dz + ((oy0 + oy - oyb) * PW + (ox0 + ox - oxb)) * PSTR + c4 * 4;
+            fd_f32x4 r[NIN], dzv[4];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dzv[j] = fd_ld4(dzp + j * PSTR);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wacc[kx] += r[j * S + kx] * dzv[j];
+        }
+    }
+    float *red = smem;
+    if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
+        const long blk = (long)bm.z * grid_x + bm.x;
+        if (c0 + tid * 4 < Cp) {
+            fd_st4(part + blk * 2 * Cp + c0 + tid * 4, ssum);
+            fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, ssx);
+        }
+    }
+    // the pixel groups' tap sums meet in LDS: red[pg][ky*K + kx][c4] (fixed order -> deterministic); one partial row per tile
+    __syncthreads();
+    if (worker) {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) fd_st4(red + ((pg * K * K + ky_w * K + kx) * lanes_c + c4) * 4, wacc[kx]);
+    }
+    __syncthreads();
+    {
+        const long blk = (long)bm.z * grid_x + bm.x;
+        for (int i = tid; i < K * K * lanes_c; i += 256) {
+            const int t = i >> cbq, cc = i & (lanes_c - 1);
+            if (c0 + cc * 4 < C) {
+                fd_f32x4 a = fd_zero4();
+                for (int g = 0; g < ngroups; ++g) a += fd_ld4(red + ((g * K * K + t) * lanes_c + cc) * 4);
+                fd_st4(wpart + (blk * K * K + t) * C + c0 + cc * 4, a);
+            }
+        }
+    }
+}
+
+// Depthwise backward, ONE workgroup per tile for both gradients ("vertical" fusion of fd_dw_dgrad and fd_dw_wgrad): the two kernels stage nearly the
+// same data -- dz of the outputs around the tile (from G, z, the BatchNorm-backward coefficients) and the unit's forward input around the tile
+// (re-created from the producer's raw output) -- and each spends most of its life waiting for those loads.  Here a tile's workgroup stages
+// both patches once (all loads of a work-item in flight together), runs the backward-data taps and the weight-gradient taps from LDS, and
+// leaves the producer's gradient, its BatchNorm partial sums and one weight-gradient partial row.  Tiles are INPUT-space (TH x TW, multiples of
+// the stride); an output belongs to the tile its receptive field starts in.
+template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_dw_bwd1(const fd_dw_bwd_args<T> a)
+{
+    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
+                                                         a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, fd_xcd_image_map(), (int)gridDim.x);
 }
 
 

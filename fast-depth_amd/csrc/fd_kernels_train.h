@@ -16,6 +16,17 @@
 #pragma once
 #include "fd_device.h"
 
+// measurement aid (tools/microbench/dwtrain.hip): shader-clock timestamps of a workgroup's phases; nothing in product builds
+#ifdef FD_DW_PROBE
+__device__ long long fd_dw_probe[8 * 16384];
+#define FD_DW_PROBE_AT(k) do { if (threadIdx.x == 0) { const unsigned b_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (b_ < 16384) fd_dw_probe[8 * b_ + (k)] = clock64(); } } while (0)
+#else
+#define FD_DW_PROBE_AT(k) ((void)0)
+#endif
+
+// 3x3 kernels: all tap rows of a strip unrolled (their LDS reads in flight together); 5x5: one row at a time (registers)
+#define FD_TAPROW_UNROLL(K_) ((K_) == 3 ? 3 : 1)
+
 // per-channel table written by fd_bn_finalize_f32:  [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) invstd
 #define FD_ST_SCALE 0
 #define FD_ST_SHIFT 1
@@ -114,6 +125,28 @@ fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__res
     }
 }
 
+// Sums a pair of 4-channel vectors over all work-items of a 256-item workgroup that share the channel group c4 = tid & (lanes_c - 1) (the per-tile
+// BatchNorm partial sums of the depthwise kernels).  Within a wave the items of a channel group are lanes c4, c4 + lanes_c, ...: a shuffle
+// butterfly adds them (fixed order), the four wave sums meet through `red` (>= 4 * lanes_c * 8 floats of LDS that no work-item still reads).
+// Work-items tid < lanes_c return true and hold the totals.  (Probe, tools/microbench/dwtrain.hip: the former 32-step serial LDS walk of lanes_c
+// work-items was 1.2 us of a 6.2 us workgroup life.)
+__device__ __forceinline__ bool fd_wg_sum_by_channel_group(fd_f32x4 &a, fd_f32x4 &b, float *red, int lanes_c, int tid)
+{
+    for (int m = lanes_c; m < 64; m <<= 1) {
+        a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
+        b.x += __shfl_xor(b.x, m); b.y += __shfl_xor(b.y, m); b.z += __shfl_xor(b.z, m); b.w += __shfl_xor(b.w, m);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    if (lane < lanes_c) { fd_st4(red + (wave * lanes_c + lane) * 8, a); fd_st4(red + (wave * lanes_c + lane) * 8 + 4, b); }
+    __syncthreads();
+    if (tid >= lanes_c) return false;
+    a = fd_ld4(red + tid * 8); b = fd_ld4(red + tid * 8 + 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { a += fd_ld4(red + (w * lanes_c + tid) * 8); b += fd_ld4(red + (w * lanes_c + tid) * 8 + 4); }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Depthwise K x K, stride S, train mode (LDS-tiled, same geometry as fd_dwconv).
 //   input  = act1(z_in * s1 + t1)                                   (MODE 0)
@@ -142,12 +175,18 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
+    FD_DW_PROBE_AT(0);
     const int cg = c0 + c4 * 4;
     const bool c_ok = cg < C;
 
-    for (int i = tid; i < K * K * CB; i += 256) {         // gather the taps of this channel block: w[c][tap] -> s_w[tap][c]
-        const int t = i / CB, cc = i - t * CB;
-        s_w[t * CB + cc] = (c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
+    // the taps of this channel block (w[c][tap] -> s_w[tap][c]): requested now, written to LDS after the patch loads have been issued, so that the two
+    // global round trips overlap instead of following each other (a workgroup's life is a chain of such latencies, not arithmetic)
+    constexpr int NWREG = (K * K * 32 + 255) / 256;
+    float wreg[NWREG];
+#pragma unroll
+    for (int j = 0; j < NWREG; ++j) {
+        const int i = tid + 256 * j, t = i / CB, cc = i - t * CB;
+        wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
     // MODE 3 (channel concatenation cat(up2(a_in), a_skip), MobileNetSkipConcat): channels [0, csplit) come from the low-resolution
     // producer (pitch csplit), the rest from the skip tensor (pitch C - csplit); a lane's 4 channels never straddle
@@ -199,14 +238,18 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
             }
         }
     }
+    FD_DW_PROBE_AT(1);
+#pragma unroll
+    for (int j = 0; j < NWREG; ++j) { const int i = tid + 256 * j; if (i < K * K * CB) s_w[i] = wreg[j]; }
     __syncthreads();
+    FD_DW_PROBE_AT(2);
 
     const int TWS = TW >> 2, nstrips = TH * TWS;
     fd_f32x4 ssum = fd_zero4(), ssq = fd_zero4();
     for (int s = pt; s < nstrips; s += npt) {
         const int oy = s / TWS, ox = (s - oy * TWS) * 4;
         fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
-#pragma unroll 1
+#pragma unroll FD_TAPROW_UNROLL(K)                              // 3x3: all 3 x NIN patch reads of a strip in flight at once (probe: the tap phase was a chain of LDS latencies)
         for (int ky = 0; ky < K; ++ky) {
             const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
             fd_f32x4 r[NIN];
@@ -233,20 +276,16 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
         }
     }
     // workgroup partial statistics: fixed-order sum over the pixel-threads that share a channel group
-    __syncthreads();
-    float *red = s_in;                                     // [npt][lanes_c][8]
-    fd_st4(red + (pt * lanes_c + c4) * 8, ssum);
-    fd_st4(red + (pt * lanes_c + c4) * 8 + 4, ssq);
-    __syncthreads();
-    if (tid < lanes_c) {
-        fd_f32x4 a = fd_zero4(), b = fd_zero4();
-        for (int i = 0; i < npt; ++i) { a += fd_ld4(red + (i * lanes_c + tid) * 8); b += fd_ld4(red + (i * lanes_c + tid) * 8 + 4); }
+    FD_DW_PROBE_AT(3);
+    if (fd_wg_sum_by_channel_group(ssum, ssq, s_in, lanes_c, tid)) {
         const long blk = (long)bm.z * gridDim.x + bm.x;
         if (c0 + tid * 4 < C) {
-            fd_st4(part + blk * 2 * C + c0 + tid * 4, a);
-            fd_st4(part + blk * 2 * C + C + c0 + tid * 4, b);
+            fd_st4(part + blk * 2 * C + c0 + tid * 4, ssum);
+            fd_st4(part + blk * 2 * C + C + c0 + tid * 4, ssq);
         }
     }
+    FD_DW_PROBE_AT(4);
+    FD_DW_PROBE_AT(5);
 }
 
 // ------------------------------------------------------------------------------------------------

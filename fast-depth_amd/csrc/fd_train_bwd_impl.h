@@ -54,7 +54,7 @@ inline int dw_dgrad_rows(const fd_train_plan *p, const TLayer &L)
 {
     if (p->flags & FD_PLAN_TUNE_DW_TH8) return 8;
     const int th = ceil_div(L.in_h, ceil_div(L.in_h, 8));
-    return L.mode != 0 ? (th + 1) / 2 * 2 : th;
+    return (L.mode != 0 || L.d.stride == 2) ? (th + 1) / 2 * 2 : th;     // (stride 2: the tile must hold whole receptive-field rows of its owned outputs)
 }
 inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size_t)ph * pw * (cb + 4), (size_t)2048) + (size_t)k * k * cb) * 4; }
 
@@ -112,11 +112,12 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     float *wpart = tws(c.p, L.wp_off);
     // tiles per workgroup (along x): as many as keep >= ~1536 workgroups in flight
-    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.grid.x * L.grid.y * L.grid.z / 1536)));
+    const int ncb_w = ceil_div(L.d.cin, 4 << L.cbq);          // (the forward launch may be persistent: its grid is not the tile grid)
+    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.tiles_x * L.tiles_y * ncb_w * c.p->B / 1536)));
     if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
     const int groups_x = ceil_div(L.tiles_x, tpw);
     tpw = ceil_div(L.tiles_x, groups_x);
-    const dim3 wgrid(groups_x * L.tiles_y, L.grid.y, L.grid.z);
+    const dim3 wgrid(groups_x * L.tiles_y, ncb_w, c.p->B);
     // LDS: activated input patch + dz tile, both [pixels][cb + 4] floats; the final reduction (npt/K groups x K*K taps x cb) reuses it
     const int cbw = 4 << L.cbq, th_in = (L.th - 1) * L.d.stride + L.d.ksize, tw_in = (L.tw - 1) * L.d.stride + L.d.ksize;
     const size_t wlds = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
@@ -176,16 +177,36 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const int ph = (a.d_th - 1 + K / 2) / S + (K - 1) / S + 3, pw = (a.d_tw - 1 + K / 2) / S + (K - 1) / S + 3;
     const size_t lds_d = dw_bwd_lds(ph, pw, cb, K);
     // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
-    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.grid.x * L.grid.y * L.grid.z / 1536)));
+    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.tiles_x * L.tiles_y * ceil_div(L.d.cin, cb) * c.p->B / 1536)));
     if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
     const int groups_x = ceil_div(L.tiles_x, tpw);
     tpw = ceil_div(L.tiles_x, groups_x);
-    a.w_th = L.th; a.w_tw = L.tw; a.w_tiles_x = L.tiles_x; a.w_tpw = tpw; a.w_gx = groups_x * L.tiles_y; a.w_gy = (int)L.grid.y;
+    a.w_th = L.th; a.w_tw = L.tw; a.w_tiles_x = L.tiles_x; a.w_tpw = tpw; a.w_gx = groups_x * L.tiles_y; a.w_gy = ceil_div(L.d.cin, cb);
     const int th_in = (L.th - 1) * S + K, tw_in = (L.tw - 1) * S + K;
     const size_t lds_w = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cb + 4), (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
     const size_t lds = std::max(lds_d, lds_w);
     if (lds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 64 KiB", lds);
-    const int wblk = a.w_gx * c.p->B, kk = K * K;
+    const int kk = K * K;
+    // measured (bf16, batch 32): the single-staging kernel wins on the stride-2 units (conv2.0 84 vs 103 us, conv4.0 50 vs 57, conv6.0 31 vs 35) and
+    // loses on the stride-1 3x3 ones (conv1.0 68 vs 57, 14x14 maps 22.4 vs 19.5: two tap phases back to back in one workgroup at lower residency);
+    // the 5x5 units tie.  FD_PLAN_TUNE_DW_BWD1 forces it everywhere (tests), FD_PLAN_TUNE_DW_BWD_PAIR nowhere.
+    if (!(c.p->flags & FD_PLAN_TUNE_DW_BWD_PAIR) && (S == 2 || (c.p->flags & FD_PLAN_TUNE_DW_BWD1))) {
+        // ONE workgroup per input-space tile stages the dz patch and the forward-input patch once and produces both gradients (fd_dw_bwd1)
+        const int oth = a.d_th / S, otw = a.d_tw / S;
+        const int th_in1 = (oth - 1) * S + K, tw_in1 = (otw - 1) * S + K;
+        const int ph1 = (a.d_th + K - 2) / S + 2, pw1 = (a.d_tw + K - 2) / S + 2;          // upper bound of the dz patch
+        const size_t lds1 = std::max((size_t)(ph1 * pw1 + th_in1 * tw_in1) * (cb + 4) + (size_t)kk * cb, (size_t)((256 / (cb / 4)) / K) * kk * cb + 2048) * 4;
+        if (lds1 > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward: LDS request %zu exceeds 160 KiB", lds1);
+        const int wblk1 = a.d_gx * c.p->B;
+        if ((size_t)wblk1 * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+        (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
+        int rc1 = check_launch("fd_dw_bwd1");
+        if (rc1) return rc1;
+        *nblk_out = a.d_gx * c.p->B;
+        return defer_weights(c, a.wpart, wblk1, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
+    }
+    const int wblk = a.w_gx * c.p->B;
     if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
     const long total = (long)c.p->B * ((long)a.d_gx * a.d_gy + (long)a.w_gx * a.w_gy);
     FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG>), dim3((unsigned)total), dim3(256), lds, c.s, a);

@@ -98,7 +98,7 @@ inline int *red_counters(fd_train_plan *p) { return reinterpret_cast<int *>(p->w
 
 template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
-                    T *zout, float *part, hipStream_t s)
+                    T *zout, float *part, hipStream_t s, int batch)
 {
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
 #define FD_DWT(K_, S_, M_)                                                                                                   \
@@ -118,12 +118,12 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
 // the skip tensor's activation, always an encoder unit)
 template <typename T>
 int dispatch_dw_train(const TLayer &L, int act1, int act2, const T *zin, const float *st1, const T *zskip, const float *st2,
-                      const float *w, T *zout, float *part, hipStream_t s)
+                      const float *w, T *zout, float *part, hipStream_t s, int batch)
 {
-    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
-    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s);
-    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
-    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
     return fail(FD_ERR_INVALID, "train: unsupported producer activations %d/%d", act1, act2);
 }
 
@@ -181,7 +181,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         case FD_OP_DW: {
             const TLayer *K = d.skip >= 0 ? &plan->layers[d.skip] : nullptr;
             rc = dispatch_dw_train<T>(L, P->d.act, K ? K->d.act : FD_ACT_RELU6, zin, st1, K ? twt<T>(plan, K->z_off) : (const T *)nullptr,
-                                      K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s);
+                                      K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s, plan->B);
             break;
         }
         case FD_OP_PW:
@@ -305,7 +305,12 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
-            L.wp_elems = (size_t)L.nblk * d.ksize * d.ksize * d.cin;
+            const int fwd_tiles = L.nblk;
+            {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
+                // up to 8 rows) -- sized for the larger count
+                const long bwd_tiles = (long)ceil_div(L.in_w, 16) * ceil_div(L.in_h, 6) * batch;
+                L.wp_elems = (size_t)std::max<long>(fwd_tiles, bwd_tiles) * d.ksize * d.ksize * d.cin;
+            }
             break;
         }
         case FD_OP_PW:

@@ -35,6 +35,8 @@ FD_PLAN_TUNE_NO_PW_PAIRING = 65536
 FD_PLAN_TUNE_PW_PAIR_TN2 = 131072
 FD_PLAN_TUNE_DW_CB16 = 262144
 FD_PLAN_TUNE_DW_TH8 = 524288
+FD_PLAN_TUNE_DW_BWD_PAIR = 8388608
+FD_PLAN_TUNE_DW_BWD1 = 16777216
 
 
 class LayerDesc(ctypes.Structure):
