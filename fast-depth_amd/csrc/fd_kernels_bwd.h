@@ -662,6 +662,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
+    constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
@@ -761,7 +762,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
                 sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
             }
             fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
-#pragma unroll FD_TAPROW_UNROLL(K)
+#pragma unroll UNR_TAPROWS
             for (int a = 0; a < K; ++a) {
                 const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
                 fd_f32x4 r[K + 3];
@@ -1098,6 +1099,7 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
+    constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
@@ -1250,7 +1252,7 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
                 sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
             }
             fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
-#pragma unroll FD_TAPROW_UNROLL(K)
+#pragma unroll UNR_TAPROWS
             for (int a = 0; a < K; ++a) {
                 const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
                 fd_f32x4 r[K + 3];

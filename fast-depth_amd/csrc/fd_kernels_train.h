@@ -24,9 +24,6 @@ __device__ long long fd_dw_probe[8 * 16384];
 #define FD_DW_PROBE_AT(k) ((void)0)
 #endif
 
-// 3x3 kernels: all tap rows of a strip unrolled (their LDS reads in flight together); 5x5: one row at a time (registers)
-#define FD_TAPROW_UNROLL(K_) ((K_) == 3 ? 3 : 1)
-
 // per-channel table written by fd_bn_finalize_f32:  [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) invstd
 #define FD_ST_SCALE 0
 #define FD_ST_SHIFT 1
@@ -162,6 +159,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
                     float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
 {
     constexpr int P = K / 2;
+    constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;           // 3x3: all tap rows of a strip unrolled (their LDS reads in flight together); 5x5: one row at a time (registers)
     constexpr int NIN = 3 * S + K;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
@@ -249,7 +247,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     for (int s = pt; s < nstrips; s += npt) {
         const int oy = s / TWS, ox = (s - oy * TWS) * 4;
         fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
-#pragma unroll FD_TAPROW_UNROLL(K)                              // 3x3: all 3 x NIN patch reads of a strip in flight at once (probe: the tap phase was a chain of LDS latencies)
+#pragma unroll UNR_TAPROWS                              // 3x3: all 3 x NIN patch reads of a strip in flight at once (probe: the tap phase was a chain of LDS latencies)
         for (int ky = 0; ky < K; ++ky) {
             const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
             fd_f32x4 r[NIN];
