@@ -18,9 +18,12 @@
 
 // workgroups the pointwise weight-gradient GEMM aims for (output tiles x pixel splits); every split writes a private fp32 partial
 // tile that fd_reduce_partials_f32 sums afterwards, so more splits = more parallelism but more partial traffic
-// (measured at batch 32: 2048 is best for the fp32 kernel, 1024 for the bf16 one whose MFMA part is 16x shorter)
+// (measured at batch 32: 2048 is best for the fp32 kernel; the bf16 one, whose MFMA part is 16x shorter, wants fewer)
+#ifndef FD_WGRAD_TUNE_H16
+#define FD_WGRAD_TUNE_H16 640      // (round 3, paired launch: 640 -> 2.840 ms per bf16 step, 1024 -> 2.877, 512 -> 2.860; fewer splits = fewer partial bytes)
+#endif
 #define FD_WGRAD_TARGET_WGS_F32 2048
-#define FD_WGRAD_TARGET_WGS_H16 1024
+#define FD_WGRAD_TARGET_WGS_H16 (FD_WGRAD_TUNE_H16)
 
 namespace {
 

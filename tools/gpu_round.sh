@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: smoke, gpu tests, bench, then ONE rocprofv3 invocation per configuration (kernel trace + stats) and the PMC passes.
 # Usage: gpurun --timeout 2400 -- bash tools/gpu_round.sh [tag] [skip-tests]
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -17,7 +17,7 @@ for cfg in infer train_f32 train_bf16 f16 bf16 pruned_f16; do
   find $OUT/prof_$cfg -name "*kernel_trace.csv" -size +20M -delete
 done
 echo "== rocprofv3 PMC passes (HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes; MFMA busy)"
-for cfg in infer train_bf16; do
+for cfg in infer train_bf16 train_f32 f16 pruned_f16; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${cfg}_$ctr -o p -- python $ROOT/bench.py --only $cfg --steps 3 --warmup 2 > /dev/null 2> $OUT/pmc_${cfg}_$ctr.err; echo "$cfg $ctr rc=$?"
   done

@@ -30,7 +30,7 @@ for cfg in CONFIGS:
     for k in rows[:14]:
         print("%-52s %6d %10.2f %10.3f %6.2f" % (k["kernel"][:52], k["calls"], k["avg_us"], k["total_ms"], k["pct"]))
     print()
-for cfg in ("infer", "train_bf16"):
+for cfg in ("infer", "train_bf16", "train_f32", "f16", "pruned_f16"):
     pmc = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         f = find("pmc_%s_%s/**/*counter_collection.csv" % (cfg, counter))
