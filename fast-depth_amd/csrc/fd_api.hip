@@ -9,12 +9,6 @@
 #include "fd_kernels_gemm16_f32.h"
 #include "fd_kernels_h16.h"
 #include "fd_kernels_gemm16_h16.h"
-// Off-by-default experiments (stream-K GEMM, fused depthwise+pointwise unit, side-stream weight gradients: all measured no faster, DESIGN.md
-// section 3) are compiled only with -DFD_EXPERIMENTS: the product library does not contain them; the emulator test build does.
-#ifdef FD_EXPERIMENTS
-#include "fd_kernels_sk_f32.h"
-#include "fd_kernels_fused_f32.h"
-#endif
 #include "fd_kernels_dwpw_f32.h"
 #include "../../include/fastdepth_hip.h"
 
@@ -132,8 +126,7 @@ struct Layer {
     bool skipped = false;        // depthwise layer executed inside the following pointwise layer's fused kernel
     int fuse_next_dw = -1;       // pointwise layer (fd_pw_gemm16_f32): index of the depthwise consumer evaluated in its epilogue
     int fused_into = -1;         // depthwise layer: index of the pointwise layer whose kernel produces this layer's output
-    int fused_dw = -1;           // pointwise layer: index of the depthwise layer fused into it
-    int np = 0, flat = 0, gpw = 0;   // fused kernel: patch pixels, tile mapping, LDS-DMA instructions per wave per chunk
+    int fused_dw = -1;           // pointwise layer: index of the depthwise layer that runs inside its fd_dwpw_f32 unit
     int fuse_head = -1;          // fd_dwpw_f32 unit: index of the 32 -> 1 pointwise head evaluated on its accumulators (that layer's fused_into = this one)
     bool dwpw = false;           // pointwise layer: fused_dw runs inside fd_dwpw_f32 (large maps: tile of pixels x all output channels)
     int dp_th = 0, dp_tw = 0 /* log2 of the tile width */, dp_tiles_x = 0, dp_wm = 0, dp_nt = 0, dp_nld = 0, dp_xcd = 0;
@@ -144,8 +137,6 @@ struct Layer {
     PwCfg pw{};
     int m_tiles = 0, n_tiles = 0, w_pitch = 0;
     int pw16_tm = 0, pw16_stride = 0;   // > 0: fd_pw_gemm16_f32 (16x16x4 MFMA, one workgroup per CU) with TM row tiles and this M stride per workgroup
-    bool sk = false;             // data-parallel rounds + stream-K remainder (fd_pw_gemm_sk_f32)
-    int sk_dp_rounds = 0, sk_base = 0, sk_rem = 0;
     size_t lds = 0;
     dim3 grid;
     std::string info, sym;
@@ -159,7 +150,6 @@ struct fd_plan {
     int B = 0, H = 0, W = 0, dtype = 0;
     uint32_t flags = 0;
     size_t ws_bytes = 0, weights_bytes = 0;
-    size_t sk_scratch_off = 0, sk_scratch_bytes = 0, sk_counter_off = 0, sk_counter_bytes = 0;   // stream-K partial tiles / per-tile arrival counters
     unsigned char *ws = nullptr;
     bool packed = false;
     double alg_bytes = 0, alg_flops = 0;
@@ -341,24 +331,6 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
         return check_launch("fd_pw_gemm16_f32");
     }
     const int key = L.pw.wgm * 1000 + L.pw.wgn * 100 + L.pw.tm * 10 + L.pw.tn;
-#ifdef FD_EXPERIMENTS
-    if (L.sk) {
-        float *scratch = reinterpret_cast<float *>(plan->ws + plan->sk_scratch_off);
-        int *counters = reinterpret_cast<int *>(plan->ws + plan->sk_counter_off);
-#define FD_SK_CASE(a, b, c, d) \
-    case a * 1000 + b * 100 + c * 10 + d: \
-        (void)hipFuncSetAttribute((const void *)fd_pw_gemm_sk_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        FD_LAUNCH((fd_pw_gemm_sk_f32<a, b, c, d, ACT>), L.grid, dim3(256), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.m_tiles, L.n_tiles, \
-                  L.sk_dp_rounds, L.sk_base, L.sk_rem, scratch, counters); break;
-        switch (key) {
-            FD_SK_CASE(2, 2, 2, 1)
-            FD_SK_CASE(2, 2, 1, 1)
-        default: return fail(FD_ERR_INVALID, "no stream-K pointwise tile %d", key);
-        }
-#undef FD_SK_CASE
-        return check_launch("fd_pw_gemm_sk_f32");
-    }
-#endif
 #define FD_PW_CASE(a, b, c, d) \
     case a * 1000 + b * 100 + c * 10 + d: \
         if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_pw_gemm_f32<a, b, c, d, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
@@ -375,26 +347,6 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
     return check_launch("fd_pw_gemm_f32");
 }
 
-#ifdef FD_EXPERIMENTS
-template <int K, int ACT2>
-int launch_sep_k(const fd_plan *p, const Layer &L, const Layer &D, const float *in, const float *wdw, const float *bdw, const float *wp,
-                 const float *bias, float *out, hipStream_t s)
-{
-    const int C = L.d.cin;
-#define FD_SEP(A1, G)                                                                                                             \
-    do {                                                                                                                          \
-        (void)hipFuncSetAttribute((const void *)fd_sep_unit_f32<K, A1, ACT2, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        FD_LAUNCH((fd_sep_unit_f32<K, A1, ACT2, G>), L.grid, dim3(256), L.lds, s, in, wdw, bdw, wp, bias, out, p->B, D.in_h, D.in_w, C,  \
-                  L.w_pitch, L.d.cout, L.np, L.flat, L.m_tiles, L.n_tiles);                                                       \
-    } while (0)
-#define FD_SEP_G(A1) do { if (L.gpw <= 5) FD_SEP(A1, 5); else if (L.gpw == 6) FD_SEP(A1, 6); else FD_SEP(A1, 7); } while (0)
-    if (D.d.act == FD_ACT_RELU6) FD_SEP_G(FD_ACT_RELU6_); else FD_SEP_G(FD_ACT_RELU_);
-#undef FD_SEP_G
-#undef FD_SEP
-    return check_launch("fd_sep_unit_f32");
-}
-
-#endif
 
 
 // depthwise + pointwise unit of a large map as one kernel (fd_kernels_dwpw_f32.h)
@@ -499,19 +451,6 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
             if constexpr (std::is_same<T, float>::value) return launch_dwpw<ACT>(p, L, out, y, s);
             else return fail(FD_ERR_INVALID, "fused units are fp32 only");
         }
-#ifdef FD_EXPERIMENTS
-        if (L.fused_dw >= 0) {
-            if constexpr (std::is_same<T, float>::value) {
-                const Layer &D = p->layers[L.fused_dw];
-                const float *din = reinterpret_cast<const float *>(p->ws + p->layers[D.d.src].out_off);
-                const float *wdw = reinterpret_cast<const float *>(p->ws + D.w_off), *bdw = reinterpret_cast<const float *>(p->ws + D.b_off);
-                if (D.d.ksize == 3) return launch_sep_k<3, ACT>(p, L, D, din, wdw, bdw, wpf, bias, out, s);
-                return launch_sep_k<5, ACT>(p, L, D, din, wdw, bdw, wpf, bias, out, s);
-            } else {
-                return fail(FD_ERR_INVALID, "fused units are fp32 only");
-            }
-        }
-#endif
         return launch_pw_t<ACT>(p, L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
     }
     return fail(FD_ERR_INVALID, "bad op");
@@ -550,14 +489,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
     if (dtype != FD_F32 && dtype != FD_F16 && dtype != FD_BF16) return fail(FD_ERR_INVALID, "unknown dtype %d", dtype);
-#ifndef FD_EXPERIMENTS
-    if (flags & (FD_PLAN_STREAMK | FD_PLAN_FUSE_SEPARABLE)) return fail(FD_ERR_INVALID, "this library was built without -DFD_EXPERIMENTS: the stream-K / fused-unit experiments are not in it");
-#endif
     fd_plan *p = new fd_plan();
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
     p->layers.resize(n_layers);
     const size_t esz = dtype == FD_F32 ? 4 : 2;   // activation / pointwise-weight element size
-    size_t woff = 0, sk_scratch = 0, sk_counters = 0;
+    size_t woff = 0;
     for (int i = 0; i < n_layers; ++i) {
         Layer &L = p->layers[i];
         L.d = layers[i];
@@ -658,26 +594,6 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                         L.lds = (size_t)(dtype == FD_F32 ? 3 : 4) * (c16.tm * 16 + 64) * 32 * 4;   // (128-byte rows in both kernels; the 16-bit one runs a 4-stage ring)
                         L.m_tiles = ceil_div(M, c16.stride); L.n_tiles = ceil_div(d.cout, 64);
                         L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
-                    }
-                }
-                // EXPERIMENTAL, opt-in (FD_PLAN_STREAMK): measured on MI355X at batch 32 the balanced decomposition takes exactly as long as
-                // the plain launch (conv7.3: 40.2 vs 40.0 us, conv13.3: 40.3 vs 39.9 us) -- see fd_kernels_sk_f32.h
-                if (dtype == FD_F32 && (flags & FD_PLAN_STREAMK) && !L.pw16_tm && L.pw.wgm == 2 && L.pw.wgn == 2 && L.pw.tn == 1) {
-                    // resident capacity: 256 CUs x (160 KiB LDS / ring size); one workgroup per slot
-                    const int per_cu = std::min(4, (int)(160 * 1024 / (L.lds + 256)));
-                    const int P = 256 * per_cu;
-                    const long tiles = (long)L.m_tiles * L.n_tiles;
-                    const int T = L.w_pitch / 32;
-                    const double eff = (double)tiles / ((double)ceil_div(tiles, P) * P);      // last-round occupancy of the plain launch
-                    (void)eff;
-                    if (T >= 2) {
-                        L.sk = true;
-                        L.sk_dp_rounds = (int)(tiles / P);
-                        const long units = (tiles % P) * T;
-                        L.sk_base = (int)(units / P); L.sk_rem = (int)(units % P);
-                        L.grid = dim3((unsigned)P);
-                        sk_scratch = std::max(sk_scratch, (size_t)P * 2 * (L.pw.wgm * L.pw.tm * 32) * (L.pw.wgn * L.pw.tn * 32) * 4);
-                        sk_counters = std::max(sk_counters, (size_t)P * 4);
                     }
                 }
             }
@@ -795,7 +711,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             }
             if (best < 0) continue;
             D.skipped = true;
-            Pw.fused_dw = i; Pw.dwpw = true; Pw.pw16_tm = 0; Pw.sk = false;
+            Pw.fused_dw = i; Pw.dwpw = true; Pw.pw16_tm = 0;
             Pw.dp_th = bth; Pw.dp_tw = btw; Pw.dp_tiles_x = ceil_div(D.out_w, 1 << btw); Pw.dp_wm = wm; Pw.dp_nt = nt; Pw.dp_nld = nld;
             const long tiles = (long)Pw.dp_tiles_x * ceil_div(D.out_h, bth) * batch;
             Pw.dp_xcd = batch >= 8 ? 1 : 0;                    // images dealt to XCDs (b mod 8); small batches: tiles dealt round-robin
@@ -807,31 +723,6 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 Layer &H = p->layers[i + 2];
                 if (H.head && H.d.src == i + 1 && H.d.skip < 0 && readers[i + 1] == 1 && H.d.cin == 32) { Pw.fuse_head = i + 2; H.fused_into = i + 1; }
             }
-        }
-    }
-
-    // ---- fusion: depthwise (stride 1, input as stored) -> pointwise pairs become ONE kernel (fd_sep_unit_f32) -------------
-    // EXPERIMENTAL, opt-in (FD_PLAN_FUSE_SEPARABLE): measured on MI355X at batch 32 the fused kernel is SLOWER than the two tuned
-    // kernels it replaces (conv7.3: 87 us vs 11.5 + 41 us) -- with M = 6272 rows the depthwise work is recomputed by each of the
-    // N/64 column tiles, and the two phases of a workgroup serialise behind barriers.  Kept for larger batches / future tuning.
-    if (dtype == FD_F32 && (flags & FD_PLAN_FUSE_SEPARABLE) && !(flags & FD_PLAN_KEEP_ACTIVATIONS)) {
-        for (int i = 0; i + 1 < n_layers; ++i) {
-            Layer &D = p->layers[i], &Pw = p->layers[i + 1];
-            if (D.d.op != FD_OP_DW || D.mode != 0 || D.d.stride != 1 || Pw.d.op != FD_OP_PW || Pw.head || Pw.d.src != i) continue;
-            const int P = D.d.ksize / 2, W = D.in_w, H = D.in_h;
-            int np = 0, flat = 0;
-            if (W <= 28 && (64 + 2 * P * (W + 1) + 7) / 8 * 8 <= 128) { flat = 1; np = (64 + 2 * P * (W + 1) + 7) / 8 * 8; }
-            else if (W % 8 == 0 && H % 8 == 0 && ((8 + 2 * P) * (8 + 2 * P) + 7) / 8 * 8 <= 128) { flat = 0; np = ((8 + 2 * P) * (8 + 2 * P) + 7) / 8 * 8; }
-            else continue;
-            D.skipped = true;
-            Pw.fused_dw = i; Pw.np = np; Pw.flat = flat;
-            Pw.pw = PwCfg{2, 2, 1, 1};
-            Pw.m_tiles = flat ? ceil_div((long)batch * H * W, 64) : batch * (H / 8) * (W / 8);
-            Pw.n_tiles = ceil_div(Pw.d.cout, 64);
-            Pw.grid = dim3((unsigned)((Pw.m_tiles + 7) / 8 * 8 * Pw.n_tiles));
-            const int taprows = (D.d.ksize * D.d.ksize + 7) / 8 * 8;
-            Pw.lds = ((size_t)3 * (np * 32 + 64 * 32 + taprows * 32) + 64 * 32 + 256) * 4;   // 3-stage ring + A tile + dump group
-            Pw.gpw = (np / 8 + 8 + taprows / 8 + 3) / 4;
         }
     }
 
@@ -866,11 +757,6 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         if (L.fuse_next_dw >= 0) p->layers[L.fuse_next_dw].out_off = woff + fl.alloc(p->layers[L.fuse_next_dw].out_bytes);
     }
     p->ws_bytes = woff + fl.top;
-    if (sk_scratch) {
-        p->sk_scratch_off = align_up(p->ws_bytes, 256); p->sk_scratch_bytes = sk_scratch;
-        p->sk_counter_off = p->sk_scratch_off + align_up(sk_scratch, 256); p->sk_counter_bytes = sk_counters;
-        p->ws_bytes = p->sk_counter_off + align_up(sk_counters, 256);
-    }
 
     // bookkeeping: algorithmic traffic and descriptions (SURVEY.md 8(d) convention)
     for (int i = 0; i < n_layers; ++i) {
@@ -898,9 +784,6 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             snprintf(buf, sizeof buf, "dwpw<dw k%d s%d mode%d + pw> persistent, 4 producer + 4 consumer waves; tile %dx%d px x all %d channels, C=%d in %d chunks, weights in LDS, grid=%u lds=%zu%s", p->layers[L.fused_dw].d.ksize,
                      p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, L.dp_th, 1 << L.dp_tw, d.cout, d.cin, d.cin / 32, L.grid.x, L.lds,
                      L.fuse_head >= 0 ? " + the 32->1 head on the accumulators" : "");
-        else if (L.fused_dw >= 0)
-            snprintf(buf, sizeof buf, "sep_unit_f32<dw k%d + pw> %s tile, patch %d px, M=%ld N=%d K=%d tiles=%dx%d lds=%zu", p->layers[L.fused_dw].d.ksize,
-                     L.flat ? "flat-64" : "8x8", L.np, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
         else if (d.op == FD_OP_STEM)
             snprintf(buf, sizeof buf, "stem3x3s2<mfma 32x32x2, LDS-staged rows, 256 px per workgroup> grid=%ux%u lds=%zu", L.grid.x, L.grid.y, L.lds);
         else if (d.op == FD_OP_DW && L.dw_rows)
@@ -911,11 +794,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (L.head)
             snprintf(buf, sizeof buf, "head_pw1 up=%d grid=%u", d.upsample, L.grid.x);
         else
-            if (L.sk)
-                snprintf(buf, sizeof buf, "pw_gemm_sk<%dx%d> M=%ld N=%d K=%d tiles=%dx%d on %u workgroups: %d full round(s) + stream-K %d.%03d K-tiles each, lds=%zu",
-                         L.pw.wgm * L.pw.tm * 32, L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.grid.x,
-                         L.sk_dp_rounds, L.sk_base, (int)(1000L * L.sk_rem / L.grid.x), L.lds);
-            else if (L.pw16_tm)
+            if (L.pw16_tm)
                 snprintf(buf, sizeof buf, "pw_gemm16<TM=%d: %dx64 tile, stride %d> M=%ld N=%d K=%d tiles=%dx%d (%.2f per CU) lds=%zu", L.pw16_tm, L.pw16_tm * 16, L.pw16_stride,
                          (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.m_tiles * L.n_tiles / 256.0, L.lds),
                 L.fuse_next_dw >= 0 ? (void)snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " + fused dw k%d of layer %d", p->layers[L.fuse_next_dw].d.ksize, L.fuse_next_dw) : (void)0;
@@ -926,14 +805,13 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
         if (L.skipped || L.fused_into >= 0) buf[0] = 0;
         else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld, L.fuse_head >= 0 ? 1 : 0);
-        else if (L.fused_dw >= 0) snprintf(buf, sizeof buf, "fd_sep_unit_f32<%d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.act, d.act, L.gpw <= 5 ? 5 : (L.gpw == 6 ? 6 : 7));
         else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows<%s, %d, %d>", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
         else if (L.pw16_tm && dtype != FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm16_h16<%s, %d, 4, %d, %d>", tn, L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0, %d>", L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
-        else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_%sf32<%d, %d, %d, %d, %d>", L.sk ? "sk_" : "", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
+        else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);
         L.sym = buf;
     }
@@ -981,9 +859,6 @@ int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n
                                reinterpret_cast<float *>(plan->ws + L.w_off), bptr, L.d.cout, inner, transpose, pitch);
         int rc = check_launch("fd_pack_fold");
         if (rc) return rc;
-    }
-    if (plan->sk_counter_bytes) {   // stream-K arrival counters start at 0 (the kernels return them to 0)
-        if (hipMemsetAsync(plan->ws + plan->sk_counter_off, 0, plan->sk_counter_bytes, s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync(stream-K counters) failed");
     }
     plan->packed = true;
     return FD_OK;
@@ -1095,7 +970,6 @@ int fd_plan_import_weights(fd_plan *plan, const void *host_buffer, size_t bytes,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemcpyAsync(plan->ws, w, h.weights_bytes, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return fail(FD_ERR_HIP, "copying the packed weights to the device failed");
-    if (plan->sk_counter_bytes && hipMemsetAsync(plan->ws + plan->sk_counter_off, 0, plan->sk_counter_bytes, s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync failed");
 #endif
     plan->packed = true;
     return FD_OK;

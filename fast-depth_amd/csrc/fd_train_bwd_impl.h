@@ -11,28 +11,11 @@ struct BwdCtx {
     // weight-gradient partials of the units processed so far in this range: reduced by ONE launch at the end of the range
     // (fd_reduce_weights_batch_f32)
     fd_wbatch wb{};
-    hipStream_t ws = nullptr;        // stream of the weight-gradient kernels (the plan's side stream, or s when concurrency is off)
 };
-
-// fork: the side stream continues from the caller's stream; join: the caller's stream waits for the side stream
-int fork_side(BwdCtx &c)
-{
-    if (c.ws == c.s) return FD_OK;
-    if (hipEventRecord(c.p->ev_fork, c.s) != hipSuccess || hipStreamWaitEvent(c.ws, c.p->ev_fork, 0) != hipSuccess) return fail(FD_ERR_HIP, "stream fork failed");
-    return FD_OK;
-}
-int join_side(BwdCtx &c)
-{
-    if (c.ws == c.s) return FD_OK;
-    if (hipEventRecord(c.p->ev_join, c.ws) != hipSuccess || hipStreamWaitEvent(c.s, c.p->ev_join, 0) != hipSuccess) return fail(FD_ERR_HIP, "stream join failed");
-    return FD_OK;
-}
 
 int flush_weights(BwdCtx &c)
 {
     if (!c.wb.count) return FD_OK;
-    int jrc = join_side(c);                                   // (experiment builds: the weight-gradient kernels ran on the side stream)
-    if (jrc) return jrc;
     FD_LAUNCH(fd_reduce_weights_batch_f32, dim3((unsigned)c.wb.cb_start[c.wb.count]), dim3(1024), 0, c.s, c.wb);
     c.wb.count = 0;
     return check_launch("fd_reduce_weights_batch_f32");
@@ -123,10 +106,9 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const size_t wlds = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
     if (wlds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise wgrad: LDS request %zu exceeds 64 KiB", wlds);
     const int wblk = groups_x * L.tiles_y * c.p->B;
-    { int frc = fork_side(c); if (frc) return frc; }
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
-        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.ws, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
+        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
                   L.cbq, L.th, L.tw, L.tiles_x, tpw, L.csplit);                                                                    \
@@ -260,7 +242,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     splits = ceil_div(M, rows);
     if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
     // backward data: 64 x 128 tiles of G_in when there are >= 128 input channels and that still leaves >= 200 workgroups: every dz fragment feeds two MFMAs
-    const bool pair = !(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING)) && !c.p->concurrent_wgrad;
+    const bool pair = !(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING));
     int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
     if (pair && !(c.p->flags & FD_PLAN_TUNE_PW_PAIR_TN2)) tn = 1;   // paired launch: 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74: the weight-gradient workgroups share it) -- measured 554 vs 583 us per bf16 step
     const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
@@ -285,10 +267,9 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         return defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
     }
     {
-        if ((rc = fork_side(c))) return rc;
         // (two k tiles per workgroup -- fd_pw_wgrad_h16<.., 2>, the staged dz tile feeding twice the MFMAs -- measured slower: 22.3 vs 20.9 us on the
         // 512 x 512 units, 3 instead of 5 workgroups per CU and half as many of them)
-        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN, 1>), dim3(n_tiles * k_tiles_w, splits), dim3(256), FD_PW_WGRAD_H16_LDS(1), c.ws, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
+        FD_LAUNCH((fd_pw_wgrad_h16<T, ACT_IN, 1>), dim3(n_tiles * k_tiles_w, splits), dim3(256), FD_PW_WGRAD_H16_LDS(1), c.s, G, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, L.wp_off), M, N, K, k_tiles_w, rows);
         if ((rc = check_launch("fd_pw_wgrad_h16"))) return rc;
         if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
@@ -328,7 +309,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     const unsigned n_dgrad = (unsigned)((m_tiles + 7) / 8 * 8 * k_tiles);
     *nblk = m_tiles;
     int rc;
-    if (!(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING)) && !c.p->concurrent_wgrad) {
+    if (!(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING))) {
         const size_t lds = std::max(lds_w, lds_d);
         const int tiles_w = n_tiles * k_tiles;
         const dim3 grid(n_dgrad + (unsigned)(tiles_w * splits));
@@ -346,8 +327,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     }
     {
         (void)hipFuncSetAttribute((const void *)fd_pw_wgrad_f32<ACT_IN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-        { int frc = fork_side(c); if (frc) return frc; }
-        FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds_w, c.ws, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
+            FD_LAUNCH((fd_pw_wgrad_f32<ACT_IN>), dim3(n_tiles * k_tiles, splits), dim3(256), lds_w, c.s, G, Z, coef, tws(c.p, P.z_off), tws(c.p, P.st_off),
                   tws(c.p, L.wp_off), M, N, K, k_tiles, rows);
         if ((rc = check_launch("fd_pw_wgrad_f32"))) return rc;
         if ((rc = defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight))) return rc;
@@ -373,15 +353,6 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
 {
     constexpr bool F32 = std::is_same<T, float>::value;
     BwdCtx c{plan, params, grads, static_cast<hipStream_t>(stream)};
-    c.ws = c.s;
-    if (plan->concurrent_wgrad) {
-        if (!plan->side) {
-            if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess)
-                return fail(FD_ERR_HIP, "could not create the side stream of the backward pass");
-        }
-        c.ws = plan->side;
-    }
     hipStream_t s = c.s;
     float *part = tws(plan, plan->part_off);
     int rc;
@@ -425,7 +396,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             break;
         }
         case FD_OP_DW: {
-            if (!(plan->flags & FD_PLAN_NO_BWD_PAIRING) && !plan->concurrent_wgrad) {
+            if (!(plan->flags & FD_PLAN_NO_BWD_PAIRING)) {
                 bool paired = false;
                 if ((rc = dispatch_dw_bwd_pair<T>(c, i, &nblk, &paired))) return rc;
                 if (paired) {

@@ -67,18 +67,6 @@ struct fd_train_plan {
     bool forward_done = false;
     float eps = 1e-5f;
     const void *x_saved = nullptr;   // the network input of the last forward (the stem's weight gradient re-reads it)
-    // backward, opt-in experiment: a unit's weight-gradient kernel runs on this side stream, concurrently with its backward-data
-    // kernel on the caller's stream (fork / join by events; both only read dz and the saved tensors).  Created lazily, owned by
-    // the plan.  Like every other multi-stream attempt on this path it lost to plain in-order launches.
-    bool concurrent_wgrad = false;   // EXPERIMENT (plan flag FD_PLAN_CONCURRENT_WGRAD, builds with -DFD_EXPERIMENTS only): measured slower at batch 32 (bf16 3.72 vs 3.33 ms, fp32 5.30 vs 5.10 ms)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    ~fd_train_plan()
-    {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
-    }
 };
 
 namespace {
@@ -247,11 +235,6 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         return fail(FD_ERR_INVALID, "train plan: dtype %d not supported (fp32 or bf16; fp16 gradients would need loss scaling)", dtype);
     fd_train_plan *p = new fd_train_plan();
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
-#ifdef FD_EXPERIMENTS
-    p->concurrent_wgrad = (flags & FD_PLAN_CONCURRENT_WGRAD) != 0;
-#else
-    if (flags & FD_PLAN_CONCURRENT_WGRAD) { delete p; return fail(FD_ERR_INVALID, "this library was built without -DFD_EXPERIMENTS: side-stream weight gradients are not in it"); }
-#endif
     const bool h16 = dtype != FD_F32;
     const size_t esz = h16 ? 2 : 4;
     p->esz = esz;

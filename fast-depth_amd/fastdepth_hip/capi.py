@@ -20,12 +20,9 @@ DTYPE_OF = _DtypeMap()      # torch dtype -> fd_dtype (torch imported lazily: th
 FD_OP_STEM, FD_OP_DW, FD_OP_PW = 0, 1, 2
 FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
 FD_PLAN_KEEP_ACTIVATIONS = 1
-FD_PLAN_FUSE_SEPARABLE = 4
 FD_PLAN_WGRAD_TILE_ROWS = 8
-FD_PLAN_STREAMK = 32
 FD_PLAN_FORCE_GEMM16 = 16
 FD_PLAN_NO_GEMM16 = 64
-FD_PLAN_CONCURRENT_WGRAD = 128
 FD_PLAN_NO_EPILOGUE_FUSION = 512
 FD_PLAN_NO_UNIT_FUSION = 1024
 FD_PLAN_FORCE_UNIT_FUSION = 2048

@@ -67,11 +67,8 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_TUNE_DW_TH8 524288u        /* tuning aid (train plans): depthwise tiles of 8 rows with a ragged last tile (round 1/2) instead of balanced row counts */
 #define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
-/* The three flags below select experiments that were measured no faster than the default path; they exist only in
- * libraries built with -DFD_EXPERIMENTS (the emulator test build), the product library rejects them. */
-#define FD_PLAN_CONCURRENT_WGRAD 128u /* experimental (train plans): a unit's weight-gradient kernel runs on a side stream next to its backward-data kernel */
-#define FD_PLAN_STREAMK 32u         /* experimental: fp32 pointwise layers with >= 2 K tiles run as data-parallel rounds + a stream-K remainder (fd_kernels_sk_f32.h); measured no faster at batch 32, and results then depend (in the last bits) on a frame's position in the batch */
-#define FD_PLAN_FUSE_SEPARABLE 4u   /* experimental: run depthwise(stride 1)+pointwise pairs as ONE kernel (fd_sep_unit_f32); measured slower at batch 32 */
+/* (bits 4, 32 and 128 selected round-1 / round-2 experiments -- a separable-unit kernel, a stream-K GEMM, side-stream weight gradients -- that were
+ * measured no faster and have been removed; DESIGN.md section 10 keeps the measurements.) */
 
 typedef struct fd_layer_desc {
     int32_t op;       /* enum fd_op */

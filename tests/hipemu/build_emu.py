@@ -17,7 +17,7 @@ def build(force=False):
                                                                 os.path.join(REPO, "include", "fastdepth_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DFD_EMU", "-DFD_EXPERIMENTS", "-I", HERE, "-Wall",
+    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DFD_EMU", "-I", HERE, "-Wall",
            "-Wno-unused-function", "-Wno-unused-variable", "-Wno-psabi", "-Wno-comment", "-mavx2", os.path.join(CSRC, "fd_api.hip"), "-o", OUT]
     subprocess.check_call(cmd)
     return OUT

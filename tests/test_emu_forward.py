@@ -34,19 +34,6 @@ def test_emulated_forward_matches_oracle(name, plan, b, hw):
     assert err < TOL
 
 
-def test_emulated_stream_k_gemm_matches_oracle():
-    """fd_pw_gemm_sk_f32 (opt-in: data-parallel rounds + stream-K remainder, partial tiles reduced by the last arriver) on every
-    pointwise layer with >= 2 K tiles of the ragged plan -- tiles << workgroups here, so every tile is split across several
-    workgroups and goes through the scratch / counter path."""
-    m = small_model(RAGGED[0], RAGGED[1], seed=11)
-    g = torch.Generator().manual_seed(6)
-    x = torch.rand(1, 3, 32, 32, generator=g)
-    err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), flags=harness.capi.FD_PLAN_STREAMK)
-    assert sum("pw_gemm_sk" in s for s in info) >= 10, info
-    bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
-    assert not bad and err < TOL, bad
-
-
 @pytest.mark.parametrize("name,plan,b,hw", [("ragged", RAGGED, 2, (32, 96)), ("tiny", TINY, 2, 64)])
 def test_emulated_gemm16_matches_oracle(name, plan, b, hw):
     """fd_pw_gemm16_f32 (16x16x4 MFMA, k-split wave pairs, leader/follower LDS-DMA, LDS-transposed epilogue) forced onto every
@@ -126,24 +113,6 @@ def test_emulated_16bit_forward_matches_oracle(name, plan, dtype, tol):
     err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), dtype=dtype)
     assert err < tol, (err, max(per_layer))
     assert max(per_layer) < 4 * tol, [(i, e, info[i]) for i, e in enumerate(per_layer) if e >= 4 * tol]
-
-
-@pytest.mark.parametrize("name,plan,hw", [("tiny", TINY, (64, 64)), ("ragged", RAGGED, (64, 64)), ("tiny_rect", TINY, (32, 96)), ("tiny128", TINY, (128, 128))])
-def test_emulated_fused_separable_units(name, plan, hw):
-    """Opt-in plans (FD_PLAN_FUSE_SEPARABLE) fuse depthwise(stride 1) + pointwise pairs into fd_sep_unit_f32 (flat-64 tiles on small
-    maps, 8x8 tiles on maps whose sides are multiples of 8).  Checked against the oracle relative to the output's RANGE (the head bias dominates max|y|)."""
-    import numpy as np
-    from oracle import oracle
-    m = small_model(plan[0], plan[1], seed=1).eval()
-    m.decode_conv6[1].bias.data.fill_(1.0)
-    x = torch.rand(1 if hw[0] > 64 else 2, 3, *hw, generator=torch.Generator().manual_seed(2))
-    yo = oracle.forward(m.state_dict(), x.numpy())
-    cp = harness.CPlan("emu", m, x, keep=False, flags=harness.capi.FD_PLAN_FUSE_SEPARABLE)
-    info = cp.info()
-    y = cp.forward(x).numpy()
-    cp.close()
-    assert sum("sep_unit" in i for i in info) == 10 and sum("fused into" in i for i in info) == 10
-    assert float(np.abs(y - yo).max()) / float(yo.max() - yo.min()) < 1e-4
 
 
 def test_emulated_no_skip_sibling_forward():
