@@ -20,8 +20,11 @@
 #ifdef FD_DW_PROBE
 __device__ long long fd_dw_probe[8 * 16384];
 #define FD_DW_PROBE_AT(k) do { if (threadIdx.x == 0) { const unsigned b_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (b_ < 16384) fd_dw_probe[8 * b_ + (k)] = clock64(); } } while (0)
+__device__ int fd_dw_abl;                                 // ablation bits (microbench): 1 = no output stores, 2 = no patch loads
+#define FD_DW_ABL(b) ((fd_dw_abl & (b)) != 0)
 #else
 #define FD_DW_PROBE_AT(k) ((void)0)
+#define FD_DW_ABL(b) false
 #endif
 
 // per-channel table written by fd_bn_finalize_f32:  [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) invstd
@@ -215,7 +218,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
             const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
             const int ql = c_ok ? cl : 0, qg = c_ok ? cg : 0;
             if (MODE == 0) {
-                v[u] = fd_ld4(zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                v[u] = FD_DW_ABL(2) ? fd_zero4() : fd_ld4(zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
             } else {
                 const int Hs = Hin >> 1, Ws = Win >> 1;
                 if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C2 + ql);
@@ -267,7 +270,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
                 const int gx = ox0 + ox + j;
                 if (gx < Wo) {
                     const fd_f32x4 zr = fd_round4(T{}, acc[j]);
-                    fd_st4(zout + (((long)n * Ho + gy) * Wo + gx) * C + cg, zr);
+                    if (!FD_DW_ABL(1)) fd_st4(zout + (((long)n * Ho + gy) * Wo + gx) * C + cg, zr);
                     ssum += zr; ssq += zr * zr;
                 }
             }

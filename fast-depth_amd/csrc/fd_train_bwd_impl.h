@@ -95,23 +95,24 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     float *wpart = tws(c.p, L.wp_off);
     // tiles per workgroup (along x): as many as keep >= ~1536 workgroups in flight
-    const int ncb_w = ceil_div(L.d.cin, 4 << L.cbq);          // (the forward launch may be persistent: its grid is not the tile grid)
-    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.tiles_x * L.tiles_y * ncb_w * c.p->B / 1536)));
-    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
-    const int groups_x = ceil_div(L.tiles_x, tpw);
-    tpw = ceil_div(L.tiles_x, groups_x);
-    const dim3 wgrid(groups_x * L.tiles_y, ncb_w, c.p->B);
+    const int ncb_w = ceil_div(L.d.cin, 4 << L.cbq);
+    const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);     // the backward-weights kernel's own output tiles (the forward's may be larger)
+    int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ncb_w * c.p->B / 1536)));
+    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = btx;
+    const int groups_x = ceil_div(btx, tpw);
+    tpw = ceil_div(btx, groups_x);
+    const dim3 wgrid(groups_x * bty, ncb_w, c.p->B);
     // LDS: activated input patch + dz tile, both [pixels][cb + 4] floats; the final reduction (npt/K groups x K*K taps x cb) reuses it
-    const int cbw = 4 << L.cbq, th_in = (L.th - 1) * L.d.stride + L.d.ksize, tw_in = (L.tw - 1) * L.d.stride + L.d.ksize;
-    const size_t wlds = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
+    const int cbw = 4 << L.cbq, th_in = (L.bth - 1) * L.d.stride + L.d.ksize, tw_in = (L.btw - 1) * L.d.stride + L.d.ksize;
+    const size_t wlds = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
     if (wlds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise wgrad: LDS request %zu exceeds 64 KiB", wlds);
-    const int wblk = groups_x * L.tiles_y * c.p->B;
+    const int wblk = groups_x * bty * c.p->B;
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
         FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
-                  L.cbq, L.th, L.tw, L.tiles_x, tpw, L.csplit);                                                                    \
+                  L.cbq, L.bth, L.btw, btx, tpw, L.csplit);                                                                    \
         break;
     switch (key) {
         FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2) FD_DWW(5, 1, 3)
@@ -159,13 +160,14 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const int ph = (a.d_th - 1 + K / 2) / S + (K - 1) / S + 3, pw = (a.d_tw - 1 + K / 2) / S + (K - 1) / S + 3;
     const size_t lds_d = dw_bwd_lds(ph, pw, cb, K);
     // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
-    int tpw = std::max(1, std::min(L.tiles_x, (int)((long)L.tiles_x * L.tiles_y * ceil_div(L.d.cin, cb) * c.p->B / 1536)));
-    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = L.tiles_x;
-    const int groups_x = ceil_div(L.tiles_x, tpw);
-    tpw = ceil_div(L.tiles_x, groups_x);
-    a.w_th = L.th; a.w_tw = L.tw; a.w_tiles_x = L.tiles_x; a.w_tpw = tpw; a.w_gx = groups_x * L.tiles_y; a.w_gy = ceil_div(L.d.cin, cb);
-    const int th_in = (L.th - 1) * S + K, tw_in = (L.tw - 1) * S + K;
-    const size_t lds_w = std::max((size_t)(th_in * tw_in + L.th * L.tw) * (cb + 4), (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
+    const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);
+    int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ceil_div(L.d.cin, cb) * c.p->B / 1536)));
+    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = btx;
+    const int groups_x = ceil_div(btx, tpw);
+    tpw = ceil_div(btx, groups_x);
+    a.w_th = L.bth; a.w_tw = L.btw; a.w_tiles_x = btx; a.w_tpw = tpw; a.w_gx = groups_x * bty; a.w_gy = ceil_div(L.d.cin, cb);
+    const int th_in = (L.bth - 1) * S + K, tw_in = (L.btw - 1) * S + K;
+    const size_t lds_w = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * (cb + 4), (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
     const size_t lds = std::max(lds_d, lds_w);
     if (lds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 64 KiB", lds);
     const int kk = K * K;

@@ -33,7 +33,8 @@ struct TLayer {
     bool head = false;
     int mode = 0;
     int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
-    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling
+    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
+    int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
     int chunk = 0;                                            // stem
     int m_tiles = 0, n_tiles = 0, pw_tn = 1;                  // pw (pw_tn: 32-column tiles per wave of the 16-bit forward GEMM)
     size_t lds = 0;
@@ -94,6 +95,7 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
 #define FD_DWT(K_, S_, M_)                                                                                                   \
     case K_ * 100 + S_ * 10 + M_:                                                                                            \
+        if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
         FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
                   L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit);                        \
         break;
@@ -286,12 +288,22 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.cbq = ilog2(cb / 4);
             L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : 16);
             L.th = (flags & FD_PLAN_TUNE_DW_TH8) ? std::min(L.out_h, 8) : ceil_div(L.out_h, ceil_div(L.out_h, 8));   // balanced rows: 14 -> 7 + 7 instead of 8 + 6 (both tiles full, smaller patches: one more workgroup per CU)
+            // The backward kernels keep these tiles (L.bth / L.btw).  The FORWARD kernel takes larger ones on stride-1 units: a workgroup's life is dominated
+            // by fixed costs (tap / table loads ~2 us, barriers, the reduction: 4 us even with no patch loads or stores at all --
+            // tools/microbench/dwtrain.hip), so fewer, fatter workgroups win until the patch staging takes too many load rounds:
+            // measured 56x56x128: 7x16 39.4 us, 14x28 30.4; 28x28x256: 20.3 -> 14.6; 112x112x32: 8x16 34.9 -> 16x16 32.1; 14x14: 7x16 10.6 -> 14x16 9.1
+            L.bth = L.th; L.btw = L.tw;
+            // (3x3 units only: the 5x5 decoder units LOSE with larger tiles -- 34 -> 50 us at 56x56, their patch staging takes too many load rounds)
+            if (d.stride == 1 && d.ksize == 3 && !(flags & FD_PLAN_TUNE_DW_SMALL_TILES)) {
+                L.th = L.out_h <= 14 ? L.out_h : (L.out_h <= 56 ? 14 : 16);
+                L.tw = L.out_w <= 16 ? (L.out_w + 3) / 4 * 4 : (L.out_w <= 56 ? 28 : 16);
+            }
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
             L.lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
-            const int fwd_tiles = L.nblk;
+            const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
                 // up to 8 rows) -- sized for the larger count
                 const long bwd_tiles = (long)ceil_div(L.in_w, 16) * ceil_div(L.in_h, 6) * batch;
@@ -333,7 +345,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         default: FD_BAD("layer %d: unknown op", i);
         }
         // (the 16-bit pointwise forward kernel raises its dynamic-LDS limit itself; the other train kernels stay within the default 64 KiB)
-        if (L.lds > ((h16 && d.op == FD_OP_PW && !L.head) ? 160 : 64) * 1024) FD_BAD("layer %d: LDS request %zu exceeds the limit", i, L.lds);
+        if (L.lds > (((h16 && d.op == FD_OP_PW && !L.head) || d.op == FD_OP_DW) ? 160 : 64) * 1024) FD_BAD("layer %d: LDS request %zu exceeds the limit", i, L.lds);
         L.M = (long)batch * L.out_h * L.out_w;
         L.z_elems = (size_t)L.M * d.cout;
         L.n_stat = (double)L.M;

@@ -34,6 +34,7 @@ FD_PLAN_TUNE_DW_CB16 = 262144
 FD_PLAN_TUNE_DW_TH8 = 524288
 FD_PLAN_TUNE_DW_BWD_PAIR = 8388608
 FD_PLAN_TUNE_DW_BWD1 = 16777216
+FD_PLAN_TUNE_DW_SMALL_TILES = 33554432
 
 
 class LayerDesc(ctypes.Structure):

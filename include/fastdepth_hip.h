@@ -64,6 +64,7 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_TUNE_PW_PAIR_TN2 131072u   /* tuning aid (16-bit train plans): the paired pointwise backward launch keeps the 64 x 128 backward-data tiles of the unpaired kernel (74 KB of LDS per workgroup instead of 49) */
 #define FD_PLAN_TUNE_DW_BWD1 16777216u     /* tuning aid / tests (train plans): every depthwise unit's backward runs as the single-staging kernel fd_dw_bwd1 (default: the stride-2 units only, where it was measured to pay) */
 #define FD_PLAN_TUNE_DW_BWD_PAIR 8388608u  /* tuning aid (train plans): a depthwise unit's backward runs as the paired launch of its two separate kernels (fd_dw_bwd) instead of the single-staging kernel fd_dw_bwd1 (which the stride-2 units use by default) */
+#define FD_PLAN_TUNE_DW_SMALL_TILES 33554432u /* tuning aid (train plans): the depthwise FORWARD kernel keeps the 7..8 x 16 output tiles of the backward kernels instead of its larger ones (14 x 28, 16 x 16, whole 14 x 14 frames) */
 #define FD_PLAN_TUNE_DW_TH8 524288u        /* tuning aid (train plans): depthwise tiles of 8 rows with a ragged last tile (round 1/2) instead of balanced row counts */
 #define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */

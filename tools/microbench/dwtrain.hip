@@ -6,7 +6,8 @@
 #include <vector>
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
-static void run(int B, int H, int C, int th, int tw) {
+static void run(int B, int H, int C, int th, int tw, int abl = 0, size_t extra_lds = 0) {
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(fd_dw_abl), &abl, 4));
   const int cb = 32, K = 3;
   const size_t n = (size_t)B * H * H * C;
   fd_bf16 *zin, *zout; float *st, *w, *part;
@@ -17,7 +18,8 @@ static void run(int B, int H, int C, int th, int tw) {
   CK(hipMemcpy(zin, h.data(), n * 2, hipMemcpyHostToDevice));
   std::vector<float> hs(4 * C, 1.0f), hw(9 * C, 0.1f); CK(hipMemcpy(st, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
   const int th_in = th - 1 + K, tw_in = tw - 1 + K;
-  const size_t lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)K * K * cb) * 4;
+  const size_t lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)K * K * cb) * 4 + extra_lds;
+  CK(hipFuncSetAttribute((const void *)fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   dim3 grid(tiles_x * tiles_y, (C + cb - 1) / cb, B);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto launch = [&]() { hipLaunchKernelGGL((fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2>), grid, dim3(256), lds, 0, zin, st, (const fd_bf16 *)nullptr, (const float *)nullptr, w, zout, part, H, H, H, H, C, 3, th, tw, tiles_x, 0); };
@@ -29,15 +31,20 @@ static void run(int B, int H, int C, int th, int tw) {
   const long np = std::min<long>(wgs, 16384);
   double d[5] = {0, 0, 0, 0, 0}; long long first = pr[0], last = 0;
   for (long b = 0; b < np; ++b) { for (int k = 0; k < 5; ++k) d[k] += (double)(pr[8 * b + k + 1] - pr[8 * b + k]); first = std::min(first, pr[8 * b]); last = std::max(last, pr[8 * b + 5]); }
-  printf("B=%d %dx%d C=%d tile %dx%d: %ld WGs, %.1f us/launch | per-WG shader clocks: issue+land patch %.0f, LDS commit+barrier %.0f, taps+stores %.0f, barrier %.0f, reduce+partial %.0f | sum %.0f clk = %.2f us at 2.1 GHz | first start -> last end %.0f clk\n",
-         B, H, H, C, th, tw, wgs, ms / 20 * 1e3, d[0] / np, d[1] / np, d[2] / np, d[3] / np, d[4] / np, (d[0] + d[1] + d[2] + d[3] + d[4]) / np, (d[0] + d[1] + d[2] + d[3] + d[4]) / np / 2100.0, (double)(last - first));
+  printf("abl %d lds %zu | B=%d %dx%d C=%d tile %dx%d: %ld WGs, %.1f us/launch | per-WG shader clocks: issue+land patch %.0f, LDS commit+barrier %.0f, taps+stores %.0f, barrier %.0f, reduce+partial %.0f | sum %.0f clk = %.2f us at 2.1 GHz | first start -> last end %.0f clk\n",
+         abl, lds, B, H, H, C, th, tw, wgs, ms / 20 * 1e3, d[0] / np, d[1] / np, d[2] / np, d[3] / np, d[4] / np, (d[0] + d[1] + d[2] + d[3] + d[4]) / np, (d[0] + d[1] + d[2] + d[3] + d[4]) / np / 2100.0, (double)(last - first));
   CK(hipFree(zin)); CK(hipFree(zout)); CK(hipFree(st)); CK(hipFree(w)); CK(hipFree(part));
 }
-int main() {
-  run(32, 112, 32, 8, 16);    // conv1.0
+int main(int argc, char **argv) {
+  if (argc > 1) {   // tile-shape sweep
+    for (int th : {8, 16, 28}) for (int tw : {16, 32}) run(32, 112, 32, th, tw);
+    for (int th : {7, 14, 28}) for (int tw : {16, 28}) run(32, 56, 128, th, tw);
+    for (int th : {7, 14, 28}) for (int tw : {16, 28}) run(32, 28, 256, th, tw);
+    return 0;
+  }
+  for (int abl : {0, 1, 2, 3}) run(32, 112, 32, 8, 16, abl);          // conv1.0: full / no stores / no loads / neither
+  for (size_t extra : {(size_t)0, (size_t)6000, (size_t)14000, (size_t)27000, (size_t)54000}) run(32, 112, 32, 8, 16, 0, extra);   // residency 5, 4, 3, 2, 1 (by LDS)
+  for (int abl : {0, 1, 2, 3}) run(32, 14, 512, 7, 16, abl);           // conv7.0
   run(32, 56, 128, 7, 16);    // conv3.0
-  run(32, 28, 256, 7, 16);    // conv5.0
-  run(32, 14, 512, 7, 16);    // conv7.0
-  run(32, 14, 512, 14, 16);   // conv7.0, whole frames
   return 0;
 }
