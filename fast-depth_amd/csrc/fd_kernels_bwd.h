@@ -429,11 +429,32 @@ fd_pw_dgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, c
     if (mt >= m_tiles) return;
     const long m0 = (long)mt * BM;
     const int k0 = kt * BKO;
-    for (int n = tid; n < N32; n += 256) {
-        tab[n] = n < N ? coef[FD_CF_A * N + n] : 0.0f;
-        tab[N32 + n] = n < N ? coef[FD_CF_C1 * N + n] : 0.0f;
-        tab[2 * N32 + n] = n < N ? coef[FD_CF_MU * N + n] : 0.0f;
-        tab[3 * N32 + n] = n < N ? coef[FD_CF_C2 * N + n] : 0.0f;
+    // the coefficient table and the epilogue's operands (producer's table, z_in, skip gradient) are requested first; the table lands in LDS after
+    // the first LDS-DMA stages have been issued and the epilogue operands wait in registers: their round trips run under the main loop instead
+    // of in front of / behind it (they are older than or interleaved with the first stages: the loop's vmcnt waits still cover every stage)
+    constexpr int TABQ = 4;                                    // N <= 1024 (checked by the plan)
+    float tcf[TABQ][4];
+#pragma unroll
+    for (int i = 0; i < TABQ; ++i) {
+        const int n = tid + 256 * i;
+        const int nc = n < N ? n : 0;
+        const float a = coef[FD_CF_A * N + nc], b = coef[FD_CF_C1 * N + nc], c = coef[FD_CF_MU * N + nc], d = coef[FD_CF_C2 * N + nc];
+        tcf[i][0] = n < N ? a : 0.0f; tcf[i][1] = n < N ? b : 0.0f; tcf[i][2] = n < N ? c : 0.0f; tcf[i][3] = n < N ? d : 0.0f;
+    }
+    const int col = k0 + wk * 32 + (lane & 31);
+    const long rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    float e_sc, e_sh, e_mu, e_is, e_z[16], e_sg[16];
+    {
+        const int cq = col < K ? col : 0;
+        e_sc = st_in[FD_ST_SCALE * K + cq]; e_sh = st_in[FD_ST_SHIFT * K + cq];
+        e_mu = st_in[FD_ST_MEAN * K + cq]; e_is = st_in[FD_ST_INVSTD * K + cq];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            long row = rbase + (r & 3) + 8 * (r >> 2);
+            if (row > M - 1) row = M - 1;
+            e_z[r] = Zin[row * K + cq];
+            if (ADD_SG) e_sg[r] = SG[row * K + cq];
+        }
     }
     // LDS-DMA sources.  G/Z tiles: 64 rows x 8 chunks = 8 row-groups each -> waves 0..3 take 2 groups of G and 2 of Z.
     // W tile: 32 rows (n) x 16 chunks (k): 64 lanes = 4 rows x 16 chunks -> 8 groups, 2 per wave.
@@ -472,9 +493,14 @@ fd_pw_dgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, c
     }
     const int b_col = wk * 32 + (lane & 31);
     const int T = N32 / BR;
-    __syncthreads();
     issue(0);
     if (FD_BWD_STAGES > 2 && T > 1) issue(1);
+#pragma unroll
+    for (int i = 0; i < TABQ; ++i) {
+        const int n = tid + 256 * i;
+        if (n < N32) { tab[n] = tcf[i][0]; tab[N32 + n] = tcf[i][1]; tab[2 * N32 + n] = tcf[i][2]; tab[3 * N32 + n] = tcf[i][3]; }
+    }
+    fd_block_barrier_lds();                                    // coefficient table visible
     for (int t = 0; t < T; ++t) {
         if (FD_BWD_STAGES > 2 && t + 1 < T) fd_wait_vmcnt<6>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
@@ -493,19 +519,16 @@ fd_pw_dgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, c
         }
     }
     // epilogue
-    const int col = k0 + wk * 32 + (lane & 31);
-    const long rbase = m0 + wm * 32 + 4 * (lane >> 5);
     float s = 0.0f, q = 0.0f;
     if (col < K) {
-        const float sc = st_in[FD_ST_SCALE * K + col], sh = st_in[FD_ST_SHIFT * K + col];
-        const float mu = st_in[FD_ST_MEAN * K + col], is = st_in[FD_ST_INVSTD * K + col];
+        const float sc = e_sc, sh = e_sh, mu = e_mu, is = e_is;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long row = rbase + (r & 3) + 8 * (r >> 2);
             if (row < M) {
-                const float z = Zin[row * K + col];
+                const float z = e_z[r];
                 float v = acc[r];
-                if (ADD_SG) v += SG[row * K + col];
+                if (ADD_SG) v += e_sg[r];
                 v *= fd_actmask<ACT_IN>(z * sc + sh);
                 Gin[row * K + col] = v;
                 s += v; q = fmaf(v, (z - mu) * is, q);

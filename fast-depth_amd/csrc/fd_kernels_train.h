@@ -305,7 +305,7 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);      // 3 stages, then the scale/shift table [2][K32], then [2][2][64] stats
     const int K32 = (K + 31) / 32 * 32;
-    float *tab = smem + 3 * STAGE;
+    float *tab = smem + (K32 < 3 * BK ? K32 / BK : 3) * STAGE;   // behind the ring's min(3, K tiles) stages
     float *red = tab + 2 * K32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -315,9 +315,16 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
 
-    for (int k = tid; k < K32; k += 256) {
-        tab[k] = k < K ? st1[FD_ST_SCALE * K + k] : 0.0f;
-        tab[K32 + k] = k < K ? st1[FD_ST_SHIFT * K + k] : 0.0f;
+    // the producer's table is requested first and lands in LDS after the first LDS-DMA stages have been issued: one round trip instead of two
+    // at the head of every workgroup
+    constexpr int TABQ = 4;                                  // K <= 1024 (checked by the plan)
+    float tsv[TABQ], ttv[TABQ];
+#pragma unroll
+    for (int i = 0; i < TABQ; ++i) {
+        const int k = tid + 256 * i;
+        const int kc = k < K ? k : 0;
+        const float a = st1[FD_ST_SCALE * K + kc], b = st1[FD_ST_SHIFT * K + kc];
+        tsv[i] = k < K ? a : 0.0f; ttv[i] = k < K ? b : 0.0f;
     }
     const float *src[RG];
     int src_chunk[RG];
@@ -351,9 +358,14 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
         }
     }
     const int T = K32 / BK;
-    __syncthreads();                                         // scale/shift table visible (before any LDS-DMA is in flight)
     issue(0);
     if (T > 1) issue(1);
+#pragma unroll
+    for (int i = 0; i < TABQ; ++i) {
+        const int k = tid + 256 * i;
+        if (k < K32) { tab[k] = tsv[i]; tab[K32 + k] = ttv[i]; }
+    }
+    fd_block_barrier_lds();                                  // scale/shift table visible
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();

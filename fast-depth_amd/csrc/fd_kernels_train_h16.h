@@ -88,7 +88,7 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     constexpr int BM = 64, BN = 64 * TN, BK = 64;
     constexpr int ROWS = BM + BN, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
     FD_DYN_SMEM(smem);
-    float *tab = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][K64]
+    float *tab = reinterpret_cast<float *>(smem + (K64 < 3 * BK ? K64 / BK : 3) * STAGE);     // [2][K64], behind the ring's min(3, K tiles) stages
     float *red = tab + 2 * K64;                                   // [2][2][BN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -97,9 +97,16 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     if (mt >= m_tiles) return;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
-    for (int k = tid; k < K64; k += 256) {
-        tab[k] = k < K ? st1[FD_ST_SCALE * K + k] : 0.0f;
-        tab[K64 + k] = k < K ? st1[FD_ST_SHIFT * K + k] : 0.0f;
+    // the producer's table is requested first and lands in LDS after the first LDS-DMA stages have been issued: one round trip instead of two
+    // at the head of every workgroup (the units with K <= 128 run a single K tile: their workgroups are all head and tail)
+    constexpr int TABQ = 4;                                       // K64 <= 1024 (checked by the plan)
+    float tsv[TABQ], ttv[TABQ];
+#pragma unroll
+    for (int i = 0; i < TABQ; ++i) {
+        const int k = tid + 256 * i;
+        const int kc = k < K ? k : 0;
+        const float a = st1[FD_ST_SCALE * K + kc], b = st1[FD_ST_SHIFT * K + kc];
+        tsv[i] = k < K ? a : 0.0f; ttv[i] = k < K ? b : 0.0f;
     }
     const T *src[RG];
     int src_k[RG];
@@ -140,9 +147,14 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
         }
     }
     const int Tn = K64 / BK;
-    __syncthreads();                                              // table visible, before any LDS-DMA is in flight
     issue(0);
     if (Tn > 1) issue(1);
+#pragma unroll
+    for (int i = 0; i < TABQ; ++i) {
+        const int k = tid + 256 * i;
+        if (k < K64) { tab[k] = tsv[i]; tab[K64 + k] = ttv[i]; }
+    }
+    fd_block_barrier_lds();                                       // table visible
     for (int t = 0; t < Tn; ++t) {
         if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
@@ -226,6 +238,8 @@ fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__r
 // Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed
 // through LDS so that z_in / skipgrad are read and G_in is written 8 channels (16 bytes) per lane.
 // ------------------------------------------------------------------------------------------------
+// bytes of the LDS-DMA ring: min(3, N tiles) stages of (64 + 64*TN) 128-byte rows, at least the epilogue's four fp32 [32][36] tiles
+#define FD_PW_DGRAD_H16_RING(N64_, TN_) ((size_t)(((N64_) < 192 ? (N64_) / 64 : 3) * (64 + 64 * (TN_)) * 128 > 4 * 32 * 36 * 4 ? ((N64_) < 192 ? (N64_) / 64 : 3) * (64 + 64 * (TN_)) * 128 : 4 * 32 * 36 * 4))
 template <typename T, int ACT_IN, int ADD_SG, int TN>   // TN: 32-column tiles per wave (workgroup tile 64 x 64*TN of G_in): every dz fragment feeds TN MFMAs
 __device__ __forceinline__ void                       // blk: linear workgroup number (blockIdx.x of the plain kernel; the paired launch fd_pw_bwd_h16 passes its own)
 fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
@@ -235,7 +249,7 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
     constexpr int BM = 64, BKO = 64 * TN, BR = 64;
     constexpr int ROWS = BM + BKO, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
     FD_DYN_SMEM(smem);
-    float *red = reinterpret_cast<float *>(smem + 3 * STAGE);     // [2][2][BKO]
+    float *red = reinterpret_cast<float *>(smem + FD_PW_DGRAD_H16_RING(N64, TN));     // [2][2][BKO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wk = wave & 1;
     const int xcd = blk & 7, slot = blk >> 3;
@@ -282,6 +296,27 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
         }
     }
     const int Tn = N64 / BR;
+    // the epilogue operands of the wave's first column tile (producer's table, z_in, skip gradient) are requested BEFORE the main loop: their
+    // round trip runs under it (they are older than every LDS-DMA load, so the loop's vmcnt waits still cover exactly the stages)
+    const int c8 = (lane & 3) * 8;
+    float psc[8], psh[8], pmu[8], pis[8];
+    fd_u16x8 pz[2], pg[2];
+    {
+        const int gcol0 = k0 + wk * TN * 32 + c8;
+        const int gc = gcol0 < K ? gcol0 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            psc[j] = st_in[FD_ST_SCALE * K + gc + j]; psh[j] = st_in[FD_ST_SHIFT * K + gc + j];
+            pmu[j] = st_in[FD_ST_MEAN * K + gc + j]; pis[j] = st_in[FD_ST_INVSTD * K + gc + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long grow = m0 + wm * 32 + (lane >> 2) + 16 * i;
+            if (grow > M - 1) grow = M - 1;
+            pz[i] = fd_ld8(Zin + grow * K + gc);
+            if (ADD_SG) pg[i] = fd_ld8(SG + grow * K + gc);
+        }
+    }
     issue(0);
     if (Tn > 1) issue(1);
     for (int t = 0; t < Tn; ++t) {
@@ -299,7 +334,6 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
     // epilogue, one 32-column tile of the wave at a time: fp32 tile [32][36] per wave
     __syncthreads();
     float *tile = reinterpret_cast<float *>(smem) + wave * 32 * 36;
-    const int c8 = (lane & 3) * 8;
 #pragma unroll
     for (int jt = 0; jt < TN; ++jt) {
         const int cw = (wk * TN + jt) * 32;                       // first column of this tile within the workgroup's BKO columns
@@ -314,8 +348,11 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
             float sc[8], sh[8], mu[8], is[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                sc[j] = st_in[FD_ST_SCALE * K + gcol + j]; sh[j] = st_in[FD_ST_SHIFT * K + gcol + j];
-                mu[j] = st_in[FD_ST_MEAN * K + gcol + j]; is[j] = st_in[FD_ST_INVSTD * K + gcol + j];
+                if (jt == 0) { sc[j] = psc[j]; sh[j] = psh[j]; mu[j] = pmu[j]; is[j] = pis[j]; }
+                else {
+                    sc[j] = st_in[FD_ST_SCALE * K + gcol + j]; sh[j] = st_in[FD_ST_SHIFT * K + gcol + j];
+                    mu[j] = st_in[FD_ST_MEAN * K + gcol + j]; is[j] = st_in[FD_ST_INVSTD * K + gcol + j];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -323,13 +360,13 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
                 const long grow = m0 + wm * 32 + row;
                 if (grow < M) {
                     float z[8], v[8];
-                    fd_unpack8(T{}, fd_ld8(Zin + grow * K + gcol), z);
+                    fd_unpack8(T{}, jt == 0 ? pz[i] : fd_ld8(Zin + grow * K + gcol), z);
                     const fd_f32x4 v0 = fd_ld4(tile + row * 36 + c8), v1 = fd_ld4(tile + row * 36 + c8 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = v0[j]; v[4 + j] = v1[j]; }
                     if (ADD_SG) {
                         float g[8];
-                        fd_unpack8(T{}, fd_ld8(SG + grow * K + gcol), g);
+                        fd_unpack8(T{}, jt == 0 ? pg[i] : fd_ld8(SG + grow * K + gcol), g);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += g[j];
                     }

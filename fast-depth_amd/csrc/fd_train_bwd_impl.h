@@ -248,7 +248,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
     if (pair && !(c.p->flags & FD_PLAN_TUNE_PW_PAIR_TN2)) tn = 1;   // paired launch: 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74: the weight-gradient workgroups share it) -- measured 554 vs 583 us per bf16 step
     const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
-    const size_t lds_d = (size_t)3 * (64 + 64 * tn) * 128 + (size_t)4 * 64 * tn * 4;
+    const size_t lds_d = FD_PW_DGRAD_H16_RING(L.n64, tn) + (size_t)4 * 64 * tn * 4;     // ring of min(3, N tiles) stages (>= the epilogue's fp32 tiles) + statistics
     const bool add = P.skip_consumer >= 0;
     const unsigned n_dgrad = (unsigned)((m_tiles + 7) / 8 * 8 * k_tiles);
     *nblk = m_tiles;
