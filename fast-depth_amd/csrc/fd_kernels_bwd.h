@@ -682,13 +682,13 @@ __device__ __forceinline__ void
 fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, const fd_blk3 bm, const int grid_x)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;
     // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
     // (bm: all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2)
     const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
@@ -885,9 +885,9 @@ __global__ void __launch_bounds__(256)
 fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr)
 {
-    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit,
+    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit, pstr,
                                                     fd_xcd_image_map(), (int)gridDim.x);
 }
 
@@ -903,13 +903,13 @@ __device__ __forceinline__ void
 fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
-                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, const fd_blk3 bm, const int grid_x)
+                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, int pstr, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
     float *s_in = smem;                                    // [TH_in*TW_in][PSTR] activated input patch; reused for the final reduction
     float *s_dz = smem + TH_in * TW_in * PSTR;             // [TH*TW][PSTR]       dz of the tile's outputs (0 outside the image)
@@ -1059,9 +1059,9 @@ __global__ void __launch_bounds__(256)
 fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
-                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit)
+                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, int pstr)
 {
-    fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(zin, st1, zskip, st2, G, Z, coef, wpart, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, tpw, csplit,
+    fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(zin, st1, zskip, st2, G, Z, coef, wpart, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, tpw, csplit, pstr,
                                                 fd_xcd_image_map(), (int)gridDim.x);
 }
 
@@ -1091,7 +1091,7 @@ template <typename T> struct fd_dw_bwd_args {
     T *Gin, *SGout;
     const float *coef, *w, *st_in, *st_skip;
     float *part, *wpart;
-    int Hin, Win, Ho, Wo, C, cbq, csplit;
+    int Hin, Win, Ho, Wo, C, cbq, csplit, pstr;        // pstr: LDS patch pitch in floats
     int d_th, d_tw, d_tiles_x, d_gx, d_gy;             // backward-data: INPUT-space tiles; grid (d_gx tiles, d_gy channel blocks) per image
     int w_th, w_tw, w_tiles_x, w_tpw, w_gx, w_gy;      // backward-weights: OUTPUT-space tiles, tpw of them per workgroup
     int B;
@@ -1105,11 +1105,11 @@ fd_dw_bwd(const fd_dw_bwd_args<T> a)
     if (pb.role == 0) {
         bm.y = bm.x / a.d_gx; bm.x -= bm.y * a.d_gx;
         fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
-                                                      a.d_th, a.d_tw, a.d_tiles_x, a.csplit, bm, a.d_gx);
+                                                      a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, bm, a.d_gx);
     } else {
         bm.y = bm.x / a.w_gx; bm.x -= bm.y * a.w_gx;
         fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
-                                                    a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, bm, a.w_gx);
+                                                    a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, a.pstr, bm, a.w_gx);
     }
 }
 
@@ -1119,13 +1119,13 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ Zskip, const float *__restrict__ st_skip,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part, float *__restrict__ wpart,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, const fd_blk3 bm, const int grid_x)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x)
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;
     // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
     // (bm: all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2)
     const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
@@ -1425,7 +1425,7 @@ __global__ void __launch_bounds__(256)
 fd_dw_bwd1(const fd_dw_bwd_args<T> a)
 {
     fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
-                                                         a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, fd_xcd_image_map(), (int)gridDim.x);
+                                                         a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, fd_xcd_image_map(), (int)gridDim.x);
 }
 
 

@@ -159,14 +159,14 @@ template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
 __global__ void __launch_bounds__(256)
 fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                     const float *__restrict__ st2, const float *__restrict__ w, T *__restrict__ zout,
-                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit)
+                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr)
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;           // 3x3: all tap rows of a strip unrolled (their LDS reads in flight together); 5x5: one row at a time (registers)
     constexpr int NIN = 3 * S + K;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = CB + 4;
+    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;   // LDS patch pitch in floats (>= CB + 4, a multiple of 4: chosen by the plan)
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
     float *s_in = smem;                                   // [TH_in*TW_in][PSTR]; reused for the stats reduction
     float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]

@@ -39,7 +39,11 @@ inline int dw_dgrad_rows(const fd_train_plan *p, const TLayer &L)
     const int th = ceil_div(L.in_h, ceil_div(L.in_h, 8));
     return (L.mode != 0 || L.d.stride == 2) ? (th + 1) / 2 * 2 : th;     // (stride 2: the tile must hold whole receptive-field rows of its owned outputs)
 }
-inline size_t dw_bwd_lds(int ph, int pw, int cb, int k) { return (std::max((size_t)ph * pw * (cb + 4), (size_t)2048) + (size_t)k * k * cb) * 4; }
+// Rows (columns) of the dz patch that an INPUT-space tile of t rows (columns, a multiple of the stride, starting on a multiple of it) reads: the
+// EXACT extent the kernel computes (fd_dw_dgrad_body: PH, PW) -- stride 1: t + K - 1; stride 2: t / 2 + 2.  (Rounds 1-2 requested up to 4 rows and
+// columns more: 58 KB instead of 38 for the 5x5 units = 2 resident workgroups per CU instead of 4.)
+inline int dw_dz_patch(int t, int k, int s) { return (t + k - 2) / s + (s == 2 ? 2 : 1); }
+inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr) { return (std::max((size_t)ph * pw * pstr, (size_t)2048) + (size_t)k * k * cb) * 4; }
 
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
@@ -58,14 +62,14 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
     const int cb = 4 << L.cbq;
     const int TH = dw_dgrad_rows(c.p, L), TW = 16;
     const int tiles_x = ceil_div(L.in_w, TW), tiles_y = ceil_div(L.in_h, TH);
-    const int ph = (TH - 1 + K / 2) / S + (K - 1) / S + 3, pw = (TW - 1 + K / 2) / S + (K - 1) / S + 3;   // upper bound of the dz patch
-    const size_t lds = dw_bwd_lds(ph, pw, cb, K);
+    const int ph = dw_dz_patch(TH, K, S), pw = dw_dz_patch(TW, K, S);
+    const size_t lds = dw_bwd_lds(ph, pw, cb, K, L.bpstr);
     dim3 grid(tiles_x * tiles_y, ceil_div(L.d.cin, cb), c.p->B);
     const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
     FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
               c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
               twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, tws(c.p, c.p->part_off),
-              L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit);
+              L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit, L.bpstr);
     *nblk_out = tiles_x * tiles_y * c.p->B;
     return check_launch("fd_dw_dgrad");
 }
@@ -104,7 +108,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const dim3 wgrid(groups_x * bty, ncb_w, c.p->B);
     // LDS: activated input patch + dz tile, both [pixels][cb + 4] floats; the final reduction (npt/K groups x K*K taps x cb) reuses it
     const int cbw = 4 << L.cbq, th_in = (L.bth - 1) * L.d.stride + L.d.ksize, tw_in = (L.btw - 1) * L.d.stride + L.d.ksize;
-    const size_t wlds = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * (cbw + 4), (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
+    const size_t wlds = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * L.bpstr, (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
     if (wlds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise wgrad: LDS request %zu exceeds 64 KiB", wlds);
     const int wblk = groups_x * bty * c.p->B;
 #define FD_DWW(K_, S_, M_)                                                                                                         \
@@ -112,7 +116,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
         FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
                   Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
                   twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
-                  L.cbq, L.bth, L.btw, btx, tpw, L.csplit);                                                                    \
+                  L.cbq, L.bth, L.btw, btx, tpw, L.csplit, L.bpstr);                                                          \
         break;
     switch (key) {
         FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2) FD_DWW(5, 1, 3)
@@ -152,13 +156,13 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.Gin = twt<T>(c.p, P.g_off); a.SGout = Kp ? twt<T>(c.p, Kp->sg_off) : nullptr;
     a.coef = tws(c.p, L.coef_off); a.w = c.params[i].conv_weight; a.st_in = tws(c.p, P.st_off); a.st_skip = Kp ? tws(c.p, Kp->st_off) : nullptr;
     a.part = tws(c.p, c.p->part_off); a.wpart = tws(c.p, L.wp_off);
-    a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.B = c.p->B;
+    a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.pstr = L.bpstr; a.B = c.p->B;
     // backward-data geometry (launch_dw_dgrad)
     a.d_th = dw_dgrad_rows(c.p, L); a.d_tw = 16;
     a.d_tiles_x = ceil_div(L.in_w, a.d_tw);
     a.d_gx = a.d_tiles_x * ceil_div(L.in_h, a.d_th); a.d_gy = ceil_div(L.d.cin, cb);
-    const int ph = (a.d_th - 1 + K / 2) / S + (K - 1) / S + 3, pw = (a.d_tw - 1 + K / 2) / S + (K - 1) / S + 3;
-    const size_t lds_d = dw_bwd_lds(ph, pw, cb, K);
+    const int ph = dw_dz_patch(a.d_th, K, S), pw = dw_dz_patch(a.d_tw, K, S);
+    const size_t lds_d = dw_bwd_lds(ph, pw, cb, K, L.bpstr);
     // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);
     int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ceil_div(L.d.cin, cb) * c.p->B / 1536)));
@@ -167,9 +171,9 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     tpw = ceil_div(btx, groups_x);
     a.w_th = L.bth; a.w_tw = L.btw; a.w_tiles_x = btx; a.w_tpw = tpw; a.w_gx = groups_x * bty; a.w_gy = ceil_div(L.d.cin, cb);
     const int th_in = (L.bth - 1) * S + K, tw_in = (L.btw - 1) * S + K;
-    const size_t lds_w = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * (cb + 4), (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
+    const size_t lds_w = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * L.bpstr, (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
     const size_t lds = std::max(lds_d, lds_w);
-    if (lds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 64 KiB", lds);
+    if (lds > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 160 KiB", lds);
     const int kk = K * K;
     // measured (bf16, batch 32): the single-staging kernel wins on the stride-2 units (conv2.0 84 vs 103 us, conv4.0 50 vs 57, conv6.0 31 vs 35) and
     // loses on the stride-1 3x3 ones (conv1.0 68 vs 57, 14x14 maps 22.4 vs 19.5: two tap phases back to back in one workgroup at lower residency);
@@ -179,7 +183,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
         const int oth = a.d_th / S, otw = a.d_tw / S;
         const int th_in1 = (oth - 1) * S + K, tw_in1 = (otw - 1) * S + K;
         const int ph1 = (a.d_th + K - 2) / S + 2, pw1 = (a.d_tw + K - 2) / S + 2;          // upper bound of the dz patch
-        const size_t lds1 = std::max((size_t)(ph1 * pw1 + th_in1 * tw_in1) * (cb + 4) + (size_t)kk * cb, (size_t)((256 / (cb / 4)) / K) * kk * cb + 2048) * 4;
+        const size_t lds1 = std::max((size_t)(ph1 * pw1 + th_in1 * tw_in1) * L.bpstr + (size_t)kk * cb, (size_t)((256 / (cb / 4)) / K) * kk * cb + 2048) * 4;
         if (lds1 > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward: LDS request %zu exceeds 160 KiB", lds1);
         const int wblk1 = a.d_gx * c.p->B;
         if ((size_t)wblk1 * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
@@ -193,6 +197,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const int wblk = a.w_gx * c.p->B;
     if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
     const long total = (long)c.p->B * ((long)a.d_gx * a.d_gy + (long)a.w_gx * a.w_gy);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG>), dim3((unsigned)total), dim3(256), lds, c.s, a);
     int rc = check_launch("fd_dw_bwd");
     if (rc) return rc;

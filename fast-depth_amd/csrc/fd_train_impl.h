@@ -35,6 +35,7 @@ struct TLayer {
     int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
+    int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels
     int chunk = 0;                                            // stem
     int m_tiles = 0, n_tiles = 0, pw_tn = 1;                  // pw (pw_tn: 32-column tiles per wave of the 16-bit forward GEMM)
     size_t lds = 0;
@@ -97,7 +98,7 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
     case K_ * 100 + S_ * 10 + M_:                                                                                            \
         if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
         FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
-                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit);                        \
+                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr);                \
         break;
     switch (key) {
         FD_DWT(3, 1, 0) FD_DWT(3, 2, 0) FD_DWT(5, 1, 0) FD_DWT(5, 1, 1) FD_DWT(5, 1, 2) FD_DWT(5, 1, 3)
@@ -293,6 +294,11 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             // tools/microbench/dwtrain.hip), so fewer, fatter workgroups win until the patch staging takes too many load rounds:
             // measured 56x56x128: 7x16 39.4 us, 14x28 30.4; 28x28x256: 20.3 -> 14.6; 112x112x32: 8x16 34.9 -> 16x16 32.1; 14x14: 7x16 10.6 -> 14x16 9.1
             L.bth = L.th; L.btw = L.tw;
+            // (5x5 weight-gradient tiles of 4 rows -- 32 KB of LDS instead of 53 -- measured slower: decode_conv5 156 -> 169 us)
+            if (d.ksize == 5 && (flags & FD_PLAN_TUNE_DW_WGRAD_TH4)) L.bth = ceil_div(L.out_h, ceil_div(L.out_h, 4));
+            // 3x3 stride-1 units: weight-gradient tiles of 7 rows where they divide the map (112, 56, 28, 14, 7 all do): patch + dz tile = 39.5 KB
+            // instead of 44.4 -> four resident workgroups per CU instead of three
+            if (d.ksize == 3 && d.stride == 1 && L.out_h % 7 == 0 && (flags & FD_PLAN_TUNE_DW_WGRAD_TH7)) L.bth = 7;
             // (3x3 units only: the 5x5 decoder units LOSE with larger tiles -- 34 -> 50 us at 56x56, their patch staging takes too many load rounds)
             if (d.stride == 1 && d.ksize == 3 && !(flags & FD_PLAN_TUNE_DW_SMALL_TILES)) {
                 L.th = L.out_h <= 14 ? L.out_h : (L.out_h <= 56 ? 14 : 16);
@@ -300,7 +306,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             }
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
-            L.lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
+            L.pstr = L.bpstr = cb + 4 + 4 * (int)((flags >> 26) & 3);       // (FD_PLAN_TUNE_DW_PITCH: +4 / +8 / +12 floats)
+            L.lds = (std::max((size_t)th_in * tw_in * L.pstr, (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
             const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
