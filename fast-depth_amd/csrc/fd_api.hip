@@ -584,7 +584,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.lds = pw_lds_bytes(L.pw);
                 // 16-bit kernel: a reduction of one or two K tiles never touches the ring's later stages -- not requested, so that more workgroups
                 // of the short-K units (conv1.3, conv2.3, decode_conv5.1: all head and tail) are resident per CU (its epilogue tile needs 10 KiB)
-                if (dtype != FD_F32) L.lds = (size_t)std::min(3, ceil_div(d.cin, 64)) * 128 * 128;
+                if (dtype != FD_F32) L.lds = (size_t)std::min(FD_H16_STAGES, ceil_div(d.cin, 64)) * 128 * 128;
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
                 L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));   // 1-D, XCD-aware mapping inside the kernel

@@ -28,6 +28,10 @@ __device__ __forceinline__ fd_f32x16 fd_mfma_32x32x16(fd_bf16, fd_u16x8 a, fd_u1
 #endif
 }
 
+// depth of the LDS-DMA ring of the 16-bit GEMMs (first-generation inference kernel, train forward, train backward-data)
+#ifndef FD_H16_STAGES
+#define FD_H16_STAGES 3
+#endif
 template <typename T, int ACT>
 __global__ void __launch_bounds__(256)
 fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *__restrict__ bias, T *__restrict__ out,
@@ -57,7 +61,7 @@ fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *_
         else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K64; }
     }
     auto issue = [&](int t) {
-        unsigned char *dst = smem + (t % 3) * STAGE + wave * 8 * 128;
+        unsigned char *dst = smem + (t % FD_H16_STAGES) * STAGE + wave * 8 * 128;
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
             int k = t * BK + src_k[i];
@@ -84,12 +88,12 @@ fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *_
     }
     const int Tn = K64 / BK;
     issue(0);
-    if (Tn > 1) issue(1);
+    if (FD_H16_STAGES > 2 && Tn > 1) issue(1);
     for (int t = 0; t < Tn; ++t) {
-        if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        if (FD_H16_STAGES > 2 && t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
-        if (t + 2 < Tn) issue(t + 2);
-        const unsigned char *cur = smem + (t % 3) * STAGE;
+        if (t + FD_H16_STAGES - 1 < Tn) issue(t + FD_H16_STAGES - 1);
+        const unsigned char *cur = smem + (t % FD_H16_STAGES) * STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const fd_u16x8 a = *reinterpret_cast<const fd_u16x8 *>(cur + a_off[s]);

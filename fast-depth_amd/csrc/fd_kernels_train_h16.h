@@ -88,7 +88,7 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     constexpr int BM = 64, BN = 64 * TN, BK = 64;
     constexpr int ROWS = BM + BN, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
     FD_DYN_SMEM(smem);
-    float *tab = reinterpret_cast<float *>(smem + (K64 < 3 * BK ? K64 / BK : 3) * STAGE);     // [2][K64], behind the ring's min(3, K tiles) stages
+    float *tab = reinterpret_cast<float *>(smem + (K64 < FD_H16_STAGES * BK ? K64 / BK : FD_H16_STAGES) * STAGE);     // [2][K64], behind the ring's min(FD_H16_STAGES, K tiles) stages
     float *red = tab + 2 * K64;                                   // [2][2][BN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -120,7 +120,7 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
         else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K64; }
     }
     auto issue = [&](int t) {
-        unsigned char *dst = smem + (t % 3) * STAGE + wave * 8 * 128;
+        unsigned char *dst = smem + (t % FD_H16_STAGES) * STAGE + wave * 8 * 128;
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
             int k = t * BK + src_k[i];
@@ -148,7 +148,7 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     }
     const int Tn = K64 / BK;
     issue(0);
-    if (Tn > 1) issue(1);
+    if (FD_H16_STAGES > 2 && Tn > 1) issue(1);
 #pragma unroll
     for (int i = 0; i < TABQ; ++i) {
         const int k = tid + 256 * i;
@@ -156,10 +156,10 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     }
     fd_block_barrier_lds();                                       // table visible
     for (int t = 0; t < Tn; ++t) {
-        if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        if (FD_H16_STAGES > 2 && t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
-        if (t + 2 < Tn) issue(t + 2);
-        const unsigned char *cur = smem + (t % 3) * STAGE;
+        if (t + FD_H16_STAGES - 1 < Tn) issue(t + FD_H16_STAGES - 1);
+        const unsigned char *cur = smem + (t % FD_H16_STAGES) * STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int kb = t * BK + (2 * s + h) * 8;
@@ -238,8 +238,8 @@ fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__r
 // Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed
 // through LDS so that z_in / skipgrad are read and G_in is written 8 channels (16 bytes) per lane.
 // ------------------------------------------------------------------------------------------------
-// bytes of the LDS-DMA ring: min(3, N tiles) stages of (64 + 64*TN) 128-byte rows, at least the epilogue's four fp32 [32][36] tiles
-#define FD_PW_DGRAD_H16_RING(N64_, TN_) ((size_t)(((N64_) < 192 ? (N64_) / 64 : 3) * (64 + 64 * (TN_)) * 128 > 4 * 32 * 36 * 4 ? ((N64_) < 192 ? (N64_) / 64 : 3) * (64 + 64 * (TN_)) * 128 : 4 * 32 * 36 * 4))
+// bytes of the LDS-DMA ring: min(FD_H16_STAGES, N tiles) stages of (64 + 64*TN) 128-byte rows, at least the epilogue's four fp32 [32][36] tiles
+#define FD_PW_DGRAD_H16_RING(N64_, TN_) ((size_t)(((N64_) < 64 * FD_H16_STAGES ? (N64_) / 64 : FD_H16_STAGES) * (64 + 64 * (TN_)) * 128 > 4 * 32 * 36 * 4 ? ((N64_) < 64 * FD_H16_STAGES ? (N64_) / 64 : FD_H16_STAGES) * (64 + 64 * (TN_)) * 128 : 4 * 32 * 36 * 4))
 template <typename T, int ACT_IN, int ADD_SG, int TN>   // TN: 32-column tiles per wave (workgroup tile 64 x 64*TN of G_in): every dz fragment feeds TN MFMAs
 __device__ __forceinline__ void                       // blk: linear workgroup number (blockIdx.x of the plain kernel; the paired launch fd_pw_bwd_h16 passes its own)
 fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
@@ -269,7 +269,7 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
         else { int row = k0 + (r - BM); if (row > K - 1) row = K - 1; src[i] = Wtt + (long)row * N64; }
     }
     auto issue = [&](int t) {
-        unsigned char *dst = smem + (t % 3) * STAGE + wave * 8 * 128;
+        unsigned char *dst = smem + (t % FD_H16_STAGES) * STAGE + wave * 8 * 128;
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
             int n = t * BR + src_n[i];
@@ -318,12 +318,12 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
         }
     }
     issue(0);
-    if (Tn > 1) issue(1);
+    if (FD_H16_STAGES > 2 && Tn > 1) issue(1);
     for (int t = 0; t < Tn; ++t) {
-        if (t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
+        if (FD_H16_STAGES > 2 && t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
-        if (t + 2 < Tn) issue(t + 2);
-        const unsigned char *cur = smem + (t % 3) * STAGE;
+        if (t + FD_H16_STAGES - 1 < Tn) issue(t + FD_H16_STAGES - 1);
+        const unsigned char *cur = smem + (t % FD_H16_STAGES) * STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const fd_u16x8 af = fd_ld8(cur + a_off[s]);

@@ -340,7 +340,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.k64 = (d.cin + 63) / 64 * 64; L.n64 = (d.cout + 63) / 64 * 64;
                 if (L.k64 > 1024 || d.cout > 1024) FD_BAD("layer %d: the train GEMMs hold per-channel tables of at most 1024 input / output channels (cin = %d, cout = %d)", i, d.cin, d.cout);
                 // (the LDS-DMA ring holds min(3, K tiles) stages: the short-K units keep more workgroups resident)
-                L.lds = h16 ? (size_t)std::min(3, L.k64 / 64) * (64 + bn) * 128 + ((size_t)2 * L.k64 + 4 * bn) * 4
+                L.lds = h16 ? (size_t)std::min(FD_H16_STAGES, L.k64 / 64) * (64 + bn) * 128 + ((size_t)2 * L.k64 + 4 * bn) * 4
                             : (size_t)(std::min(3, ceil_div(d.cin, 32)) * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
                 L.nblk = L.m_tiles;
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)

@@ -8,7 +8,8 @@ import models
 from fastdepth_hip import capi
 from fastdepth_hip.train import TrainEngine
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--dtype", default="bf16"); ap.add_argument("--plan-flags", type=lambda v: int(v, 0), default=0); ap.add_argument("--summary", action="store_true"); a = ap.parse_args()
+ap.add_argument("--dtype", default="bf16"); ap.add_argument("--plan-flags", type=lambda v: int(v, 0), default=0); ap.add_argument("--summary", action="store_true"); ap.add_argument("--lib", default=None); a = ap.parse_args()
+if a.lib: capi.DEFAULT_LIB = os.path.abspath(a.lib)       # a tools/build_variant.py build instead of the product library
 from fastdepth_hip import train as _train
 _train._TrainPlan.default_flags = a.plan_flags
 torch.manual_seed(0)
