@@ -97,8 +97,8 @@ fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C,
 // Two shapes of work in one kernel (uniform per workgroup):
 //   few rows (nblk <= 64: the pointwise layers' M splits)   each of the 16 waves owns 256 columns and adds ALL rows itself, 8 row loads
 //                                                            in flight -- a pure stream, no LDS, no barrier (4096 columns per workgroup);
-//   many rows (depthwise / stem partial rows, up to ~3000)   the 16 waves split the rows of 256 columns (wave w: rows w, w+16, ... in
-//                                                            order), then the 16 wave sums are added in wave order.
+//   many rows (depthwise / stem partial rows, up to ~3000)   64 columns per workgroup, the rows dealt to 4 x 16 row lanes (shuffle across the four of
+//                                                            a wave, then the 16 wave sums in wave order).
 // Fixed orders: bit-reproducible.
 #define FD_WBATCH_MAX 40
 #define FD_WBATCH_FEW_ROWS 64
@@ -138,23 +138,29 @@ fd_reduce_weights_batch_f32(const fd_wbatch B)
         fd_wbatch_store(W, j, s);
         return;
     }
-    const int j = (cb * 64 + lane) * 4;
+    // many rows: 64 columns per workgroup (16 lanes x 4), the rows dealt to 64 row lanes (4 per wave x 16 waves: row lane r takes rows r, r + 64, ...,
+    // eight loads in flight) -- a 3136-row entry (fd_dw_bwd1 of conv2: one row per input-space tile) is 49 rows deep per lane instead of 196
+    const int cl = lane & 15, rsub = lane >> 4;
+    const int j = (cb * 16 + cl) * 4;
     fd_f32x4 s = fd_zero4();
     if (j < W.n) {
         const float *p = W.part + j;
-        int b = wave;
-        for (; b + 7 * 16 < W.nblk; b += 8 * 16) {
+        int b = wave * 4 + rsub;
+        for (; b + 7 * 64 < W.nblk; b += 8 * 64) {
             fd_f32x4 t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = fd_ld4(p + (long)(b + 16 * u) * W.n);
+            for (int u = 0; u < 8; ++u) t[u] = fd_ld4(p + (long)(b + 64 * u) * W.n);
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += t[u];
         }
-        for (; b < W.nblk; b += 16) s += fd_ld4(p + (long)b * W.n);
+        for (; b < W.nblk; b += 64) s += fd_ld4(p + (long)b * W.n);
     }
+    // the four row lanes of a wave (fixed order), then the 16 waves in wave order
+#pragma unroll
+    for (int m = 16; m < 64; m <<= 1) { s.x += __shfl_xor(s.x, m); s.y += __shfl_xor(s.y, m); s.z += __shfl_xor(s.z, m); s.w += __shfl_xor(s.w, m); }
     sh[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && j < W.n) {
+    if (wave == 0 && rsub == 0 && j < W.n) {
         s = sh[0][lane];
         for (int w = 1; w < 16; ++w) s += sh[w][lane];
         fd_wbatch_store(W, j, s);

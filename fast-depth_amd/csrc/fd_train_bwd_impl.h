@@ -26,7 +26,7 @@ int defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C,
     if (c.wb.count == FD_WBATCH_MAX) { int rc = flush_weights(c); if (rc) return rc; }
     if (c.wb.count == 0) c.wb.cb_start[0] = 0;
     c.wb.e[c.wb.count] = fd_wred_args{part, out, nrows, n, KK, C};
-    c.wb.cb_start[c.wb.count + 1] = c.wb.cb_start[c.wb.count] + ceil_div(n, nrows <= FD_WBATCH_FEW_ROWS ? 4096 : 256);
+    c.wb.cb_start[c.wb.count + 1] = c.wb.cb_start[c.wb.count] + ceil_div(n, nrows <= FD_WBATCH_FEW_ROWS ? 4096 : 64);
     ++c.wb.count;
     return FD_OK;
 }
@@ -36,6 +36,10 @@ int defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C,
 inline int dw_dgrad_rows(const fd_train_plan *p, const TLayer &L)
 {
     if (p->flags & FD_PLAN_TUNE_DW_TH8) return 8;
+    // 3x3 stride-1 units: 14 rows where they divide the map (same reasoning as the forward kernel's larger tiles: fewer, fatter workgroups; the
+    // dz patch of 16 x 18 pixels = 41.5 KB stays below the 44.4 KB the paired weight-gradient role needs anyway)
+    // (measured, bf16 step: conv1 55.3 -> 52.1 us, conv3 59.2 -> 55.1, conv5 35.3 -> 32.7, 14x14 maps 20.5 -> 19.5)
+    if (L.d.ksize == 3 && L.d.stride == 1 && L.mode == 0 && L.in_h % 14 == 0) return 14;
     const int th = ceil_div(L.in_h, ceil_div(L.in_h, 8));
     return (L.mode != 0 || L.d.stride == 2) ? (th + 1) / 2 * 2 : th;     // (stride 2: the tile must hold whole receptive-field rows of its owned outputs)
 }
@@ -101,7 +105,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     // tiles per workgroup (along x): as many as keep >= ~1536 workgroups in flight
     const int ncb_w = ceil_div(L.d.cin, 4 << L.cbq);
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);     // the backward-weights kernel's own output tiles (the forward's may be larger)
-    int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ncb_w * c.p->B / 1536)));
+    int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ncb_w * c.p->B / FD_DW_WGRAD_TARGET_WGS)));
     if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = btx;
     const int groups_x = ceil_div(btx, tpw);
     tpw = ceil_div(btx, groups_x);
@@ -165,7 +169,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const size_t lds_d = dw_bwd_lds(ph, pw, cb, K, L.bpstr);
     // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);
-    int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ceil_div(L.d.cin, cb) * c.p->B / 1536)));
+    int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ceil_div(L.d.cin, cb) * c.p->B / FD_DW_WGRAD_TARGET_WGS)));
     if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = btx;
     const int groups_x = ceil_div(btx, tpw);
     tpw = ceil_div(btx, groups_x);

@@ -19,6 +19,9 @@
 // workgroups the pointwise weight-gradient GEMM aims for (output tiles x pixel splits); every split writes a private fp32 partial
 // tile that fd_reduce_partials_f32 sums afterwards, so more splits = more parallelism but more partial traffic
 // (measured at batch 32: 2048 is best for the fp32 kernel; the bf16 one, whose MFMA part is 16x shorter, wants fewer)
+#ifndef FD_DW_WGRAD_TARGET_WGS
+#define FD_DW_WGRAD_TARGET_WGS 1536   // depthwise weight-gradient kernel: a workgroup walks up to a tile row's tiles as long as about this many workgroups remain
+#endif
 #ifndef FD_WGRAD_TUNE_H16
 #define FD_WGRAD_TUNE_H16 640      // (round 3, paired launch: 640 -> 2.840 ms per bf16 step, 1024 -> 2.877, 512 -> 2.860; fewer splits = fewer partial bytes)
 #endif
@@ -296,9 +299,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.bth = L.th; L.btw = L.tw;
             // (5x5 weight-gradient tiles of 4 rows -- 32 KB of LDS instead of 53 -- measured slower: decode_conv5 156 -> 169 us)
             if (d.ksize == 5 && (flags & FD_PLAN_TUNE_DW_WGRAD_TH4)) L.bth = ceil_div(L.out_h, ceil_div(L.out_h, 4));
-            // 3x3 stride-1 units: weight-gradient tiles of 7 rows where they divide the map (112, 56, 28, 14, 7 all do): patch + dz tile = 39.5 KB
-            // instead of 44.4 -> four resident workgroups per CU instead of three
-            if (d.ksize == 3 && d.stride == 1 && L.out_h % 7 == 0 && (flags & FD_PLAN_TUNE_DW_WGRAD_TH7)) L.bth = 7;
+            // (3x3 stride-1 weight-gradient tiles of 7 rows -- 39.5 KB instead of 44.4: four resident workgroups per CU -- measured neutral in the paired launch)
             // (3x3 units only: the 5x5 decoder units LOSE with larger tiles -- 34 -> 50 us at 56x56, their patch staging takes too many load rounds)
             if (d.stride == 1 && d.ksize == 3 && !(flags & FD_PLAN_TUNE_DW_SMALL_TILES)) {
                 L.th = L.out_h <= 14 ? L.out_h : (L.out_h <= 56 ? 14 : 16);

@@ -38,7 +38,6 @@ FD_PLAN_TUNE_DW_SMALL_TILES = 33554432
 FD_PLAN_TUNE_DW_PITCH4 = 67108864
 FD_PLAN_TUNE_DW_PITCH8 = 134217728
 FD_PLAN_TUNE_DW_WGRAD_TH4 = 268435456
-FD_PLAN_TUNE_DW_WGRAD_TH7 = 536870912
 
 
 class LayerDesc(ctypes.Structure):

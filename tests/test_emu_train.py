@@ -153,7 +153,8 @@ def assert_local_parity(rep, dtype):
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD_PAIR), ("ragged", RAGGED, torch.float32, capi.FD_PLAN_TUNE_DW_BWD_PAIR),
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD1), ("ragged", RAGGED, torch.float32, capi.FD_PLAN_TUNE_DW_BWD1),
                                                    ("ragged", RAGGED, torch.bfloat16, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_PITCH8),
-                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_WGRAD_TH4)])
+                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_WGRAD_TH4),
+                                                   ("tiny_tall", TINY, torch.bfloat16, 0)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     """Every unit's forward and backward kernels on their own stored inputs against an fp64 single-unit autograd reference
     (harness.local_train_parity): the rigorous check of the bf16 train plan, whose end-to-end
@@ -162,7 +163,8 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     if name.endswith("sat6"):
         harness.saturate_encoder(m)
     g = torch.Generator().manual_seed(9)
-    h, w = (160, 224) if name == "tiny_wide" else (64, 64)   # tiny_wide: > 256 partial rows per reduction (280 for conv1.3 / decode_conv5.1) -> the sliced (last-arriver) path
+    h, w = (160, 224) if name == "tiny_wide" else ((224, 32) if name == "tiny_tall" else (64, 64))   # tiny_tall: map heights 112 ... 7 (the 14-row backward-data tiles; H must be a multiple of 32)
+    # tiny_wide: > 256 partial rows per reduction (280 for conv1.3 / decode_conv5.1) -> the sliced (last-arriver) path
     # (default plans: a stride-2 depthwise unit's backward is ONE single-staging kernel (fd_dw_bwd1), the other depthwise units' two kernels and a
     # pointwise unit's two GEMMs share a paired launch; FD_PLAN_TUNE_DW_BWD1 / _PAIR: the single-staging kernel everywhere / nowhere;
     # FD_PLAN_NO_BWD_PAIRING: every kernel on its own)
