@@ -53,75 +53,142 @@ __device__ __forceinline__ fd_f32x4 fd_round4(fd_half, fd_f32x4 v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem, train mode: raw weights w[Cout][27] (torch layout), raw output z (NHWC) + stats partials
-// part[(blockIdx.x)*2*Cout + {0: sum, Cout: sumsq} + c].
+// Stem, train mode (forward and weight gradient share the input staging).  A workgroup owns 256 consecutive output pixels [p0, p1) of ONE
+// image (grid: blocks per image x images, fd_xcd_image_map2 -- neighbouring blocks' input bands overlap, so an image stays on one XCD's L2).
+// fd_stem_stage_band brings the zero-padded band of input rows under those pixels into LDS with 16-byte row loads (the first
+// generation issued 27 strided 4-byte loads per pixel):  patch[c][r][PR], input column x at index 4 + x (x = -1 at index 3, so that x = 0 is
+// 16-byte aligned), rows iy_first .. iy_first + nrows - 1, PR = W + 8.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CHUNK>
+struct fd_stem_band { int oy_first, nrows, PR; };
+__device__ __forceinline__ fd_stem_band fd_stem_stage_band(const float *__restrict__ xn, float *patch, int H, int W, int Wo, int p0, int p1, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    fd_stem_band g;
+    g.oy_first = p0 / Wo;
+    const int oy_last = (p1 - 1) / Wo;
+    const int iy_first = 2 * g.oy_first - 1;
+    g.nrows = 2 * (oy_last - g.oy_first) + 3;
+    g.PR = W + 8;
+    const int W4 = W >> 2;                                    // W % 32 == 0
+    constexpr int U = 8;                                      // row chunks in flight per work-item before the first LDS write
+    for (int rbase = wave; rbase < 3 * g.nrows; rbase += 4 * U)
+        for (int qb = lane; qb < W4; qb += 64) {
+            fd_f32x4 v[U];
+            int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = rbase + 4 * u;                 // row of the [3 * nrows] band: plane c, band row r
+                const int c = (rr >= g.nrows) + (rr >= 2 * g.nrows), r = rr - c * g.nrows;
+                const int iy = iy_first + r;
+                const bool in_band = rr < 3 * g.nrows;
+                const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qc = c > 2 ? 2 : c;       // clamped address, unconditional load, padding by select
+                v[u] = fd_ld4(xn + ((long)qc * H + qy) * W + qb * 4);
+                if (!(in_band && iy >= 0 && iy < H)) v[u] = fd_zero4();
+                off[u] = in_band ? rr * g.PR + 4 + qb * 4 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (off[u] >= 0) fd_st4(patch + off[u], v[u]);
+        }
+    for (int rr = tid; rr < 3 * g.nrows; rr += 256) { patch[rr * g.PR + 3] = 0.0f; patch[rr * g.PR + 4 + W] = 0.0f; }   // x = -1 and x = W
+    return g;
+}
+// offset of tap t = (c, ky, kx) relative to a pixel's tap (0, 0, 0) inside the band
+__device__ __forceinline__ int fd_stem_tap_offset(int t, int nrows, int PR)
+{
+    const int c = t / 9, ky = (t - c * 9) / 3, kx = t - c * 9 - ky * 3;
+    return (c * nrows + ky) * PR + kx;
+}
+__device__ __forceinline__ float fd_round1(float, float v) { return v; }
+__device__ __forceinline__ float fd_round1(fd_bf16, float v) { return fd_bf16_to_f32(fd_f32_to_bf16(v)); }
+__device__ __forceinline__ float fd_round1(fd_half, float v) { return (float)(_Float16)v; }
+
+// Forward: z[p][co] = sum_t tap[p][t] * w[co][t] as 32x32x2 MFMAs (a wave = 64 pixels = two 32-row tiles, K = 27 taps padded to 28, raw torch
+// weights w[Cout][27]); the accumulators are rounded to T, transposed through a wave-private LDS tile for 16-byte NHWC stores, and their
+// per-channel sums over the valid pixels go to part[blk*2*Cout + {0: sum, Cout: sum of squares} + c], blk = image * gridDim.x + block.
+// LDS: max(band, 4 x [64][36] output tiles) + [4][2][32] statistics.
+template <typename T>
 __global__ void __launch_bounds__(256)
-fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__restrict__ z,
-                  float *__restrict__ part, int B, int H, int W, int Cout)
+fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__restrict__ z, float *__restrict__ part, int H, int W, int Cout, int tile_floats)
 {
     FD_DYN_SMEM(smem_raw);
-    float *tile = reinterpret_cast<float *>(smem_raw);       // [256][CHUNK + 4]
-    constexpr int TS = CHUNK + 4;
-    const int Ho = H >> 1, Wo = W >> 1;
-    const long npix = (long)B * Ho * Wo;
-    const int tid = threadIdx.x;
-    const long p = (long)blockIdx.x * 256 + tid;
-    const bool valid = p < npix;
-    int n = 0, oy = 0, ox = 0;
-    if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
-    float in[27];
+    float *smem = reinterpret_cast<float *>(smem_raw);
+    float *red = smem + tile_floats;                          // [4 waves][2][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int Ho = H >> 1, Wo = W >> 1, npix = Ho * Wo;
+    const fd_blk3 blk = fd_xcd_image_map2();
+    const int n = blk.z;
+    const int p0 = blk.x * 256;
+    const int p1 = p0 + 256 < npix ? p0 + 256 : npix;
+    const fd_stem_band g = fd_stem_stage_band(x + (long)n * 3 * H * W, smem, H, W, Wo, p0, p1, tid);
+    __syncthreads();
+    const int pw0 = p0 + wave * 64;                           // this wave's 64 pixels
+    float a[2][14];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int m = 0; m < 2; ++m) {
+        const int p = pw0 + 32 * m + i;
+        const bool valid = p < p1;
+        const int pq = valid ? p : p0;
+        const int oy = pq / Wo, ox = pq - oy * Wo;
+        const float *base = smem + (2 * (oy - g.oy_first)) * g.PR + 4 + 2 * ox - 1;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-                const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);   // branch-free: clamp, load, select
-                const float v = x[(((long)n * 3 + c) * H + qy) * W + qx];
-                in[(c * 3 + ky) * 3 + kx] = ok ? v : 0.0f;
-            }
-    for (int c0 = 0; c0 < Cout; c0 += CHUNK) {
-        float acc[CHUNK];
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) acc[j] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 27; ++t)
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) acc[j] = fmaf(in[t], w[(c0 + j) * 27 + t], acc[j]);
-#pragma unroll
-        for (int j = 0; j < CHUNK; j += 4) {
-            fd_f32x4 v = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
-            if (!valid) v = fd_zero4();
-            fd_st4(tile + tid * TS + j, fd_round4(T{}, v));
+        for (int s = 0; s < 14; ++s) {
+            // tap 2s + h of this half-wave in MFMA step s (t = 27: the zero pad); both alternatives have compile-time (c, ky, kx), the lane half selects
+            const int o0 = fd_stem_tap_offset(2 * s, g.nrows, g.PR), o1 = fd_stem_tap_offset(2 * s + 1 < 27 ? 2 * s + 1 : 26, g.nrows, g.PR);
+            const float v = base[h ? o1 : o0];
+            a[m][s] = (valid && 2 * s + h < 27) ? v : 0.0f;
         }
+    }
+    __syncthreads();                                          // the band is consumed: its LDS becomes the output staging area
+    float *otile = smem + wave * 64 * 36;                     // [64 pixels][32 channels + 4]
+    const long blk_row = (long)n * gridDim.x + blk.x;
+    for (int n0 = 0; n0 < Cout; n0 += 32) {
+        const int col = n0 + i;
+        const bool col_ok = col < Cout;
+        float b[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int t = 2 * s + h;
+            b[s] = (col_ok && t < 27) ? w[(long)(col_ok ? col : 0) * 27 + (t < 27 ? t : 0)] : 0.0f;
+        }
+        fd_f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[s], acc[m], 0, 0, 0);
+        }
+        const int cw = Cout - n0 < 32 ? Cout - n0 : 32;       // channels of this chunk (a multiple of 8)
+        const int lsh = cw >= 32 ? 3 : (cw >= 16 ? 2 : 1), lpp = 1 << lsh;     // lanes per pixel (4 channels each): 8, 4 or 2
+        float ssum = 0.0f, ssq = 0.0f;                        // column i over this lane's rows of both tiles (rounded values, valid pixels)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fd_round1(T{}, acc[m][r]);
+                otile[row * 36 + i] = v;
+                if (pw0 + row < p1 && col_ok) { ssum += v; ssq = fmaf(v, v, ssq); }
+            }
+        }
+        fd_wave_lds_fence();                                  // wave-private tile
+        for (int q = lane; q < 64 * lpp; q += 64) {
+            const int px = q >> lsh, c4 = (q & (lpp - 1)) * 4;
+            const int p = pw0 + px;
+            if (p < p1) fd_st4(z + ((long)n * npix + p) * Cout + n0 + c4, fd_ld4(otile + px * 36 + c4));
+        }
+        ssum += __shfl_xor(ssum, 32); ssq += __shfl_xor(ssq, 32);             // the two half-waves hold different rows of column i
+        if (lane < 32) { red[(wave * 2 + 0) * 32 + lane] = ssum; red[(wave * 2 + 1) * 32 + lane] = ssq; }
         __syncthreads();
-        constexpr int Q = CHUNK / 4;
-        for (int f = tid; f < 256 * Q; f += 256) {
-            const int px = f / Q, c4 = f - px * Q;
-            const long gp = (long)blockIdx.x * 256 + px;
-            if (gp < npix) fd_st4(z + gp * Cout + c0 + c4 * 4, fd_ld4(tile + px * TS + c4 * 4));
+        if (tid < 64) {
+            const int which = tid >> 5, c = tid & 31;
+            if (n0 + c < Cout)
+                part[blk_row * 2 * Cout + which * Cout + n0 + c] =
+                    (red[(0 * 2 + which) * 32 + c] + red[(1 * 2 + which) * 32 + c]) + (red[(2 * 2 + which) * 32 + c] + red[(3 * 2 + which) * 32 + c]);
         }
-        // per-channel partial statistics of this workgroup's 256 pixels (invalid pixels hold zeros): 8 work-items per
-        // channel each sum 32 pixels in a fixed order, then a 3-step shuffle
-        {
-            const int c = tid >> 3, part8 = tid & 7;
-            float s = 0.0f, q = 0.0f;
-            if (c < CHUNK) {
-                for (int i = 0; i < 32; ++i) { const float v = tile[(part8 * 32 + i) * TS + c]; s += v; q = fmaf(v, v, q); }
-            }
-            s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
-            s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
-            s += __shfl_xor(s, 4); q += __shfl_xor(q, 4);
-            if (c < CHUNK && part8 == 0) {
-                part[(long)blockIdx.x * 2 * Cout + c0 + c] = s;
-                part[(long)blockIdx.x * 2 * Cout + Cout + c0 + c] = q;
-            }
-        }
-        __syncthreads();
+        __syncthreads();                                      // red and the output tiles are reused by the next channel chunk
     }
 }
 

@@ -38,6 +38,7 @@ struct TLayer {
     int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
+    int stem_band = 0;                                        // floats of the stem kernels' input band in LDS
     int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels
     int chunk = 0;                                            // stem
     int m_tiles = 0, n_tiles = 0, pw_tn = 1;                  // pw (pw_tn: 32-column tiles per wave of the 16-bit forward GEMM)
@@ -168,11 +169,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         int rc = FD_OK;
         switch (d.op) {
         case FD_OP_STEM:
-            switch (L.chunk) {
-            case 32: FD_LAUNCH((fd_stem_train<T, 32>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
-            case 16: FD_LAUNCH((fd_stem_train<T, 16>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
-            default: FD_LAUNCH((fd_stem_train<T, 8>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, plan->B, L.in_h, L.in_w, d.cout); break;
-            }
+            FD_LAUNCH((fd_stem_train<T>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, L.in_h, L.in_w, d.cout, (int)(L.lds / 4) - 4 * 2 * 32);
             rc = check_launch("fd_stem_train");
             break;
         case FD_OP_DW: {
@@ -278,9 +275,15 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             if (d.src != -1 || d.cin != 3 || d.ksize != 3 || d.stride != 2 || d.upsample || d.skip >= 0 || d.cout % 8) FD_BAD("layer %d: bad stem", i);
             L.out_h = L.in_h / 2; L.out_w = L.in_w / 2;
             L.chunk = d.cout % 32 == 0 ? 32 : (d.cout % 16 == 0 ? 16 : 8);
-            L.lds = 256 * (L.chunk + 4) * 4;
-            L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w, 256));
-            L.nblk = (int)L.grid.x;
+            if (d.cout > 64) FD_BAD("layer %d: the stem supports at most 64 output channels", i);
+            {   // blocks of 256 consecutive output pixels of ONE image; LDS: the zero-padded band of input rows under a block (3 planes; reused as
+                // the four waves' [64][36] output tiles) + [4][2][32] statistics
+                const int bpi = ceil_div((long)L.out_h * L.out_w, 256), nrows = 2 * ceil_div(255, L.out_w) + 3;
+                L.stem_band = std::max(3 * nrows * (L.in_w + 8), 4 * 64 * 36);
+                L.lds = (size_t)(L.stem_band + 4 * 2 * 32) * 4;
+                L.grid = dim3(bpi, batch);
+                L.nblk = bpi * batch;
+            }
             L.wp_elems = (size_t)std::min(L.nblk, 512) * 27 * d.cout;
             break;
         case FD_OP_DW: {
