@@ -1436,22 +1436,23 @@ fd_dw_bwd1(const fd_dw_bwd_args<T> a)
 
 
 // ------------------------------------------------------------------------------------------------
-// Stem backward-weights: dW[co][t] = sum_px dz[px][co] * tap[px][t], t over the 27 taps -- a [Cout x P] x [P x 27] matrix
-// product over the P = B*Ho*Wo output pixels.  A workgroup walks blocks of 256 pixels of one image (grid-stride over the nblocks = blocks per
-// image x images blocks of the forward kernel), stages the input band of a block (fd_stem_stage_band: 16-byte row loads) and its dz (formed
-// from G, z on load) in LDS and feeds them to v_mfma_f32_32x32x2_f32: A[i = co][k = pixel], B[k = pixel][j = tap] read straight from the band
-// (a lane's tap offset is fixed, the pixel's base walks along the row), each wave accumulating 64 pixels of every block.
-// wpart[blk][Cout*27], blk = blockIdx.x.  LDS: band + [256][Cout + 1] dz (>= the [4][32][33] reduction tiles).
+// Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps -- a [Cout x P] x [P x 27] matrix
+// product over the P = B*Ho*Wo output pixels.  A workgroup walks blocks of 256 pixels (grid-stride), stages dz (formed from
+// G, z on load) and the 27-tap input patches in LDS and feeds them to v_mfma_f32_32x32x2_f32: A[i = co][k = pixel],
+// B[k = pixel][j = tap], each wave accumulating 64 pixels of every block.  wpart[blk][Cout*27], blk = blockIdx.x.
+// (Staging the input band with 16-byte row loads as the forward kernel does and reading the B operand straight from it was measured
+// slower: 58.6 vs 56.1 us bf16, 77 vs 72 us fp32 -- this kernel is one round of two workgroups per CU, bound by its dz staging and barriers.)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
 fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__restrict__ Z,
-              const float *__restrict__ coef, float *__restrict__ wpart, int H, int W, int Cout, int nblocks, int bpi, int band_floats)
+              const float *__restrict__ coef, float *__restrict__ wpart, int B, int H, int W, int Cout, int nblocks)
 {
     FD_DYN_SMEM(smem_raw);
-    float *s_in = reinterpret_cast<float *>(smem_raw);     // the input band (>= 4 * 32 * 33 floats)
-    float *s_dz = s_in + band_floats;                       // [256][Cout + 1]
-    const int Ho = H >> 1, Wo = W >> 1, npix = Ho * Wo;
+    float *s_in = reinterpret_cast<float *>(smem_raw);     // [256][33]: taps 0..26, zeros in 27..31
+    float *s_dz = s_in + 256 * 33;                          // [256][Cout + 1]
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long npix = (long)B * Ho * Wo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int DP = Cout + 1;
     const int cgroups = (Cout + 31) / 32;                   // 32-channel column groups of the A operand (<= 2 supported)
@@ -1460,14 +1461,25 @@ fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__r
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
-    const int i = lane & 31, kk = lane >> 5;
+    for (int t = 27; t < 32; ++t) s_in[tid * 33 + t] = 0.0f;
     for (int pb = blockIdx.x; pb < nblocks; pb += gridDim.x) {
-        const int n = pb / bpi, bx = pb - n * bpi;
-        const int p0 = bx * 256, p1 = p0 + 256 < npix ? p0 + 256 : npix;
-        const long p = (long)n * npix + p0 + tid;           // this work-item's pixel in the flat [B*Ho*Wo] order of G / Z
-        const bool valid = p0 + tid < p1;
+        const long p = (long)pb * 256 + tid;
+        const bool valid = p < npix;
+        int n = 0, oy = 0, ox = 0;
+        if (valid) { ox = (int)(p % Wo); const long t = p / Wo; oy = (int)(t % Ho); n = (int)(t / Ho); }
         __syncthreads();                                    // the previous block's fragment reads are done
-        const fd_stem_band bd = fd_stem_stage_band(x + (long)n * 3 * H * W, s_in, H, W, Wo, p0, p1, tid);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                    const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);   // branch-free: clamp, load, select
+                    const float v = x[(((long)n * 3 + c) * H + qy) * W + qx];
+                    s_in[tid * 33 + (c * 3 + ky) * 3 + kx] = ok ? v : 0.0f;
+                }
         for (int c = 0; c < Cout; c += 4) {
             fd_f32x4 dz = fd_zero4();
             if (valid) dz = fd_dz4(fd_ld4(G + p * Cout + c), fd_ld4(Z + p * Cout + c), fd_ld4(coef + FD_CF_A * Cout + c), fd_ld4(coef + FD_CF_C1 * Cout + c),
@@ -1475,16 +1487,11 @@ fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__r
             s_dz[tid * DP + c] = dz.x; s_dz[tid * DP + c + 1] = dz.y; s_dz[tid * DP + c + 2] = dz.z; s_dz[tid * DP + c + 3] = dz.w;
         }
         __syncthreads();
-        // B operand: tap i of pixel px (zero for the pad taps i >= 27 and -- through dz = 0 -- for pixels beyond p1)
-        const int toff = fd_stem_tap_offset(i < 27 ? i : 26, bd.nrows, bd.PR);
-        int px = wave * 64 + kk;                            // this half-wave's pixel in MFMA step q: wave*64 + 2q + kk
-        int pq = p0 + px < p1 ? p0 + px : p0;
-        int oy = pq / Wo, ox = pq - oy * Wo;
+        const int i = lane & 31, kk = lane >> 5;
 #pragma unroll 4
         for (int q = 0; q < 32; ++q) {
-            const bool pv = p0 + px < p1;
-            const float bv = s_in[(2 * (oy - bd.oy_first)) * bd.PR + 4 + 2 * ox - 1 + toff];
-            const float b = (pv && i < 27) ? bv : 0.0f;
+            const int px = wave * 64 + 2 * q + kk;
+            const float b = s_in[px * 33 + i];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 if (g < cgroups) {
@@ -1492,9 +1499,6 @@ fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__r
                     const float a = co < Cout ? s_dz[px * DP + co] : 0.0f;
                     acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
                 }
-            px += 2; ox += 2;
-            if (ox >= Wo) { ox -= Wo; ++oy; }
-            if (p0 + px >= p1) { oy = bd.oy_first; ox = 0; }  // beyond the block: any in-band address (the value is masked)
         }
     }
     // cross-wave reduction through LDS: red[wave][32 co][33]

@@ -53,7 +53,7 @@ __device__ __forceinline__ fd_f32x4 fd_round4(fd_half, fd_f32x4 v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem, train mode (forward and weight gradient share the input staging).  A workgroup owns 256 consecutive output pixels [p0, p1) of ONE
+// Stem, train mode, forward.  A workgroup owns 256 consecutive output pixels [p0, p1) of ONE
 // image (grid: blocks per image x images, fd_xcd_image_map2 -- neighbouring blocks' input bands overlap, so an image stays on one XCD's L2).
 // fd_stem_stage_band brings the zero-padded band of input rows under those pixels into LDS with 16-byte row loads (the first
 // generation issued 27 strided 4-byte loads per pixel):  patch[c][r][PR], input column x at index 4 + x (x = -1 at index 3, so that x = 0 is

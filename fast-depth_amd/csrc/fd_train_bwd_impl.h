@@ -398,13 +398,11 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         g_trace_layer = i;
         switch (d.op) {
         case FD_OP_STEM: {
-            const int nb_w = std::min(L.nblk, 512);          // workgroups walk the 256-pixel blocks grid-stride
+            const int nblocks_w = ceil_div((long)plan->B * L.out_h * L.out_w, 256);   // blocks of 256 pixels of the flat [B*Ho*Wo] order (they may straddle images)
+            const int nb_w = std::min(nblocks_w, 512);       // workgroups walk them grid-stride
             if (d.cout > 64) return fail(FD_ERR_INVALID, "stem weight gradient supports at most 64 output channels");
             float *wpart = tws(plan, L.wp_off);
-            const size_t lds_sw = (size_t)(L.stem_band + 256 * (d.cout + 1)) * 4;      // band (>= the [4][32][33] reduction tiles) + dz
-            if (lds_sw > 160 * 1024) return fail(FD_ERR_INVALID, "stem weight gradient: LDS request %zu exceeds 160 KiB", lds_sw);
-            if (lds_sw > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_stem_wgrad<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sw);
-            FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), lds_sw, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, L.in_h, L.in_w, d.cout, L.nblk, (int)L.grid.x, L.stem_band);
+            FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), (size_t)(256 * 33 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout, nblocks_w);
             if ((rc = check_launch("fd_stem_wgrad"))) return rc;
             if ((rc = defer_weights(c, wpart, nb_w, 27 * d.cout, 0, 0, grads[i].conv_weight))) return rc;
             break;
