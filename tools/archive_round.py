@@ -1,6 +1,8 @@
 """Copies the judged summaries of a tools/gpu_round.sh visit from gpurun_out/<tag>/ into profiles/<round>/ (tracked): one
 kernel_stats.csv per configuration (its own rocprofv3 run), the PMC per-kernel means, the bench line, test and smoke logs."""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fd_demangle import demangle
 tag, rnd = sys.argv[1], sys.argv[2]
 src, dst = os.path.join("gpurun_out", tag), os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -24,15 +26,16 @@ for d in glob.glob(os.path.join(src, "pmc_*")):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(m[0])):
-        acc[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        acc[(demangle(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     rest = os.path.basename(d)[4:]
     cfg = next(c for c in ("train_bf16", "train_f32", "pruned_f16", "infer", "f16", "bf16") if rest.startswith(c + "_"))
     ctr = rest[len(cfg) + 1:]
     os.makedirs(os.path.join(dst, cfg), exist_ok=True)
-    w = csv.writer(open(os.path.join(dst, cfg, "pmc_%s_per_kernel.csv" % ctr), "w"))
-    w.writerow(["kernel", "counter", "launches", "mean_value_per_launch"])
-    for (k, c), v in sorted(acc.items()):
-        w.writerow([k, c, len(v), sum(v) / len(v)])
+    with open(os.path.join(dst, cfg, "pmc_%s_per_kernel.csv" % ctr), "w") as fh:        # (closed before the traffic table below reads it back)
+        w = csv.writer(fh)
+        w.writerow(["kernel", "counter", "launches", "mean_value_per_launch"])
+        for (k, c), v in sorted(acc.items()):
+            w.writerow([k, c, len(v), sum(v) / len(v)])
 # profiles/pmc_traffic.json: per-launch HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE
 # reports half the bytes of wide coalesced reads) per configuration -- inference configurations keyed by kernel symbol, train steps keyed by
 # kernel FAMILY (the name before the template arguments: what bench.py's fd_trace aggregates by), launch-weighted.
