@@ -40,9 +40,10 @@ inline int dw_dgrad_rows(const fd_train_plan *p, const TLayer &L)
     // dz patch of 16 x 18 pixels = 41.5 KB stays below the 44.4 KB the paired weight-gradient role needs anyway)
     // (measured, bf16 step: conv1 55.3 -> 52.1 us, conv3 59.2 -> 55.1, conv5 35.3 -> 32.7, 14x14 maps 20.5 -> 19.5)
     if (L.d.ksize == 3 && L.d.stride == 1 && L.mode == 0 && L.in_h % 14 == 0) return 14;
-    const int th = ceil_div(L.in_h, ceil_div(L.in_h, 8));
+    const int th = ceil_div(L.in_h, ceil_div(L.in_h, L.d.ksize == 5 ? FD_T_DW5_DTH : (L.d.stride == 2 ? FD_T_S2_DTH : 8)));
     return (L.mode != 0 || L.d.stride == 2) ? (th + 1) / 2 * 2 : th;     // (stride 2: the tile must hold whole receptive-field rows of its owned outputs)
 }
+inline int dw_dgrad_cols(const TLayer &L) { return L.d.ksize == 5 ? FD_T_DW5_DTW : (L.d.stride == 2 ? FD_T_S2_DTW : 16); }
 // Rows (columns) of the dz patch that an INPUT-space tile of t rows (columns, a multiple of the stride, starting on a multiple of it) reads: the
 // EXACT extent the kernel computes (fd_dw_dgrad_body: PH, PW) -- stride 1: t + K - 1; stride 2: t / 2 + 2.  (Rounds 1-2 requested up to 4 rows and
 // columns more: 58 KB instead of 38 for the 5x5 units = 2 resident workgroups per CU instead of 4.)
@@ -64,7 +65,7 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
     TLayer &L = c.p->layers[i];
     TLayer &P = c.p->layers[L.d.src];
     const int cb = 4 << L.cbq;
-    const int TH = dw_dgrad_rows(c.p, L), TW = 16;
+    const int TH = dw_dgrad_rows(c.p, L), TW = dw_dgrad_cols(L);
     const int tiles_x = ceil_div(L.in_w, TW), tiles_y = ceil_div(L.in_h, TH);
     const int ph = dw_dz_patch(TH, K, S), pw = dw_dz_patch(TW, K, S);
     const size_t lds = dw_bwd_lds(ph, pw, cb, K, L.bpstr);
@@ -162,7 +163,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.part = tws(c.p, c.p->part_off); a.wpart = tws(c.p, L.wp_off);
     a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.pstr = L.bpstr; a.B = c.p->B;
     // backward-data geometry (launch_dw_dgrad)
-    a.d_th = dw_dgrad_rows(c.p, L); a.d_tw = 16;
+    a.d_th = dw_dgrad_rows(c.p, L); a.d_tw = dw_dgrad_cols(L);
     a.d_tiles_x = ceil_div(L.in_w, a.d_tw);
     a.d_gx = a.d_tiles_x * ceil_div(L.in_h, a.d_th); a.d_gy = ceil_div(L.d.cin, cb);
     const int ph = dw_dz_patch(a.d_th, K, S), pw = dw_dz_patch(a.d_tw, K, S);

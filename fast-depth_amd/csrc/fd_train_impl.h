@@ -19,6 +19,19 @@
 // workgroups the pointwise weight-gradient GEMM aims for (output tiles x pixel splits); every split writes a private fp32 partial
 // tile that fd_reduce_partials_f32 sums afterwards, so more splits = more parallelism but more partial traffic
 // (measured at batch 32: 2048 is best for the fp32 kernel; the bf16 one, whose MFMA part is 16x shorter, wants fewer)
+// tile shapes of the 5x5 depthwise train kernels (build switches for tools/build_variant.py sweeps; the defaults are the measured best)
+#ifndef FD_T_DW5_FTH
+#define FD_T_DW5_FTH 8      // forward: rows (balanced over the map), columns
+#define FD_T_DW5_FTW 16
+#define FD_T_DW5_WTH 8      // backward-weights: output-space tile
+#define FD_T_DW5_WTW 16
+#define FD_T_DW5_DTH 8      // backward-data: input-space tile
+#define FD_T_DW5_DTW 16
+#endif
+#ifndef FD_T_S2_DTH
+#define FD_T_S2_DTH 8       // stride-2 units (single-staging backward kernel): input-space tile
+#define FD_T_S2_DTW 16
+#endif
 #ifndef FD_DW_WGRAD_TARGET_WGS
 #define FD_DW_WGRAD_TARGET_WGS 1536   // depthwise weight-gradient kernel: a workgroup walks up to a tile row's tiles as long as about this many workgroups remain
 #endif
@@ -293,13 +306,15 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             const int cb_max = (flags & FD_PLAN_TUNE_DW_CB16) ? 16 : 32;
             const int cb = d.cin >= cb_max ? cb_max : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);
-            L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : 16);
-            L.th = (flags & FD_PLAN_TUNE_DW_TH8) ? std::min(L.out_h, 8) : ceil_div(L.out_h, ceil_div(L.out_h, 8));   // balanced rows: 14 -> 7 + 7 instead of 8 + 6 (both tiles full, smaller patches: one more workgroup per CU)
+            const bool k5 = d.ksize == 5;
+            L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : (k5 ? FD_T_DW5_FTW : 16));
+            L.th = (flags & FD_PLAN_TUNE_DW_TH8) ? std::min(L.out_h, 8) : ceil_div(L.out_h, ceil_div(L.out_h, k5 ? FD_T_DW5_FTH : 8));   // balanced rows: 14 -> 7 + 7 instead of 8 + 6 (both tiles full, smaller patches: one more workgroup per CU)
             // The backward kernels keep these tiles (L.bth / L.btw).  The FORWARD kernel takes larger ones on stride-1 units: a workgroup's life is dominated
             // by fixed costs (tap / table loads ~2 us, barriers, the reduction: 4 us even with no patch loads or stores at all --
             // tools/microbench/dwtrain.hip), so fewer, fatter workgroups win until the patch staging takes too many load rounds:
             // measured 56x56x128: 7x16 39.4 us, 14x28 30.4; 28x28x256: 20.3 -> 14.6; 112x112x32: 8x16 34.9 -> 16x16 32.1; 14x14: 7x16 10.6 -> 14x16 9.1
             L.bth = L.th; L.btw = L.tw;
+            if (k5) { L.btw = std::min((L.out_w + 3) / 4 * 4, FD_T_DW5_WTW); L.bth = ceil_div(L.out_h, ceil_div(L.out_h, FD_T_DW5_WTH)); }
             // (5x5 weight-gradient tiles of 4 rows -- 32 KB of LDS instead of 53 -- measured slower: decode_conv5 156 -> 169 us)
             if (d.ksize == 5 && (flags & FD_PLAN_TUNE_DW_WGRAD_TH4)) L.bth = ceil_div(L.out_h, ceil_div(L.out_h, 4));
             // (3x3 stride-1 weight-gradient tiles of 7 rows -- 39.5 KB instead of 44.4: four resident workgroups per CU -- measured neutral in the paired launch)
@@ -372,6 +387,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.st_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         L.coef_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         max_part = std::max(max_part, (size_t)L.nblk * 2 * d.cout);
+        // (the depthwise backward-data kernel leaves one row of the PRODUCER's statistics per input-space tile: sized for the smallest tile a build
+        // switch may select, 4 rows x 8 columns)
+        if (d.op == FD_OP_DW) max_part = std::max(max_part, (size_t)ceil_div(L.in_w, 8) * ceil_div(L.in_h, 4) * batch * d.cin);
         max_width = std::max(max_width, (size_t)2 * d.cout);
         if (d.op == FD_OP_DW) max_width = std::max(max_width, (size_t)d.ksize * d.ksize * d.cin);
         if (d.op == FD_OP_STEM) max_width = std::max(max_width, (size_t)27 * d.cout);
