@@ -215,6 +215,72 @@ __device__ __forceinline__ bool fd_wg_sum_by_channel_group(fd_f32x4 &a, fd_f32x4
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depthwise 3x3, stride S, train mode, register-window variant (fd_dw3_rows' design: no LDS staging, no barrier before the
+// statistics) for the large maps with a power-of-two channel-group count C/4 in 8 ... 64: a work-item is q = x * (C/4) + c4 (one
+// 16-byte channel group of one output column) and walks down TH output rows keeping the 3 x 3 window of the ACTIVATED input
+// act1(z_in * s1 + t1) in registers -- per output row it loads and activates the 3*S new vectors; the horizontal neighbours are the words its
+// neighbour work-items load (L1 / L2 hits).  Raw weights w[C][9]; output raw z (rounded to T) + this workgroup's per-channel sums of the
+// rounded values: part[blk*2*C + {0, C} + c], blk = (image * gridDim.y + strip) * gridDim.x + column block.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int S, int ACT1>
+__global__ void __launch_bounds__(256)
+fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w, T *__restrict__ zout,
+                  float *__restrict__ part, int H, int W, int Ho, int Wo, int C, int TH)
+{
+    __shared__ float red[4 * 64 * 8];
+    const int CG = C >> 2;                                   // a power of two, 8 <= CG <= 64 (plan)
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int tid = threadIdx.x;
+    const int q = blk.x * 256 + tid;
+    const bool live = q < Wo * CG;
+    const int qq = live ? q : 0;
+    const int xo = qq / CG, c4 = qq - xo * CG;               // (256 % CG == 0: c4 == tid & (CG - 1) for every work-item, live or not)
+    const int n = blk.z;
+    const int oy0 = blk.y * TH;
+    const int oy1 = (oy0 + TH < Ho) ? oy0 + TH : Ho;
+    fd_f32x4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wv[t].x = w[(c4 * 4 + 0) * 9 + t]; wv[t].y = w[(c4 * 4 + 1) * 9 + t]; wv[t].z = w[(c4 * 4 + 2) * 9 + t]; wv[t].w = w[(c4 * 4 + 3) * 9 + t]; }
+    const fd_f32x4 sc = fd_ld4(st1 + FD_ST_SCALE * C + c4 * 4), sh = fd_ld4(st1 + FD_ST_SHIFT * C + c4 * 4);
+    const T *img = zin + (long)n * H * W * C + c4 * 4;
+    const int x0 = xo * S - 1;                               // leftmost input column of the window
+    const bool okl = x0 >= 0, okr = (x0 + 2) < W;            // the centre column x0 + 1 is always inside
+    const int xl = okl ? x0 : x0 + 1, xr = okr ? x0 + 2 : x0 + 1;   // clamped: the three loads are always issued, the padding is a select
+    auto load_row = [&](int iy, fd_f32x4 &l, fd_f32x4 &c, fd_f32x4 &r) {
+        const bool oky = iy >= 0 && iy < H;
+        const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        const T *p = img + (long)qy * W * C;
+        const fd_f32x4 vl = fd_ld4(p + (long)xl * C), vc = fd_ld4(p + (long)(x0 + 1) * C), vr = fd_ld4(p + (long)xr * C);
+        l = (oky && okl) ? fd_bn_act4<ACT1>(vl, sc, sh) : fd_zero4();       // zero padding of the ACTIVATED input
+        c = oky ? fd_bn_act4<ACT1>(vc, sc, sh) : fd_zero4();
+        r = (oky && okr) ? fd_bn_act4<ACT1>(vr, sc, sh) : fd_zero4();
+    };
+    T *o = zout + (((long)n * Ho + oy0) * Wo) * C + (long)qq * 4;
+    fd_f32x4 ssum = fd_zero4(), ssq = fd_zero4();
+    fd_f32x4 r0l, r0c, r0r, r1l, r1c, r1r, r2l, r2c, r2r;
+    load_row(S * oy0 - 1, r0l, r0c, r0r);
+    if (S == 1) load_row(oy0, r1l, r1c, r1r);
+    for (int oy = oy0; oy < oy1; ++oy) {
+        if (S == 1) load_row(oy + 1, r2l, r2c, r2r);
+        else { load_row(2 * oy, r1l, r1c, r1r); load_row(2 * oy + 1, r2l, r2c, r2r); }
+        fd_f32x4 acc = r0l * wv[0];
+        acc += r0c * wv[1]; acc += r0r * wv[2];
+        acc += r1l * wv[3]; acc += r1c * wv[4]; acc += r1r * wv[5];
+        acc += r2l * wv[6]; acc += r2c * wv[7]; acc += r2r * wv[8];
+        const fd_f32x4 zr = fd_round4(T{}, acc);
+        if (live) { fd_st4(o, zr); ssum += zr; ssq += zr * zr; }
+        o += (long)Wo * C;
+        if (S == 1) { r0l = r1l; r0c = r1c; r0r = r1r; r1l = r2l; r1c = r2c; r1r = r2r; }
+        else { r0l = r2l; r0c = r2c; r0r = r2r; }
+    }
+    if (fd_wg_sum_by_channel_group(ssum, ssq, red, CG, tid)) {
+        const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
+        fd_st4(part + row * 2 * C + tid * 4, ssum);
+        fd_st4(part + row * 2 * C + C + tid * 4, ssq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Depthwise K x K, stride S, train mode (LDS-tiled, same geometry as fd_dwconv).
 //   input  = act1(z_in * s1 + t1)                                   (MODE 0)
 //          = up2(act1(z_in * s1 + t1))                              (MODE 1)

@@ -51,6 +51,7 @@ struct TLayer {
     int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
+    int rows_th = 0;                                          // > 0: the forward runs on fd_dw3_rows_train with row strips of this height
     int stem_band = 0;                                        // floats of the stem kernels' input band in LDS
     int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels
     int chunk = 0;                                            // stem
@@ -110,6 +111,11 @@ template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
                     T *zout, float *part, hipStream_t s, int batch)
 {
+    if (L.rows_th) {                                          // register-window kernel (3x3, plain input, large maps)
+        if (L.d.stride == 1) FD_LAUNCH((fd_dw3_rows_train<T, 1, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th);
+        else FD_LAUNCH((fd_dw3_rows_train<T, 2, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th);
+        return check_launch("fd_dw3_rows_train");
+    }
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
 #define FD_DWT(K_, S_, M_)                                                                                                   \
     case K_ * 100 + S_ * 10 + M_:                                                                                            \
@@ -329,6 +335,21 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.lds = (std::max((size_t)th_in * tw_in * L.pstr, (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
+            {   // FORWARD of the 3x3 units on plain inputs whose channel-group count C/4 is a power of two in 8 ... 64 (32 ... 256 channels: the
+                // large maps; the plan takes it up to 128 channels): the register-window kernel (fd_dw3_rows_train, no LDS staging); row strips as high as still leave >= ~1024 workgroups
+                const int cg = d.cin / 4;
+                const bool rows_ok = d.ksize == 3 && L.mode == 0 && d.cin % 4 == 0 && cg >= 8 && cg <= 64 && (cg & (cg - 1)) == 0;
+                // measured (bf16, us, rows vs tiled): conv1.0 19.2 / 22.9, conv2.0 15.1 / 29.2, conv3.0 19.0 / 21.1, conv4.0 10.5 / 15.1, conv5.0 (256 channels) 13.8 / 11.7
+                if (rows_ok && !(flags & FD_PLAN_TUNE_DW_NO_ROWS) && (((long)L.out_h * L.out_w >= 28 * 28 && cg <= 32) || (flags & FD_PLAN_TUNE_DW_FORCE_ROWS))) {
+                    const int gx = ceil_div((long)L.out_w * cg, 256);
+                    int th = L.out_h;
+                    while (th > 4 && (long)gx * ceil_div(L.out_h, th) * batch < 1024) th = (th + 1) / 2;
+                    L.rows_th = th;
+                    L.grid = dim3(gx, ceil_div(L.out_h, th), batch);
+                    L.nblk = gx * ceil_div(L.out_h, th) * batch;
+                    L.lds = 0;
+                }
+            }
             const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
                 // up to 8 rows) -- sized for the larger count

@@ -38,6 +38,8 @@ FD_PLAN_TUNE_DW_SMALL_TILES = 33554432
 FD_PLAN_TUNE_DW_PITCH4 = 67108864
 FD_PLAN_TUNE_DW_PITCH8 = 134217728
 FD_PLAN_TUNE_DW_WGRAD_TH4 = 268435456
+FD_PLAN_TUNE_DW_NO_ROWS = 536870912
+FD_PLAN_TUNE_DW_FORCE_ROWS = 1073741824
 
 
 class LayerDesc(ctypes.Structure):

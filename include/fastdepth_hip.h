@@ -68,6 +68,8 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_TUNE_DW_PITCH4 67108864u   /* tuning aid (train plans): the depthwise kernels' LDS patch pitch is 4 floats (PITCH8: 8; both: 12) above the default */
 #define FD_PLAN_TUNE_DW_PITCH8 134217728u
 #define FD_PLAN_TUNE_DW_WGRAD_TH4 268435456u /* tuning aid (train plans): the 5x5 depthwise weight-gradient workgroups take output tiles of 4 rows instead of 7..8 (32 KB of LDS instead of 53) */
+#define FD_PLAN_TUNE_DW_NO_ROWS 536870912u   /* tuning aid (train plans): the 3x3 depthwise forward always runs on the LDS-tiled kernel (default: the register-window kernel fd_dw3_rows_train on the large maps with 32 ... 256 channels) */
+#define FD_PLAN_TUNE_DW_FORCE_ROWS 1073741824u /* tests: the register-window kernel on every eligible 3x3 unit whatever the map size */
 #define FD_PLAN_TUNE_DW_TH8 524288u        /* tuning aid (train plans): depthwise tiles of 8 rows with a ragged last tile (round 1/2) instead of balanced row counts */
 #define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */

@@ -154,7 +154,8 @@ def assert_local_parity(rep, dtype):
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD1), ("ragged", RAGGED, torch.float32, capi.FD_PLAN_TUNE_DW_BWD1),
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_PITCH8),
                                                    ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_WGRAD_TH4),
-                                                   ("tiny_tall", TINY, torch.bfloat16, 0)])
+                                                   ("tiny_tall", TINY, torch.bfloat16, 0),
+                                                   ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_FORCE_ROWS)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     """Every unit's forward and backward kernels on their own stored inputs against an fp64 single-unit autograd reference
     (harness.local_train_parity): the rigorous check of the bf16 train plan, whose end-to-end
