@@ -149,11 +149,10 @@ def assert_local_parity(rep, dtype):
 @pytest.mark.parametrize("name,plan,dtype,flags", [("tiny", TINY, torch.float32, 0), ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_WGRAD_TILE_ROWS),
                                                    ("ragged", RAGGED, torch.bfloat16, 0), ("tiny_wide", TINY, torch.float32, 0),
                                                    ("tiny_sat6", TINY, torch.float32, 0), ("ragged_sat6", RAGGED, torch.bfloat16, 0),
-                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_NO_BWD_PAIRING), ("ragged", RAGGED, torch.bfloat16, capi.FD_PLAN_NO_BWD_PAIRING),
+                                                   ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_NO_BWD_PAIRING),
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD_PAIR),
-                                                   ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD1), ("ragged", RAGGED, torch.float32, capi.FD_PLAN_TUNE_DW_BWD1),
-                                                   ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_PITCH8),
-                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_WGRAD_TH4),
+                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_BWD1),
+                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_PITCH8 | capi.FD_PLAN_TUNE_DW_WGRAD_TH4),
                                                    ("tiny_tall", TINY, torch.bfloat16, 0),
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_FORCE_ROWS)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
