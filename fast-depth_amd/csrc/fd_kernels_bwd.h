@@ -1436,6 +1436,165 @@ fd_dw_bwd1(const fd_dw_bwd_args<T> a)
 
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the 3x3 STRIDE-2 depthwise units on the large maps, register-window form (the forward's fd_dw3_rows_train design: no LDS
+// staging; channel-group count C/4 a power of two in 8 ... 64).  Two kernels:
+//
+// fd_dw3s2_dgrad_rows -- a work-item is q = x_in * (C/4) + c4, one 16-byte channel group of one INPUT column, and walks down pairs of input
+// rows (2b, 2b+1).  With  out(oy, ox) = sum in(2oy-1+ky, 2ox-1+kx) w[ky][kx]  an input column x = 2a receives only ox = a through kx = 1, a
+// column x = 2a+1 receives ox = a through kx = 2 and ox = a+1 through kx = 0; rows likewise.  So per row pair the work-item needs dz at two
+// columns (A = x/2, B = x/2 + 1) of two output rows (b: kept from the previous pair, b+1: loaded), and six vector FMAs with taps selected
+// once by the column's parity:   din(2b, x)   = dzA(b) wA[1] + dzB(b) wB[1]
+//                                din(2b+1, x) = dzA(b) wA[2] + dzB(b) wB[2] + dzA(b+1) wA[0] + dzB(b+1) wB[0].
+// Epilogue per input pixel as in fd_dw_dgrad (skip-gradient add, producer's activation mask, rounding, BN partials of the producer):
+// part[blk*2*C + {0, C} + c], blk = (image * gridDim.y + strip) * gridDim.x + column block.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int ACT_IN, int ADD_SG>
+__global__ void __launch_bounds__(256)
+fd_dw3s2_dgrad_rows(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef, const float *__restrict__ w,
+                    const T *__restrict__ Zin, const float *__restrict__ st_in, const T *__restrict__ SG, T *__restrict__ Gin,
+                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int TH2)
+{
+    __shared__ float red[4 * 64 * 8];
+    const int CG = C >> 2;
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int tid = threadIdx.x;
+    const int q = blk.x * 256 + tid;
+    const bool live = q < Win * CG;
+    const int qq = live ? q : 0;
+    const int x = qq / CG, c4 = qq - x * CG;
+    const int n = blk.z;
+    const int b0 = blk.y * TH2, H2 = Hin >> 1;
+    const int b1 = (b0 + TH2 < H2) ? b0 + TH2 : H2;
+    const int cg = c4 * 4;
+    const bool odd = x & 1;
+    const int oxA = x >> 1, oxB = (x >> 1) + 1;
+    const bool okB = odd && oxB < Wo;
+    fd_f32x4 wA[3], wB[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ka = odd ? 2 : 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wA[ky][j] = w[(cg + j) * 9 + ky * 3 + ka];
+            const float wb = w[(cg + j) * 9 + ky * 3 + 0];
+            wB[ky][j] = okB ? wb : 0.0f;
+        }
+    }
+    const fd_f32x4 cA = fd_ld4(coef + FD_CF_A * C + cg), c1 = fd_ld4(coef + FD_CF_C1 * C + cg), cM = fd_ld4(coef + FD_CF_MU * C + cg), c2 = fd_ld4(coef + FD_CF_C2 * C + cg);
+    const fd_f32x4 sc = fd_ld4(st_in + FD_ST_SCALE * C + cg), sh = fd_ld4(st_in + FD_ST_SHIFT * C + cg);
+    const fd_f32x4 mu = fd_ld4(st_in + FD_ST_MEAN * C + cg), is = fd_ld4(st_in + FD_ST_INVSTD * C + cg);
+    const int qB = okB ? oxB : oxA;                          // clamped column: the load is always issued, wB is zero where B does not exist
+    auto load_dz = [&](int oy, fd_f32x4 &a, fd_f32x4 &b) {
+        const bool ok = oy < Ho;
+        const long row = ((long)n * Ho + (ok ? oy : Ho - 1)) * Wo;
+        const long oa = (row + oxA) * C + cg, ob = (row + qB) * C + cg;
+        const fd_f32x4 da = fd_dz4(fd_ld4(G + oa), fd_ld4(Z + oa), cA, c1, cM, c2), db = fd_dz4(fd_ld4(G + ob), fd_ld4(Z + ob), cA, c1, cM, c2);
+        a = ok ? da : fd_zero4(); b = ok ? db : fd_zero4();
+    };
+    fd_f32x4 ssum = fd_zero4(), ssx = fd_zero4();
+    fd_f32x4 dA, dB, nA, nB;
+    load_dz(b0, dA, dB);
+    for (int b = b0; b < b1; ++b) {
+        const long o0 = (((long)n * Hin + 2 * b) * Win + x) * C + cg, o1 = o0 + (long)Win * C;
+        const fd_f32x4 z0 = fd_ld4(Zin + o0), z1 = fd_ld4(Zin + o1);              // requested together with the next dz row
+        fd_f32x4 g0 = fd_zero4(), g1 = fd_zero4();
+        if (ADD_SG) { g0 = fd_ld4(SG + o0); g1 = fd_ld4(SG + o1); }
+        load_dz(b + 1, nA, nB);
+        fd_f32x4 v0 = dA * wA[1] + dB * wB[1];
+        fd_f32x4 v1 = (dA * wA[2] + dB * wB[2]) + (nA * wA[0] + nB * wB[0]);
+        if (ADD_SG) { v0 += g0; v1 += g1; }
+        v0 = fd_round4(T{}, v0 * fd_actmask4<ACT_IN>(z0 * sc + sh));
+        v1 = fd_round4(T{}, v1 * fd_actmask4<ACT_IN>(z1 * sc + sh));
+        if (live) {
+            fd_st4(Gin + o0, v0); fd_st4(Gin + o1, v1);
+            ssum += v0; ssx += v0 * ((z0 - mu) * is);
+            ssum += v1; ssx += v1 * ((z1 - mu) * is);
+        }
+        dA = nA; dB = nB;
+    }
+    if (fd_wg_sum_by_channel_group(ssum, ssx, red, CG, tid)) {
+        const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
+        fd_st4(part + row * 2 * C + tid * 4, ssum);
+        fd_st4(part + row * 2 * C + C + tid * 4, ssx);
+    }
+}
+
+// fd_dw3_wgrad_rows -- dW[c][ky][kx] = sum dz(oy, ox) a_in(S oy - 1 + ky, S ox - 1 + kx): a work-item is q = x_out * (C/4) + c4 and walks down TH
+// output rows with the 3 x 3 window of the activated input in registers (as the forward) and nine vector accumulators; at the end the
+// accumulators of the work-items that share a channel group meet by shuffle butterfly (within a wave) and one LDS hop (across the four
+// waves).  wpart[(blk*9 + t)*C + c], tap-major like the other depthwise weight-gradient kernels.
+template <typename T, int S, int ACT1>
+__global__ void __launch_bounds__(256)
+fd_dw3_wgrad_rows(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ G, const T *__restrict__ Z,
+                  const float *__restrict__ coef, float *__restrict__ wpart, int H, int W, int Ho, int Wo, int C, int TH)
+{
+    __shared__ float red[4 * 64 * 36];                      // [wave][channel group][9 taps][4]
+    const int CG = C >> 2;
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blk.x * 256 + tid;
+    const bool live = q < Wo * CG;
+    const int qq = live ? q : 0;
+    const int xo = qq / CG, c4 = qq - xo * CG;
+    const int n = blk.z, cg = c4 * 4;
+    const int oy0 = blk.y * TH;
+    const int oy1 = (oy0 + TH < Ho) ? oy0 + TH : Ho;
+    const fd_f32x4 sc = fd_ld4(st1 + FD_ST_SCALE * C + cg), sh = fd_ld4(st1 + FD_ST_SHIFT * C + cg);
+    const fd_f32x4 cA = fd_ld4(coef + FD_CF_A * C + cg), c1 = fd_ld4(coef + FD_CF_C1 * C + cg), cM = fd_ld4(coef + FD_CF_MU * C + cg), c2 = fd_ld4(coef + FD_CF_C2 * C + cg);
+    const T *img = zin + (long)n * H * W * C + cg;
+    const int x0 = xo * S - 1;
+    const bool okl = x0 >= 0, okr = (x0 + 2) < W;
+    const int xl = okl ? x0 : x0 + 1, xr = okr ? x0 + 2 : x0 + 1;
+    auto load_row = [&](int iy, fd_f32x4 &l, fd_f32x4 &c, fd_f32x4 &r) {
+        const bool oky = iy >= 0 && iy < H;
+        const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        const T *p = img + (long)qy * W * C;
+        const fd_f32x4 vl = fd_ld4(p + (long)xl * C), vc = fd_ld4(p + (long)(x0 + 1) * C), vr = fd_ld4(p + (long)xr * C);
+        l = (oky && okl) ? fd_bn_act4<ACT1>(vl, sc, sh) : fd_zero4();
+        c = oky ? fd_bn_act4<ACT1>(vc, sc, sh) : fd_zero4();
+        r = (oky && okr) ? fd_bn_act4<ACT1>(vr, sc, sh) : fd_zero4();
+    };
+    fd_f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = fd_zero4();
+    fd_f32x4 r0l, r0c, r0r, r1l, r1c, r1r, r2l, r2c, r2r;
+    load_row(S * oy0 - 1, r0l, r0c, r0r);
+    if (S == 1) load_row(oy0, r1l, r1c, r1r);
+    const T *gp = G + (((long)n * Ho + oy0) * Wo) * C + (long)qq * 4, *zp = Z + (((long)n * Ho + oy0) * Wo) * C + (long)qq * 4;
+    for (int oy = oy0; oy < oy1; ++oy) {
+        const fd_f32x4 gv = fd_ld4(gp), zv = fd_ld4(zp);
+        if (S == 1) load_row(oy + 1, r2l, r2c, r2r);
+        else { load_row(2 * oy, r1l, r1c, r1r); load_row(2 * oy + 1, r2l, r2c, r2r); }
+        const fd_f32x4 dz = live ? fd_dz4(gv, zv, cA, c1, cM, c2) : fd_zero4();
+        acc[0] += dz * r0l; acc[1] += dz * r0c; acc[2] += dz * r0r;
+        acc[3] += dz * r1l; acc[4] += dz * r1c; acc[5] += dz * r1r;
+        acc[6] += dz * r2l; acc[7] += dz * r2c; acc[8] += dz * r2r;
+        gp += (long)Wo * C; zp += (long)Wo * C;
+        if (S == 1) { r0l = r1l; r0c = r1c; r0r = r1r; r1l = r2l; r1c = r2c; r1r = r2r; }
+        else { r0l = r2l; r0c = r2c; r0r = r2r; }
+    }
+    // lanes c4, c4 + CG, ... of a wave hold the same channel group (256 % CG == 0): butterfly, then the four wave sums through LDS
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        for (int m = CG; m < 64; m <<= 1) {
+            acc[t].x += __shfl_xor(acc[t].x, m); acc[t].y += __shfl_xor(acc[t].y, m); acc[t].z += __shfl_xor(acc[t].z, m); acc[t].w += __shfl_xor(acc[t].w, m);
+        }
+    if (lane < CG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) fd_st4(red + ((wave * CG + lane) * 9 + t) * 4, acc[t]);
+    }
+    __syncthreads();
+    const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
+    for (int i = tid; i < 9 * CG; i += 256) {
+        const int t = i / CG, c = i - t * CG;
+        fd_f32x4 s = fd_ld4(red + ((0 * CG + c) * 9 + t) * 4);
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) s += fd_ld4(red + ((wv * CG + c) * 9 + t) * 4);
+        fd_st4(wpart + (row * 9 + t) * C + c * 4, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stem backward-weights: dW[co][t] = sum_px dz[px][co] * patch[px][t], t over the 27 taps -- a [Cout x P] x [P x 27] matrix
 // product over the P = B*Ho*Wo output pixels.  A workgroup walks blocks of 256 pixels (grid-stride), stages dz (formed from
 // G, z on load) and the 27-tap input patches in LDS and feeds them to v_mfma_f32_32x32x2_f32: A[i = co][k = pixel],

@@ -180,6 +180,35 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const size_t lds = std::max(lds_d, lds_w);
     if (lds > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 160 KiB", lds);
     const int kk = K * K;
+    // The stride-2 3x3 units of the large maps (channel-group count a power of two in 8 ... 64): two register-window kernels without LDS staging
+    // (fd_dw3s2_dgrad_rows over input columns, fd_dw3_wgrad_rows over output columns), row strips as high as still leave >= ~1024 workgroups
+    {
+        const int cgn = L.d.cin / 4;
+        const bool rows_ok = K == 3 && S == 2 && MODE == 0 && L.d.cin % 4 == 0 && cgn >= 8 && cgn <= 64 && (cgn & (cgn - 1)) == 0 &&
+                             (((long)L.out_h * L.out_w >= 28 * 28 && sizeof(T) == 2) || (c.p->flags & FD_PLAN_TUNE_DW_FORCE_ROWS));
+        // measured (us, rows pair vs single-staging kernel): bf16 conv2.0 48.9 + 16.8 vs 79.3, conv4.0 33.4 + 11.0 vs 48.2, conv6.0 (14x14 outputs) 23.4 + 7.8 vs 29.6;
+        // fp32 conv2.0 69.0 + 26.7 vs 96.2, conv4.0 40.7 + 15.3 vs 55.2 (equal: both forms move the fp32 bytes at the same rate) -> 16-bit plans, maps >= 28x28
+        if (rows_ok && !(c.p->flags & (FD_PLAN_TUNE_DW_NO_ROWS | FD_PLAN_TUNE_DW_BWD_PAIR | FD_PLAN_TUNE_DW_BWD1))) {
+            const int gxd = ceil_div((long)L.in_w * cgn, 256), h2 = L.in_h / 2;
+            int th2 = h2;
+            while (th2 > 2 && (long)gxd * ceil_div(h2, th2) * c.p->B < 1024) th2 = (th2 + 1) / 2;
+            const int gyd = ceil_div(h2, th2);
+            FD_LAUNCH((fd_dw3s2_dgrad_rows<T, ACT1, ADD_SG>), dim3(gxd, gyd, c.p->B), dim3(256), 0, c.s, a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.part,
+                      L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, th2);
+            int rcr = check_launch("fd_dw3s2_dgrad_rows");
+            if (rcr) return rcr;
+            const int gxw = ceil_div((long)L.out_w * cgn, 256);
+            int thw = L.out_h;
+            while (thw > 4 && (long)gxw * ceil_div(L.out_h, thw) * c.p->B < 1024) thw = (thw + 1) / 2;
+            const int gyw = ceil_div(L.out_h, thw), wrows = gxw * gyw * c.p->B;
+            if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+            FD_LAUNCH((fd_dw3_wgrad_rows<T, 2, ACT1>), dim3(gxw, gyw, c.p->B), dim3(256), 0, c.s, a.Zin, a.st_in, a.G, a.Z, a.coef, a.wpart,
+                      L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, thw);
+            if ((rcr = check_launch("fd_dw3_wgrad_rows"))) return rcr;
+            *nblk_out = gxd * gyd * c.p->B;
+            return defer_weights(c, a.wpart, wrows, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
+        }
+    }
     // measured (bf16, batch 32): the single-staging kernel wins on the stride-2 units (conv2.0 84 vs 103 us, conv4.0 50 vs 57, conv6.0 31 vs 35) and
     // loses on the stride-1 3x3 ones (conv1.0 68 vs 57, 14x14 maps 22.4 vs 19.5: two tap phases back to back in one workgroup at lower residency);
     // the 5x5 units tie.  FD_PLAN_TUNE_DW_BWD1 forces it everywhere (tests), FD_PLAN_TUNE_DW_BWD_PAIR nowhere.
