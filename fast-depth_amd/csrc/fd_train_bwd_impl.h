@@ -209,6 +209,8 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             return defer_weights(c, a.wpart, wrows, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
         }
     }
+    // (stride-1 3x3 units: the LDS-tiled backward-data kernel on its own + fd_dw3_wgrad_rows instead of the paired launch measured equal -- conv1.0
+    // 31.2 + 20.3 vs 52.8 us, conv3.0 34.8 + 20.5 vs 56.4, conv5.0 22.1 + 14.6 vs 33.1 -- the pair stays)
     // measured (bf16, batch 32): the single-staging kernel wins on the stride-2 units (conv2.0 84 vs 103 us, conv4.0 50 vs 57, conv6.0 31 vs 35) and
     // loses on the stride-1 3x3 ones (conv1.0 68 vs 57, 14x14 maps 22.4 vs 19.5: two tap phases back to back in one workgroup at lower residency);
     // the 5x5 units tie.  FD_PLAN_TUNE_DW_BWD1 forces it everywhere (tests), FD_PLAN_TUNE_DW_BWD_PAIR nowhere.
