@@ -244,7 +244,7 @@ Pw16Cfg choose_pw16(long M, int N, int K, bool force)
     return best;
 }
 
-int pw_lds_bytes(const PwCfg &c) { return 3 * (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 32 * 4; }   // 3-stage ring of 128-byte rows
+int pw_lds_bytes(const PwCfg &c) { return FD_F32_STAGES * (c.wgm * c.tm * 32 + c.wgn * c.tn * 32) * 32 * 4; }   // 3-stage ring of 128-byte rows
 
 int ilog2(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 

@@ -372,6 +372,9 @@ fd_dw3_rows(const T *__restrict__ in, const float *__restrict__ wp, const float 
 //    consecutive slots on ONE XCD so the A panel is fetched into that XCD's L2 once; weights stay L2 resident.
 // Ragged M / N: source rows are clamped (finite garbage in rows that are never stored).
 // ------------------------------------------------------------------------------------------------
+#ifndef FD_F32_STAGES
+#define FD_F32_STAGES 3      // depth of the LDS-DMA ring of fd_pw_gemm_f32 (build switch: 2 = 33 KB per 64 x 64 workgroup)
+#endif
 template <int WGM, int WGN, int TM, int TN, int ACT>
 __global__ void __launch_bounds__(64 * WGM * WGN)
 fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
@@ -407,7 +410,7 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
         else { int row = n0 + (r - BM); if (row > N - 1) row = N - 1; src[i] = Wt + (long)row * K32; }
     }
     auto issue = [&](int t) {
-        float *dst = smem + (t % 3) * STAGE + wave * 8 * BK;
+        float *dst = smem + (t % FD_F32_STAGES) * STAGE + wave * 8 * BK;
 #pragma unroll
         for (int i = 0; i < RG; ++i) {
             int k = t * BK + src_chunk[i];
@@ -447,11 +450,11 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
 
     const int T = K32 / BK;
     issue(0);
-    if (T > 1) issue(1);
+    if (FD_F32_STAGES > 2 && T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();   // leave only tile t+1's loads in flight
+        if (FD_F32_STAGES > 2 && t + 1 < T) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();   // leave only tile t+1's loads in flight
         fd_block_barrier();                                  // tile t landed for every wave; stage (t+2)%3 is free again
-        const float *cur = smem + (t % 3) * STAGE;
+        const float *cur = smem + (t % FD_F32_STAGES) * STAGE;
         // software pipeline inside the K tile: the fragments of chunk pair g+1 are requested before the MFMAs of
         // pair g are issued, and the LDS-DMA for tile t+2 is issued under the first fragment reads' latency
         fd_f32x4 a[2][TM], b[2][TN];
@@ -459,7 +462,7 @@ fd_pw_gemm_f32(const float *__restrict__ A, const float *__restrict__ Wt, const 
         for (int i = 0; i < TM; ++i) a[0][i] = fd_ld4(cur + a_off[i][0]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[0][j] = fd_ld4(cur + b_off[j][0]);
-        if (t + 2 < T) issue(t + 2);
+        if (t + FD_F32_STAGES - 1 < T) issue(t + FD_F32_STAGES - 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < 3) {
