@@ -38,7 +38,9 @@
 #ifndef FD_WGRAD_TUNE_H16
 #define FD_WGRAD_TUNE_H16 640      // (round 3, paired launch: 640 -> 2.840 ms per bf16 step, 1024 -> 2.877, 512 -> 2.860; fewer splits = fewer partial bytes)
 #endif
-#define FD_WGRAD_TARGET_WGS_F32 2048
+#ifndef FD_WGRAD_TARGET_WGS_F32
+#define FD_WGRAD_TARGET_WGS_F32 1536   // (round 3, paired launch: 1024 -> 4.355 ms per fp32 step, 1536 -> 4.340, 2048 -> 4.361, 3072 -> 4.364)
+#endif
 #define FD_WGRAD_TARGET_WGS_H16 (FD_WGRAD_TUNE_H16)
 
 namespace {
