@@ -388,12 +388,12 @@ int launch_dwpw(const fd_plan *p, const Layer &L, float *out, float *y, hipStrea
 }
 
 template <int ACT>
-int launch_pw_t(const fd_plan *plan, const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s)
+int launch_pw_t(const fd_plan *plan, const Layer &L, const float *A, const void *wp, const float *bias, float *out, long M, hipStream_t s, float * = nullptr)
 {
     return launch_pw<ACT>(plan, L, A, static_cast<const float *>(wp), bias, out, M, s);
 }
 template <int ACT, typename T>
-int launch_pw_t(const fd_plan *plan, const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s)
+int launch_pw_t(const fd_plan *plan, const Layer &L, const T *A, const void *wp, const float *bias, T *out, long M, hipStream_t s, float *y = nullptr)
 {
     const int K = L.d.cin;
     if (L.pw16_tm) {                                         // fd_pw_gemm16_h16: whole frames per workgroup, optionally with the consuming depthwise layer
@@ -423,6 +423,15 @@ int launch_pw_t(const fd_plan *plan, const Layer &L, const T *A, const void *wp,
 #undef FD_PW16H_LAUNCH
         return check_launch("fd_pw_gemm16_h16");
     }
+    if (L.fuse_head >= 0) {                                  // the network head on this GEMM's output tile (cout <= 32): one launch, no intermediate tensor
+        const Layer &H = plan->layers[L.fuse_head];
+        fd_pw_head hd{};
+        hd.w = reinterpret_cast<const float *>(plan->ws + H.w_off); hd.b = reinterpret_cast<const float *>(plan->ws + H.b_off);
+        hd.y = y; hd.act = H.d.act == FD_ACT_RELU6 ? 2 : (H.d.act == FD_ACT_RELU ? 1 : 0); hd.up = H.d.upsample; hd.h = L.out_h; hd.w_ = L.out_w;
+        FD_LAUNCH((fd_pw_gemm_head_h16<T, ACT>), L.grid, dim3(256), L.lds, s, A, static_cast<const T *>(wp), bias, (int)M, L.d.cout, K, (K + 63) / 64 * 64,
+                  L.m_tiles, L.n_tiles, hd);
+        return check_launch("fd_pw_gemm_head_h16");
+    }
     FD_LAUNCH((fd_pw_gemm_h16<T, ACT>), L.grid, dim3(256), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, (K + 63) / 64 * 64,
               L.m_tiles, L.n_tiles);
     return check_launch("fd_pw_gemm_h16");
@@ -451,7 +460,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
             if constexpr (std::is_same<T, float>::value) return launch_dwpw<ACT>(p, L, out, y, s);
             else return fail(FD_ERR_INVALID, "fused units are fp32 only");
         }
-        return launch_pw_t<ACT>(p, L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s);
+        return launch_pw_t<ACT>(p, L, in, wp, bias, out, (long)p->B * L.out_h * L.out_w, s, y);
     }
     return fail(FD_ERR_INVALID, "bad op");
 }
@@ -729,6 +738,22 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         }
     }
 
+    // 16-bit plans: the network head behind a pointwise layer of <= 32 channels (decode_conv5.1 -> decode_conv6) rides on that GEMM's output tile
+    // (fd_pw_gemm_head_h16): the 112x112xC tensor is neither written nor re-read and the head's launch disappears
+    if (dtype != FD_F32 && !(flags & (FD_PLAN_KEEP_ACTIVATIONS | FD_PLAN_NO_EPILOGUE_FUSION))) {
+        std::vector<int> rd(n_layers, 0);
+        for (int i = 0; i < n_layers; ++i) {
+            if (p->layers[i].d.src >= 0) ++rd[p->layers[i].d.src];
+            if (p->layers[i].d.skip >= 0) ++rd[p->layers[i].d.skip];
+        }
+        for (int i = 0; i + 1 < n_layers; ++i) {
+            Layer &Pw = p->layers[i], &H = p->layers[i + 1];
+            if (Pw.d.op != FD_OP_PW || Pw.head || Pw.pw16_tm || Pw.dwpw || Pw.fuse_next_dw >= 0 || Pw.skipped || Pw.fused_into >= 0 || Pw.to_output) continue;
+            if (!H.head || H.d.src != i || H.d.skip >= 0 || rd[i] != 1 || H.d.cin != Pw.d.cout || Pw.d.cout > 32 || Pw.d.cout % 8 || Pw.n_tiles != 1) continue;
+            Pw.fuse_head = i + 1; H.fused_into = i;
+        }
+    }
+
     // activation arena
     std::vector<int> last_use(n_layers, -1);
     for (int i = 0; i < n_layers; ++i) {
@@ -780,7 +805,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         if (L.skipped)
             snprintf(buf, sizeof buf, "(fused into layer %d)", i + 1);
         else if (L.fused_into >= 0 && L.head)
-            snprintf(buf, sizeof buf, "(pointwise head evaluated on the accumulators of layer %d's dwpw kernel)", L.fused_into);
+            snprintf(buf, sizeof buf, "(pointwise head evaluated on the accumulators of layer %d's %s kernel)", L.fused_into, p->layers[L.fused_into].dwpw ? "dwpw" : "pw_gemm");
         else if (L.fused_into >= 0)
             snprintf(buf, sizeof buf, "(dw k%d s%d%s evaluated in the epilogue of layer %d's pw_gemm16)", d.ksize, d.stride, d.upsample ? " on up2" : "", L.fused_into);
         else if (L.dwpw)
@@ -803,7 +828,8 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.fuse_next_dw >= 0 ? (void)snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " + fused dw k%d of layer %d", p->layers[L.fuse_next_dw].d.ksize, L.fuse_next_dw) : (void)0;
             else
             snprintf(buf, sizeof buf, "pw_gemm<%dx%d> M=%ld N=%d K=%d tiles=%dx%d lds=%zu", L.pw.wgm * L.pw.tm * 32,
-                     L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds);
+                     L.pw.wgn * L.pw.tn * 32, (long)batch * L.out_h * L.out_w, d.cout, d.cin, L.m_tiles, L.n_tiles, L.lds),
+            (L.fuse_head >= 0 && !L.dwpw) ? (void)snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " + the %d->1 head on its output tile", d.cout) : (void)0;
         L.info = buf;
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
         if (L.skipped || L.fused_into >= 0) buf[0] = 0;
@@ -815,6 +841,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (L.pw16_tm && dtype != FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm16_h16<%s, %d, 4, %d, %d>", tn, L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0, %d>", L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
+        else if (L.fuse_head >= 0) snprintf(buf, sizeof buf, "fd_pw_gemm_head_h16<%s, %d>", tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);
         L.sym = buf;
     }

@@ -32,10 +32,12 @@ __device__ __forceinline__ fd_f32x16 fd_mfma_32x32x16(fd_bf16, fd_u16x8 a, fd_u1
 #ifndef FD_H16_STAGES
 #define FD_H16_STAGES 3
 #endif
-template <typename T, int ACT>
-__global__ void __launch_bounds__(256)
-fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *__restrict__ bias, T *__restrict__ out,
-               int M, int N, int K, int K64, int m_tiles, int n_tiles)
+// the network head (Cout -> 1 pointwise + activation, nearest x2) evaluated on this GEMM's output tile instead of a launch of its own
+struct fd_pw_head { const float *w, *b; float *y; int act, up, h, w_; };
+template <typename T, int ACT, int HEAD>
+__device__ __forceinline__ void
+fd_pw_gemm_h16_body(const T *__restrict__ A, const T *__restrict__ Wt, const float *__restrict__ bias, T *__restrict__ out,
+               int M, int N, int K, int K64, int m_tiles, int n_tiles, const fd_pw_head hd)
 {
     constexpr int BM = 64, BN = 64, BK = 64;                // BK elements = 128 bytes per LDS row
     constexpr int ROWS = BM + BN, STAGE = ROWS * 128;        // bytes per stage
@@ -111,6 +113,28 @@ fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *_
         fd_st1(tile + row * 40 + col, fd_act<ACT>(acc[r]));
     }
     __syncthreads();
+    if (HEAD) {
+        // N <= 32: the wn == 0 waves' tiles hold every channel of their 32 pixels (rounded to T like the stored tensor the separate head kernel
+        // would read); lane = pixel: y = act_h(sum_c tile[c] * w_h[c] + b_h), written as a 2x2 block of the full-resolution output (or 1:1)
+        if (wn == 0 && lane < 32) {
+            const long p = m0 + wm * 32 + lane;
+            if (p < M) {
+                float acc1 = hd.b[0];
+                for (int c = 0; c < N; ++c) acc1 = fmaf(fd_ld1(tile + lane * 40 + c), hd.w[c], acc1);
+                const float v = hd.act == 2 ? fminf(fmaxf(acc1, 0.0f), 6.0f) : (hd.act == 1 ? fmaxf(acc1, 0.0f) : acc1);
+                if (!hd.up) hd.y[p] = v;
+                else {
+                    const int ox = (int)(p % hd.w_);
+                    const long t = p / hd.w_;
+                    const int oy = (int)(t % hd.h);
+                    const long n = t / hd.h;
+                    float *o = hd.y + ((n * 2 * hd.h + 2 * oy) * 2 * (long)hd.w_ + 2 * ox);
+                    o[0] = v; o[1] = v; o[2 * hd.w_] = v; o[2 * hd.w_ + 1] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = lane + 64 * i;                         // 128 chunks of 8 elements: row = id / 4, chunk = id % 4
@@ -125,4 +149,20 @@ fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *_
             }
         }
     }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256)
+fd_pw_gemm_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *__restrict__ bias, T *__restrict__ out,
+               int M, int N, int K, int K64, int m_tiles, int n_tiles)
+{
+    fd_pw_gemm_h16_body<T, ACT, 0>(A, Wt, bias, out, M, N, K, K64, m_tiles, n_tiles, fd_pw_head{});
+}
+// the same GEMM with the network head on its output tile (N <= 32): the pointwise output itself is not written
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256)
+fd_pw_gemm_head_h16(const T *__restrict__ A, const T *__restrict__ Wt, const float *__restrict__ bias,
+                    int M, int N, int K, int K64, int m_tiles, int n_tiles, const fd_pw_head hd)
+{
+    fd_pw_gemm_h16_body<T, ACT, 1>(A, Wt, bias, (T *)nullptr, M, N, K, K64, m_tiles, n_tiles, hd);
 }

@@ -221,3 +221,22 @@ def test_emulated_16bit_gemm16_and_fused_epilogues(name, plan, b, hw, flags, dty
         assert float((a - r).abs().max()) <= 2.5 * ulp * max(float(r.abs().max()), 1e-30), (i, info[i])
     assert harness.rel_err(y_new.numpy(), y_old.numpy()) < 4 * ulp
     new.close(); old.close()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,plan", [("tiny", TINY), ("ragged", RAGGED)])
+def test_emulated_16bit_head_on_the_last_gemm(name, plan, dtype):
+    """16-bit product plans evaluate the network head (decode_conv6: Cout -> 1 pointwise + ReLU, nearest x2) on the output tile of decode_conv5.1's
+    GEMM (fd_pw_gemm_head_h16: that layer's tensor is neither written nor re-read).  Same arithmetic as the separate head kernel on the stored
+    tensor (the tile is rounded to the storage type first), different summation order: the two plans agree to fp32 rounding."""
+    m = small_model(plan[0], plan[1], seed=33).eval()
+    x = torch.rand(3, 3, 64, 96, generator=torch.Generator().manual_seed(12))
+    cap = harness.capi
+    fused = harness.CPlan("emu", m, x, keep=False, dtype=dtype)
+    plain = harness.CPlan("emu", m, x, keep=False, dtype=dtype, flags=cap.FD_PLAN_NO_EPILOGUE_FUSION)
+    info = fused.info()
+    assert any("head on its output tile" in s for s in info) and any("pointwise head evaluated" in s for s in info), info
+    assert not any("head on its output tile" in s for s in plain.info())
+    ya, yb = fused.forward(x), plain.forward(x)
+    assert ya.shape == (3, 1, 64, 96) and harness.rel_err(ya.numpy(), yb.numpy()) < 2e-6
+    fused.close(); plain.close()
