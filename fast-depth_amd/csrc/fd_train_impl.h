@@ -356,8 +356,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
                 // up to 8 rows) -- sized for the larger count
                 const long bwd_tiles = (long)ceil_div(L.in_w, 16) * ceil_div(L.in_h, 6) * batch;
-                // (the register-window weight-gradient kernel of the 3x3 units: one row per 256 (column, channel group) pairs x strip of >= 4 rows)
-                const long rows_tiles = d.ksize == 3 ? (long)ceil_div((long)L.out_w * (d.cin / 4), 256) * ceil_div(L.out_h, 4) * batch : 0;
+                // (the register-window weight-gradient kernels: one row per 256 (column, channel group) pairs x strip of >= 4 rows)
+                const long rows_tiles = (long)ceil_div((long)L.out_w * (d.cin / 4), 256) * ceil_div(L.out_h, 4) * batch;
                 L.wp_elems = (size_t)std::max<long>(std::max<long>(fwd_tiles, bwd_tiles), rows_tiles) * d.ksize * d.ksize * d.cin;
             }
             break;
