@@ -199,11 +199,13 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
     const int cg = c0 + c4 * 4;                            // first global channel of this lane
     const bool c_ok = cg < C;
 
-    for (int i = tid; i < K * K * lanes_c; i += 256) {
-        const int t = i >> cbq, cc = i & (lanes_c - 1);
-        fd_st4(s_w + t * CB + cc * 4, (c0 + cc * 4 < C) ? fd_ld4(wp + (long)t * C + c0 + cc * 4) : fd_zero4());
-    }
-    if (tid < lanes_c) fd_st4(s_b + tid * 4, (c0 + tid * 4 < C) ? fd_ld4(bias + c0 + tid * 4) : fd_zero4());
+    // taps and bias of this channel block: requested now, written to LDS after the patch loads have been issued -- one round trip at the head of
+    // the workgroup instead of two (K*K*lanes_c <= 200 vectors: one per work-item)
+    const bool w_item = tid < K * K * lanes_c;
+    const int w_t = tid >> cbq, w_cc = tid & (lanes_c - 1);
+    fd_f32x4 w_reg = fd_zero4(), b_reg = fd_zero4();
+    if (w_item && c0 + w_cc * 4 < C) w_reg = fd_ld4(wp + (long)w_t * C + c0 + w_cc * 4);
+    if (tid < lanes_c && c0 + tid * 4 < C) b_reg = fd_ld4(bias + c0 + tid * 4);
 
     // Staging with memory-level parallelism: U patch pixels per work-item are requested back to back (2*U
     // independent 16-byte loads in flight in MODE 2) before any of them is consumed; a load -> add -> ds_write
@@ -247,6 +249,8 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
             if (px < npx_in) fd_st4(s_in + px * PSTR + c4 * 4, ok[u] ? (MODE == 2 ? v[u] + sk[u] : v[u]) : fd_zero4());
         }
     }
+    if (w_item) fd_st4(s_w + w_t * CB + w_cc * 4, w_reg);
+    if (tid < lanes_c) fd_st4(s_b + tid * 4, b_reg);
     __syncthreads();
 
     const int TWS = TW >> 2, nstrips = TH * TWS;
