@@ -18,32 +18,7 @@
 #include "fd_kernels_h16.h"
 #include "fd_kernels_bwd.h"
 
-__device__ __forceinline__ void fd_unpack8(fd_bf16, fd_u16x8 r, float (&f)[8])
-{
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = fd_bf16_to_f32(r[j]);
-}
-__device__ __forceinline__ void fd_unpack8(fd_half, fd_u16x8 r, float (&f)[8])
-{
-    const fd_f16x8 h = __builtin_bit_cast(fd_f16x8, r);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (float)h[j];
-}
-__device__ __forceinline__ fd_u16x8 fd_pack8(fd_bf16, const float (&f)[8])
-{
-    typedef unsigned fd_u32x4 __attribute__((ext_vector_type(4)));
-    const fd_u32x4 r = {fd_f32x2_to_bf16x2(f[0], f[1]), fd_f32x2_to_bf16x2(f[2], f[3]), fd_f32x2_to_bf16x2(f[4], f[5]), fd_f32x2_to_bf16x2(f[6], f[7])};
-    return __builtin_bit_cast(fd_u16x8, r);
-}
-__device__ __forceinline__ fd_u16x8 fd_pack8(fd_half, const float (&f)[8])
-{
-    fd_f16x8 h;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (_Float16)f[j];
-    return __builtin_bit_cast(fd_u16x8, h);
-}
-__device__ __forceinline__ fd_u16x8 fd_ld8(const void *p) { return *reinterpret_cast<const fd_u16x8 *>(p); }
-__device__ __forceinline__ void fd_st8(void *p, fd_u16x8 v) { *reinterpret_cast<fd_u16x8 *>(p) = v; }
+// (fd_unpack8 / fd_pack8 / fd_ld8 / fd_st8: fd_kernels_h16.h)
 
 // ------------------------------------------------------------------------------------------------
 // Master weights W[N][K] (fp32, torch layout) -> wt[N][K64] and wtt[K][N64] in T, zero padded along the reduction index of

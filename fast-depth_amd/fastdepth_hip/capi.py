@@ -23,6 +23,7 @@ FD_PLAN_KEEP_ACTIVATIONS = 1
 FD_PLAN_WGRAD_TILE_ROWS = 8
 FD_PLAN_FORCE_GEMM16 = 16
 FD_PLAN_NO_GEMM16 = 64
+FD_PLAN_NO_ROWS8 = 128
 FD_PLAN_NO_EPILOGUE_FUSION = 512
 FD_PLAN_NO_UNIT_FUSION = 1024
 FD_PLAN_FORCE_UNIT_FUSION = 2048

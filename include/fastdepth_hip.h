@@ -72,6 +72,7 @@ enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 #define FD_PLAN_TUNE_DW_FORCE_ROWS 1073741824u /* tests: the register-window kernel on every eligible 3x3 unit whatever the map size */
 #define FD_PLAN_TUNE_DW_TH8 524288u        /* tuning aid (train plans): depthwise tiles of 8 rows with a ragged last tile (round 1/2) instead of balanced row counts */
 #define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
+#define FD_PLAN_NO_ROWS8 128u        /* 16-bit plans: the 3x3 depthwise layers run on the 4-channel register-window kernel instead of the 8-channel one (A/B measurements, tests) */
 #define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
 /* (bits 4, 32 and 128 selected round-1 / round-2 experiments -- a separable-unit kernel, a stream-K GEMM, side-stream weight gradients -- that were
  * measured no faster and have been removed; DESIGN.md section 10 keeps the measurements.) */
