@@ -174,6 +174,25 @@ __device__ __forceinline__ void fd_st4(fd_bf16 *p, fd_f32x4 v)
 }
 // raw (unconverted) 4-channel loads: lets a kernel keep prefetched 16-bit data in half the registers until it is used
 __device__ __forceinline__ fd_f32x4 fd_ldraw4(const float *p) { return *reinterpret_cast<const fd_f32x4 *>(p); }
+// LDS transpose read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive 16-bit words; within each 16-lane group those 16 x 4 words
+// are a 4 x 16 row-major matrix (lanes 4r .. 4r+3 = row r) and lane j receives its column j -- four values of the SLOW index for one fast index,
+// i.e. an MFMA operand piece read straight from an image that was stored the way it came from memory.
+#ifdef FD_EMU
+inline fd_u16x4 fd_lds_read_tr16(const void *p)
+{
+    unsigned short o[4];
+    hipemu_lds_read_tr16_b64(p, o);
+    fd_u16x4 r = {o[0], o[1], o[2], o[3]};
+    return r;
+}
+#else
+__device__ __forceinline__ fd_u16x4 fd_lds_read_tr16(const void *p)
+{
+    typedef short fd_s16x4_hw __attribute__((ext_vector_type(4)));
+    const fd_s16x4_hw v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fd_s16x4_hw *)(p));
+    return __builtin_bit_cast(fd_u16x4, v);
+}
+#endif
 __device__ __forceinline__ fd_u16x4 fd_ldraw4(const fd_half *p) { return *reinterpret_cast<const fd_u16x4 *>(p); }
 __device__ __forceinline__ fd_u16x4 fd_ldraw4(const fd_bf16 *p) { return *reinterpret_cast<const fd_u16x4 *>(p); }
 __device__ __forceinline__ fd_f32x4 fd_cvt4(float, fd_f32x4 r) { return r; }

@@ -384,9 +384,11 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
 
 // ------------------------------------------------------------------------------------------------
 // Backward-weights:  wpart[split][n][k] = sum over the split's pixels m of dz[m][n] * a_in[m][k],  a_in = act_in(z_in*s+t).
-// Workgroup = 64 (n) x 64 (k) output tile, 64 pixels per step.  LDS image: dzT[64 n][64 m], aT[64 k][64 m] in T, rows of
-// 192 bytes, the 16-byte chunk (8 consecutive m) of row r stored at chunk position c ^ ((r >> 3) & 7): the 2-byte transposing
-// writes of a wave then spread over the banks, and a fragment is one ds_read_b128.
+// Workgroup = 64 (n) x 64 (k) output tile, 64 pixels per step.  The reduction index m is the ROW index of both operands in memory, the MFMA wants
+// it as the fast index of a fragment.  LDS images are stored the way the rows arrive -- dz[64 m][64 n], a[64 m][64 k] in T, 16-byte writes, rows of
+// 192 bytes -- and the fragments come out of gfx950's LDS transpose read (ds_read_b64_tr_b16, fd_lds_read_tr16: 4 pixels of one column per read,
+// two reads per fragment; with the 192-byte pitch the eight 32-byte row pieces of a 32-lane half fall on distinct banks).  Rounds 1-2 transposed on
+// the way INTO LDS with 2-byte writes: 32 ds_write_b16 per work-item and step against 8 MFMAs per wave -- that write phase was the kernel's bound.
 // ------------------------------------------------------------------------------------------------
 #define FD_PW_WGRAD_H16_LDS(TN_) ((size_t)64 * (1 + (TN_)) * 192)
 template <typename T, int ACT_IN, int TN>   // TN: 64-column k tiles per workgroup (output tile 64 n x 64*TN k): the staged dz tile feeds TN times the MFMAs
@@ -396,8 +398,8 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
 {
     constexpr int BT = 64, BR = 64, PITCH = 192;   // 192-byte rows: the transposing 2-byte writes AND the fragment ds_read_b128s are bank-conflict free (144: 2-way read conflicts, PMC)
     FD_DYN_SMEM(smem_w);
-    unsigned char *s_dz = smem_w;                          // [BT][PITCH]
-    unsigned char *s_a = smem_w + BT * PITCH;              // [BT * TN][PITCH]
+    unsigned char *s_dz = smem_w;                          // [BR pixels][PITCH]: 64 n columns
+    unsigned char *s_a = smem_w + BR * PITCH;              // [TN][BR pixels][PITCH]: 64 k columns each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int nt = bx / k_tiles, kt = bx - nt * k_tiles;
@@ -406,9 +408,7 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
     long mend = mbeg + rows_per_split; if (mend > M) mend = M;
     const int Tn = (int)((mend - mbeg + BR - 1) / BR);
     // loader mapping: chunk cc = tid & 7 (8 columns), rows lr and lr + 32 of the 64-pixel step
-    // (the pixel order within a wave's 8 pixels is 0,2,4,6,1,3,5,7: lanes l and l+32 then hold the two 16-bit halves of one LDS dword --
-    // ds_write_b16 is served in the two 32-lane halves, and two lanes of one half on the same dword are a 2-way conflict)
-    const int cc = tid & 7, lr = (tid >> 3 & ~7) + 2 * (tid >> 3 & 3) + (tid >> 5 & 1);
+    const int cc = tid & 7, lr = tid >> 3;
     const int ncol = n0 + cc * 8;
     const bool n_ok = ncol < N;                                   // N, K % 8 == 0
     int kcol[TN];
@@ -440,20 +440,16 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
     auto stage = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int ml = lr + 32 * i;                           // pixel within the step
+            const int ml = lr + 32 * i;                           // pixel (row of the LDS images) within the step
             const long m = mbeg + (long)t * BR + ml;
-            const int pos = (((ml >> 3) ^ cc) << 4) + (ml & 7) * 2;   // rows cc*8 .. cc*8+7 all have (r >> 3) & 7 == cc
-#pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned short *>(s_dz + (cc * 8 + j) * PITCH + pos) = rdz[i][j];
+            fd_st8(s_dz + ml * PITCH + cc * 16, rdz[i]);
 #pragma unroll
             for (int q = 0; q < TN; ++q) {
                 float a[8];
                 fd_unpack8(T{}, rzi[i][q], a);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[j] = (m < mend && k_ok[q]) ? fd_act<ACT_IN>(fmaf(a[j], sc[q][j], sh[q][j])) : 0.0f;
-                const fd_u16x8 pa = fd_pack8(T{}, a);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned short *>(s_a + (q * BT + cc * 8 + j) * PITCH + pos) = pa[j];
+                fd_st8(s_a + (q * BR + ml) * PITCH + cc * 16, fd_pack8(T{}, a));
             }
         }
     };
@@ -462,8 +458,12 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
     for (int q = 0; q < TN; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    // fragment = 8 consecutive pixels (reduction index) of one column: two LDS transpose reads (fd_lds_read_tr16) of 4 pixels each.  A lane of a
+    // 16-lane group points at row (lane & 15) >> 2 of the 4-pixel block, 8-byte chunk (lane & 3) of the group's 16 columns, and receives column lane & 15
     const int hh = lane >> 5;
-    const int ra = wn * 32 + (lane & 31), rb = wk * 32 + (lane & 31);   // (rb: row within one 64-row k tile of s_a)
+    const int tr_row = (lane & 15) >> 2;
+    const int tr_col_a = (wn * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;      // byte offset within a row of s_dz
+    const int tr_col_b = (wk * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;      // ... of a 64-column k tile of s_a
     // (a second register set -- the loads of step t + 2 in flight during step t -- measured slower: 21.9 vs 21.5 us on the 512 x 512 units, 513 vs
     // 500 us for the paired family: the step is bound by the transposing staging writes and the two barriers, not by the loads)
     if (Tn > 0) load(0);
@@ -474,10 +474,13 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
         if (t + 1 < Tn) load(t + 1);                              // in flight during the MFMAs
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const fd_u16x8 a = fd_ld8(s_dz + ra * PITCH + (((2 * s + hh) ^ ((ra >> 3) & 7)) << 4));
+            const int m0 = 16 * s + 8 * hh + tr_row;                // first pixel row this lane points at
+            const fd_u16x4 a0 = fd_lds_read_tr16(s_dz + m0 * PITCH + tr_col_a), a1 = fd_lds_read_tr16(s_dz + (m0 + 4) * PITCH + tr_col_a);
+            const fd_u16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
             for (int q = 0; q < TN; ++q) {
-                const fd_u16x8 b = fd_ld8(s_a + (q * BT + rb) * PITCH + (((2 * s + hh) ^ ((rb >> 3) & 7)) << 4));
+                const fd_u16x4 b0 = fd_lds_read_tr16(s_a + (q * BR + m0) * PITCH + tr_col_b), b1 = fd_lds_read_tr16(s_a + (q * BR + m0 + 4) * PITCH + tr_col_b);
+                const fd_u16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 acc[q] = fd_mfma_32x32x16(T{}, a, b, acc[q]);
             }
         }

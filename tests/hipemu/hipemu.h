@@ -190,6 +190,23 @@ inline float __shfl_xor(float v, int mask)
     return r;
 }
 
+// ds_read_b64_tr_b16 (gfx950): within each 16-lane group the lanes' 4 x 16-bit words form a 4 x 16 matrix (lanes 4r .. 4r+3 hold row r, each 4
+// consecutive elements at ITS OWN address); lane j of the group receives column j (probed on an MI355X: tools/microbench/tr_read_probe.hip)
+inline void hipemu_lds_read_tr16_b64(const void *p, unsigned short (&out)[4])
+{
+    hipemu::WaveXchg &x = hipemu::wave_xchg();
+    const int l = hipemu::lane_id();
+    memcpy(&x.f[l][0], &p, sizeof p);
+    hipemu::yield(hipemu::COLLECTIVE);
+    const int g = l & ~15, j = l & 15;
+    for (int k = 0; k < 4; ++k) {
+        const void *q;
+        memcpy(&q, &x.f[g + 4 * k + (j >> 2)][0], sizeof q);
+        out[k] = reinterpret_cast<const unsigned short *>(q)[j & 3];
+    }
+    hipemu::yield(hipemu::COLLECTIVE);
+}
+
 inline float __shfl(float v, int src_lane)
 {
     hipemu::WaveXchg &x = hipemu::wave_xchg();
