@@ -390,7 +390,10 @@ fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__
 // two reads per fragment; with the 192-byte pitch the eight 32-byte row pieces of a 32-lane half fall on distinct banks).  Rounds 1-2 transposed on
 // the way INTO LDS with 2-byte writes: 32 ds_write_b16 per work-item and step against 8 MFMAs per wave -- that write phase was the kernel's bound.
 // ------------------------------------------------------------------------------------------------
-#define FD_PW_WGRAD_H16_LDS(TN_) ((size_t)64 * (1 + (TN_)) * 192)
+#ifndef FD_PW_WGRAD_H16_BUFS
+#define FD_PW_WGRAD_H16_BUFS 1          // LDS image sets of the weight-gradient GEMM: 2 = the next step is staged while this step's MFMAs run (one barrier per step); measured: 512 x 512 units 26.1 vs 26.4 us, short-N units slower (49 KB per workgroup in the paired launch), family 477 vs 466 us
+#endif
+#define FD_PW_WGRAD_H16_LDS(TN_) ((size_t)FD_PW_WGRAD_H16_BUFS * 64 * (1 + (TN_)) * 192)
 template <typename T, int ACT_IN, int TN>   // TN: 64-column k tiles per workgroup (output tile 64 n x 64*TN k): the staged dz tile feeds TN times the MFMAs
 __device__ __forceinline__ void             // (bx, by) = (output tile, pixel split): blockIdx of the plain kernel; dynamic LDS: FD_PW_WGRAD_H16_LDS(TN) bytes
 fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const float *__restrict__ st_in, float *__restrict__ wpart,
@@ -398,8 +401,7 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
 {
     constexpr int BT = 64, BR = 64, PITCH = 192;   // 192-byte rows: the transposing 2-byte writes AND the fragment ds_read_b128s are bank-conflict free (144: 2-way read conflicts, PMC)
     FD_DYN_SMEM(smem_w);
-    unsigned char *s_dz = smem_w;                          // [BR pixels][PITCH]: 64 n columns
-    unsigned char *s_a = smem_w + BR * PITCH;              // [TN][BR pixels][PITCH]: 64 k columns each
+    // LDS image set: dz [BR pixels][PITCH] (64 n columns), then TN input tiles [BR pixels][PITCH] (64 k columns each)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int nt = bx / k_tiles, kt = bx - nt * k_tiles;
@@ -437,7 +439,9 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
             }
         }
     };
+    constexpr int SET = BR * (1 + TN) * PITCH;                  // bytes of one image set (dz + TN input tiles)
     auto stage = [&](int t) {
+        unsigned char *s_dz = smem_w + (FD_PW_WGRAD_H16_BUFS > 1 ? (t & 1) * SET : 0), *s_a = s_dz + BR * PITCH;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int ml = lr + 32 * i;                           // pixel (row of the LDS images) within the step
@@ -467,11 +471,15 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
     // (a second register set -- the loads of step t + 2 in flight during step t -- measured slower: 21.9 vs 21.5 us on the 512 x 512 units, 513 vs
     // 500 us for the paired family: the step is bound by the transposing staging writes and the two barriers, not by the loads)
     if (Tn > 0) load(0);
+    if (FD_PW_WGRAD_H16_BUFS > 1 && Tn > 0) { stage(0); __syncthreads(); }
     for (int t = 0; t < Tn; ++t) {
-        __syncthreads();                                          // the previous step's fragment reads are done
-        stage(t);
-        __syncthreads();
+        if (FD_PW_WGRAD_H16_BUFS == 1) {
+            __syncthreads();                                      // the previous step's fragment reads are done
+            stage(t);
+            __syncthreads();
+        }
         if (t + 1 < Tn) load(t + 1);                              // in flight during the MFMAs
+        const unsigned char *s_dz = smem_w + (FD_PW_WGRAD_H16_BUFS > 1 ? (t & 1) * SET : 0), *s_a = s_dz + BR * PITCH;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int m0 = 16 * s + 8 * hh + tr_row;                // first pixel row this lane points at
@@ -483,6 +491,10 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
                 const fd_u16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 acc[q] = fd_mfma_32x32x16(T{}, a, b, acc[q]);
             }
+        }
+        if (FD_PW_WGRAD_H16_BUFS > 1) {                          // the other image set is free (its readers passed the previous barrier): stage the next step
+            if (t + 1 < Tn) stage(t + 1);
+            __syncthreads();
         }
     }
     float *o = wpart + (long)by * N * K;
