@@ -431,3 +431,26 @@ def test_16bit_gemm16_fused_epilogues_vs_first_generation_kernels(pruned, b, fla
         assert float((a - r).abs().max()) <= 2.5 * ulp * max(float(r.abs().max()), 1e-30), (i, info[i])
     assert harness.rel_err(y_new.cpu().numpy(), y_old.cpu().numpy()) < 4 * ulp
     new.close(); old.close()
+
+
+@pytest.mark.parametrize("pruned", [False, True])
+def test_16bit_head_fusion_and_rows8_match_the_separate_kernels(pruned):
+    """Round-3 kernels of the 16-bit plans at full size: the network head on decode_conv5.1's GEMM tile (fd_pw_gemm_head_h16) equals the separate
+    head kernel to fp32 rounding (same T-rounded operands, different summation order), and the 8-channel 3x3 depthwise kernel (fd_dw3_rows8) is
+    bit-identical to the 4-channel one (same arithmetic per channel)."""
+    import sys
+    sys.path.insert(0, inputs.PKG)
+    from fastdepth_hip import capi
+    from fastdepth_hip.engine import Engine
+    models = inputs.product_models()
+    torch.manual_seed(90)
+    m = harness.randomize_bn(models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None), 91).eval().cuda()
+    x = torch.rand(5, 3, 224, 224, generator=torch.Generator().manual_seed(92)).cuda()
+    for dt in (torch.float16, torch.bfloat16):
+        with torch.no_grad():
+            y = Engine(m, dtype=dt).forward(x)
+            y_sep_head = Engine(m, dtype=dt, plan_flags=capi.FD_PLAN_NO_EPILOGUE_FUSION).forward(x)
+            y_rows4 = Engine(m, dtype=dt, plan_flags=capi.FD_PLAN_NO_ROWS8).forward(x)
+        assert torch.equal(y, y_rows4), dt
+        assert harness.rel_err(y.cpu().numpy(), y_sep_head.cpu().numpy()) < (5e-3 if dt == torch.float16 else 4e-2), dt   # (NO_EPILOGUE_FUSION also un-fuses the 14x14 pairs: storage-type rounding)
+        assert bool(torch.isfinite(y).all())
