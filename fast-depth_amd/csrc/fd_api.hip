@@ -11,6 +11,7 @@
 #include "fd_kernels_gemm16_h16.h"
 #include "fd_kernels_dwpw_f32.h"
 #include "../../include/fastdepth_hip.h"
+#include "fd_tuning.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -28,6 +29,10 @@
 namespace {
 
 thread_local std::string g_err;
+
+// private tuning mask handed over by fd_tuning_next (fd_tuning.h): consumed by the next plan creation of this thread
+thread_local uint32_t g_tune_next = 0;
+inline uint32_t fd_take_tuning() { const uint32_t t = g_tune_next; g_tune_next = 0; return t; }
 
 // fd_forward_timed sets these so that the next launch records the kernel's own begin/end timestamps
 // (hipExtLaunchKernelGGL start/stop events == what rocprofv3's kernel trace reports), without the
@@ -121,7 +126,8 @@ struct Layer {
     bool head = false;           // Cout == 1 pointwise: fd_head_pw1
     bool pw_packed_t = false;    // packed weights are 16-bit (pointwise layers of a 16-bit plan)
     // dw tiling
-    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0, pstr = 0;   // pstr: LDS patch row pitch in floats (pick_patch_pitch)
+    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0, pstr = 0;   // pstr: LDS patch row pitch in LDS elements (pick_patch_pitch)
+    int dw_n = 4;                // channels per work-item of the LDS-tiled depthwise kernel (8: 16-bit plans, storage-typed patches)
     int csplit = 0;              // concatenating consumer: channels [0, csplit) come from src, the rest from skip
     bool skipped = false;        // depthwise layer executed inside the following pointwise layer's fused kernel
     int fuse_next_dw = -1;       // pointwise layer (fd_pw_gemm16_f32): index of the depthwise consumer evaluated in its epilogue
@@ -149,7 +155,7 @@ struct Layer {
 struct fd_plan {
     std::vector<Layer> layers;
     int B = 0, H = 0, W = 0, dtype = 0;
-    uint32_t flags = 0;
+    uint32_t flags = 0, tune = 0;    // public plan flags (include/fastdepth_hip.h) / private tuning mask (fd_tuning.h)
     size_t ws_bytes = 0, weights_bytes = 0;
     unsigned char *ws = nullptr;
     bool packed = false;
@@ -271,7 +277,14 @@ int launch_stem(const Layer &L, const float *x, const float *wp, const float *bi
 template <typename T, int K, int S, int MODE, int ACT>
 int launch_dw_inst(const Layer &L, const T *in, const T *skip, const float *wp, const float *bias, T *out, hipStream_t s)
 {
-    FD_LAUNCH((fd_dwconv<T, K, S, MODE, ACT>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
+    if constexpr (!std::is_same<T, float>::value) {
+        if (L.dw_n == 8) {                                   // storage-typed LDS patches, 8 channels (16 bytes) per work-item
+            FD_LAUNCH((fd_dwconv<T, K, S, MODE, ACT, 8>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
+                      L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr);
+            return check_launch("fd_dwconv");
+        }
+    }
+    FD_LAUNCH((fd_dwconv<T, K, S, MODE, ACT, 4>), L.grid, dim3(256), L.lds, s, in, skip, wp, bias, out,
                        L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr);
     return check_launch("fd_dwconv");
 }
@@ -420,7 +433,7 @@ int launch_pw_t(const fd_plan *plan, const Layer &L, const T *A, const void *wp,
         }
 #define FD_PW16H_LAUNCH(TMV, FD_) \
         do { (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_h16<T, TMV, 4, ACT, FD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-             FD_LAUNCH((fd_pw_gemm16_h16<T, TMV, 4, ACT, FD_>), L.grid, dim3(512), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz, (int)((plan->flags >> 20) & 7)); } while (0)
+             FD_LAUNCH((fd_pw_gemm16_h16<T, TMV, 4, ACT, FD_>), L.grid, dim3(512), L.lds, s, A, static_cast<const T *>(wp), bias, out, (int)M, L.d.cout, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz, 0 /* ablation bits: tools/microbench only */); } while (0)
 #define FD_PW16H_CASE(TMV) \
     case TMV: if (fdw == 3) FD_PW16H_LAUNCH(TMV, 3); else if (fdw == 5) FD_PW16H_LAUNCH(TMV, 5); else FD_PW16H_LAUNCH(TMV, 0); break;
         switch (L.pw16_tm) {
@@ -498,6 +511,8 @@ int run_layer(fd_plan *plan, const Layer &L, const float *x, float *out, hipStre
 // ==================================================================================================
 extern "C" {
 
+void fd_tuning_next(uint32_t mask) { g_tune_next = mask; }
+
 const char *fd_last_error(void) { return g_err.c_str(); }
 const char *fd_version(void) { return "fastdepth_hip 0.3 (gfx950; inference f32/f16/bf16, train step f32/bf16)"; }
 
@@ -507,9 +522,12 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
+    const uint32_t tune = fd_take_tuning();                  // (consumed even when the creation fails)
     if (dtype != FD_F32 && dtype != FD_F16 && dtype != FD_BF16) return fail(FD_ERR_INVALID, "unknown dtype %d", dtype);
+    if (flags & ~FD_PLAN_ALL_FLAGS) return fail(FD_ERR_INVALID, "unknown plan flag bits 0x%x", flags & ~FD_PLAN_ALL_FLAGS);
+    if (tune & ~FD_TUNE_ALL) return fail(FD_ERR_INVALID, "unknown tuning bits 0x%x", tune & ~FD_TUNE_ALL);
     fd_plan *p = new fd_plan();
-    p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
+    p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags; p->tune = tune;
     p->layers.resize(n_layers);
     const size_t esz = dtype == FD_F32 ? 4 : 2;   // activation / pointwise-weight element size
     size_t woff = 0;
@@ -571,15 +589,21 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.w_bytes = (size_t)9 * d.cin * 4; L.w_elems = (size_t)9 * d.cin;
                 break;
             }
-            const int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
-            L.cbq = ilog2(cb / 4);
+            // 16-bit plans: 8 channels (16 bytes) per work-item and patches kept in the storage type -- a 64-channel block has the LDS footprint
+            // (and the instruction count) of the 32-channel fp32 block; FD_TUNE_NO_DW_H8 keeps the 4-channel / fp32-patch form for A/B runs
+            const bool h8 = dtype != FD_F32 && d.cin % 8 == 0 && (!concat || L.csplit % 8 == 0) && !(tune & FD_TUNE_NO_DW_H8);
+            L.dw_n = h8 ? 8 : 4;
+            int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
+            if (h8 && d.cin >= 64 && ceil_div(d.cin, 64) * 64 <= ceil_div(d.cin, 32) * 32) cb = 64;   // (pruned widths: the block size that pads the channel count least)
+            L.cbq = ilog2(cb / L.dw_n);
             const int tmax_w = d.stride == 2 ? 8 : 16, tmax_h = d.ksize == 5 ? 7 : 8;   // 8x16 (5x5: 7x16, conflict-free pitch 40) outputs x 32 channels: < 40 KB LDS -> 4 workgroups per CU
             L.tw = std::min((L.out_w + 3) / 4 * 4, tmax_w);
             L.th = std::min(L.out_h, tmax_h);
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
-            L.pstr = pick_patch_pitch(cb, L.tw, tw_in, d.stride);
-            L.lds = ((size_t)th_in * tw_in * L.pstr + (size_t)d.ksize * d.ksize * cb + cb) * 4;
+            // (h8: a lane's 8 channels are 4 dwords, so the bank replay is that of cb / 2 fp32 channels; the pitch comes back in dwords)
+            L.pstr = h8 ? 2 * pick_patch_pitch(cb / 2, L.tw, tw_in, d.stride) : pick_patch_pitch(cb, L.tw, tw_in, d.stride);
+            L.lds = align_up((size_t)th_in * tw_in * L.pstr * (h8 ? 2 : 4), 16) + ((size_t)d.ksize * d.ksize * cb + cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.w_bytes = (size_t)d.ksize * d.ksize * d.cin * 4; L.w_elems = (size_t)d.ksize * d.ksize * d.cin;
             break;
@@ -608,10 +632,10 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
                 L.m_tiles = ceil_div(M, L.pw.wgm * L.pw.tm * 32);
                 L.n_tiles = ceil_div(d.cout, L.pw.wgn * L.pw.tn * 32);
                 L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));   // 1-D, XCD-aware mapping inside the kernel
-                if ((dtype == FD_F32 || (flags & FD_PLAN_FORCE_GEMM16)) && !(flags & FD_PLAN_NO_GEMM16)) {
+                if ((dtype == FD_F32 || (tune & FD_TUNE_FORCE_GEMM16)) && !(flags & FD_PLAN_NO_GEMM16)) {
                     // (16-bit plans take fd_pw_gemm16_h16 where a depthwise consumer fuses behind it -- decided in the fusion pass below --
-                    // or, with FD_PLAN_FORCE_GEMM16, everywhere: tests)
-                    const Pw16Cfg c16 = choose_pw16(M, d.cout, d.cin, (flags & FD_PLAN_FORCE_GEMM16) != 0);
+                    // or, with FD_TUNE_FORCE_GEMM16, everywhere: tests)
+                    const Pw16Cfg c16 = choose_pw16(M, d.cout, d.cin, (tune & FD_TUNE_FORCE_GEMM16) != 0);
                     if (c16.tm) {
                         L.pw16_tm = c16.tm; L.pw16_stride = c16.stride;
                         L.lds = (size_t)(dtype == FD_F32 ? 3 : 4) * (c16.tm * 16 + 64) * 32 * 4;   // (128-byte rows in both kernels; the 16-bit one runs a 4-stage ring)
@@ -656,9 +680,9 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             size_t lds = Pw.lds;
             // (measured at batch 32 / 64, fp16: the fused launch takes 11-12.6 us where the pointwise GEMM + the depthwise launch took 18 on the 14x14
             // maps; on the 7x7 maps (6.6 + 5.4 us unfused) and where the grid needs a second round of workgroups (pruned plan at batch 64) it is
-            // no faster, so those keep the first-generation kernels unless FD_PLAN_FORCE_EPILOGUE_FUSION asks for every eligible pair: tests)
-            const bool want_all = (flags & FD_PLAN_FORCE_EPILOGUE_FUSION) != 0;
-            const bool h16_pick = dtype != FD_F32 && !(flags & (FD_PLAN_NO_GEMM16 | FD_PLAN_FORCE_GEMM16)) && hw <= 208 &&
+            // no faster, so those keep the first-generation kernels unless FD_TUNE_FORCE_EPILOGUE_FUSION asks for every eligible pair: tests)
+            const bool want_all = (tune & FD_TUNE_FORCE_EPILOGUE_FUSION) != 0;
+            const bool h16_pick = dtype != FD_F32 && !(flags & FD_PLAN_NO_GEMM16) && !(tune & FD_TUNE_FORCE_GEMM16) && hw <= 208 &&
                                   (want_all || (hw >= 128 && (long)batch * ceil_div(Pw.d.cout, 64) <= 272));
             if (h16_pick) {
                 // 16-bit plans: a pointwise layer of a small map (a frame is at most 13 row tiles) followed by a fusable depthwise layer moves to
@@ -690,7 +714,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
     // ---- fusion: depthwise -> pointwise units of the LARGE maps become one kernel (fd_dwpw_f32): the depthwise output (up to 103 MB at
     // batch 32) never makes its HBM round trip.  Applies where a workgroup can own a pixel tile with ALL output channels (N <= 128, or
     // <= 256 behind a stride-2 depthwise) -- on the small maps the GEMM is the cost and the opposite fusion (above) is used.
-    if (dtype == FD_F32 && !(flags & FD_PLAN_NO_UNIT_FUSION) && (!(flags & FD_PLAN_KEEP_ACTIVATIONS) || (flags & FD_PLAN_FORCE_UNIT_FUSION))) {
+    if (dtype == FD_F32 && !(flags & FD_PLAN_NO_UNIT_FUSION) && (!(flags & FD_PLAN_KEEP_ACTIVATIONS) || (tune & FD_TUNE_FORCE_UNIT_FUSION))) {
         std::vector<int> readers(n_layers, 0);
         for (int i = 0; i < n_layers; ++i) {
             if (p->layers[i].d.src >= 0) ++readers[p->layers[i].d.src];
@@ -715,7 +739,7 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             // pixels (conv1: 52.7 -> 39 us, conv2: 50.4 -> 42 us, decode_conv5: 87 -> 80 us).  The 128-channel units are bound by the fp32
             // MFMAs (conv3) or the 5x5 taps' LDS reads (decode_conv4) and lose 7 us each; small maps are launch-bound and use the
             // GEMM-epilogue fusion above.
-            if (!(flags & FD_PLAN_FORCE_UNIT_FUSION) && (C > 64 || D.out_h * D.out_w < 28 * 28)) continue;
+            if (!(tune & FD_TUNE_FORCE_UNIT_FUSION) && (C > 64 || D.out_h * D.out_w < 28 * 28)) continue;
             // the whole weight matrix, the taps and two A tiles stay in LDS next to the patch
             const size_t lds = ((size_t)nld * 32 * 36 + 2 * 32 * wm * 32 + (size_t)N * C + (size_t)KS * KS * C + C) * 4;
             if ((C / 32) & (C / 32 - 1) || lds > 160 * 1024) continue;
@@ -828,8 +852,8 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         else if (d.op == FD_OP_DW && L.dw_rows)
             snprintf(buf, sizeof buf, "dw3_rows%s<s%d> rows/item %d grid=%ux%ux%u", L.dw_rows8 ? "8" : "", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW)
-            snprintf(buf, sizeof buf, "dwconv<k%d s%d mode%d> tile %dx%dx%d pitch %d grid=%ux%ux%u lds=%zu", d.ksize, d.stride, L.mode,
-                     L.th, L.tw, 4 << L.cbq, L.pstr, L.grid.x, L.grid.y, L.grid.z, L.lds);
+            snprintf(buf, sizeof buf, "dwconv<k%d s%d mode%d> tile %dx%dx%d pitch %d grid=%ux%ux%u lds=%zu, %d channels per work-item", d.ksize, d.stride, L.mode,
+                     L.th, L.tw, L.dw_n << L.cbq, L.pstr, L.grid.x, L.grid.y, L.grid.z, L.lds, L.dw_n);
         else if (L.head)
             snprintf(buf, sizeof buf, "head_pw1 up=%d grid=%u", d.upsample, L.grid.x);
         else
@@ -844,12 +868,12 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
         L.info = buf;
         const char *tn = dtype == FD_F32 ? "float" : (dtype == FD_F16 ? "_Float16" : "fd_bf16");
         if (L.skipped || L.fused_into >= 0) buf[0] = 0;
-        else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d, %d>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld, L.fuse_head >= 0 ? 1 : 0);
+        else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d, %d, 0>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld, L.fuse_head >= 0 ? 1 : 0);
         else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows%s<%s, %d, %d>", L.dw_rows8 ? "8" : "", tn, d.stride, d.act);
-        else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act);
+        else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act, L.dw_n);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
-        else if (L.pw16_tm && dtype != FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm16_h16<%s, %d, 4, %d, %d>", tn, L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
+        else if (L.pw16_tm && dtype != FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm16_h16<%s, %d, 4, %d, %d, 1>", tn, L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, 3, %d, 0, %d>", L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else if (L.fuse_head >= 0) snprintf(buf, sizeof buf, "fd_pw_gemm_head_h16<%s, %d>", tn, d.act);
@@ -925,13 +949,13 @@ int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)
  * reference's TVM artefacts deploy_graph.json + deploy_param.params (deploy/tx2_run_tvm.py:13-20). ---- */
 namespace {
 struct BundleHeader {
-    char magic[8];            // "FDPLAN1\0"
+    char magic[8];            // "FDPLAN2\0" (FDPLAN1: rounds 2-3, whose flag word used bit values that have since been retired)
     uint32_t header_bytes, n_layers;
     int32_t batch, height, width, dtype;
     uint32_t flags, desc_bytes;
     uint64_t weights_bytes;   // the packed-weight region of the workspace, bit for bit
 };
-const char kBundleMagic[8] = {'F', 'D', 'P', 'L', 'A', 'N', '1', 0};
+const char kBundleMagic[8] = {'F', 'D', 'P', 'L', 'A', 'N', '2', 0};
 }  // namespace
 
 size_t fd_plan_export_bytes(const fd_plan *plan)
@@ -982,6 +1006,7 @@ int fd_plan_import(const void *host_buffer, size_t bytes, int32_t batch_override
         memcpy(descs.data(), static_cast<const unsigned char *>(host_buffer) + sizeof h, (size_t)h.n_layers * sizeof(fd_layer_desc));
         // the packed weights do not depend on the batch size: a bundle exported at one batch serves any other
         // (descriptors and flags go through fd_plan_create's own validation, like a caller's)
+        // (unknown flag bits are refused there; the private tuning mask is not part of a bundle)
         rc = fd_plan_create(descs.data(), (int32_t)h.n_layers, batch_override > 0 ? batch_override : h.batch, h.height, h.width, h.dtype, h.flags, &p);
     } catch (const std::exception &e) {
         return fail(FD_ERR_INVALID, "deploy bundle rejected: %s", e.what());          // no C++ exception crosses the C ABI

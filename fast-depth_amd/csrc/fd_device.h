@@ -223,6 +223,108 @@ struct fd_px_walk {
 };
 __device__ __forceinline__ fd_f32x4 fd_zero4() { fd_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
+// ---- lane vectors of the LDS-tiled depthwise kernels --------------------------------------------------------------------------------
+// A work-item of those kernels owns N consecutive channels of a pixel.  fd_lane<T, 4>: the round-1 form -- 4 channels, LDS patches kept in
+// fp32 (16 bytes per lane in LDS; 16 bytes per lane in memory only when T is float).  fd_lane<T, 8> (T a 16-bit storage type): 8 channels
+// per work-item = 16 bytes per lane in memory AND in LDS, patches kept in the storage type: half the LDS footprint per channel (twice the
+// channels per workgroup at the same residency) and half the load / ds_write / ds_read instructions per byte; arithmetic stays fp32 (the
+// conversion happens on the LDS read).  A 16-bit plan staged fp32 patches of 4 channels per lane before: its workgroups had the LDS
+// footprint and instruction count of the fp32 plan and only their HBM bytes halved (8-byte loads: half the bytes in flight per load).
+typedef float fd_f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ fd_f32x8 fd_zero8() { fd_f32x8 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
+__device__ __forceinline__ fd_f32x8 fd_cvt8(fd_half, fd_u16x8 r)
+{
+    const fd_f16x8 h = __builtin_bit_cast(fd_f16x8, r);
+    fd_f32x8 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3], (float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+    return v;
+}
+__device__ __forceinline__ fd_f32x8 fd_cvt8(fd_bf16, fd_u16x8 r)
+{
+    // two channels per dword: the low one is a shift, the high one a mask (no unpacking of the 16-bit halves first)
+    typedef unsigned fd_u32x4_ __attribute__((ext_vector_type(4)));
+    const fd_u32x4_ d = __builtin_bit_cast(fd_u32x4_, r);
+    fd_f32x8 v = {__builtin_bit_cast(float, d[0] << 16), __builtin_bit_cast(float, d[0] & 0xffff0000u), __builtin_bit_cast(float, d[1] << 16), __builtin_bit_cast(float, d[1] & 0xffff0000u),
+                  __builtin_bit_cast(float, d[2] << 16), __builtin_bit_cast(float, d[2] & 0xffff0000u), __builtin_bit_cast(float, d[3] << 16), __builtin_bit_cast(float, d[3] & 0xffff0000u)};
+    return v;
+}
+__device__ __forceinline__ fd_u16x8 fd_pack8v(fd_half, fd_f32x8 v)
+{
+    fd_f16x8 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3], (_Float16)v[4], (_Float16)v[5], (_Float16)v[6], (_Float16)v[7]};
+    return __builtin_bit_cast(fd_u16x8, h);
+}
+__device__ __forceinline__ fd_u16x8 fd_pack8v(fd_bf16, fd_f32x8 v)
+{
+    typedef unsigned fd_u32x4_ __attribute__((ext_vector_type(4)));
+    const fd_u32x4_ r = {fd_f32x2_to_bf16x2(v[0], v[1]), fd_f32x2_to_bf16x2(v[2], v[3]), fd_f32x2_to_bf16x2(v[4], v[5]), fd_f32x2_to_bf16x2(v[6], v[7])};
+    return __builtin_bit_cast(fd_u16x8, r);
+}
+template <int ACT>
+__device__ __forceinline__ fd_f32x8 fd_act4(fd_f32x8 v)      // (same name as the 4-channel form: the kernels are generic in the lane width)
+{
+    fd_f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = fd_act<ACT>(v[j]);
+    return r;
+}
+// value a T-typed store will hold (the train kernels take their statistics over the STORED, i.e. rounded, tensor)
+__device__ __forceinline__ fd_f32x4 fd_round4(float, fd_f32x4 v) { return v; }
+__device__ __forceinline__ fd_f32x4 fd_round4(fd_bf16, fd_f32x4 v)
+{
+    fd_f32x4 r = {fd_bf16_to_f32(fd_f32_to_bf16(v.x)), fd_bf16_to_f32(fd_f32_to_bf16(v.y)), fd_bf16_to_f32(fd_f32_to_bf16(v.z)), fd_bf16_to_f32(fd_f32_to_bf16(v.w))};
+    return r;
+}
+__device__ __forceinline__ fd_f32x4 fd_round4(fd_half, fd_f32x4 v)
+{
+    fd_f32x4 r = {(float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w};
+    return r;
+}
+template <typename T, int N> struct fd_lane;
+template <typename T> struct fd_lane<T, 4> {
+    static constexpr int n = 4;
+    typedef fd_f32x4 vec;
+    typedef float lds_t;                                     // element type of the LDS patch images
+    typedef decltype(fd_ldraw4((const T *)nullptr)) raw;     // a lane's channels as loaded, before conversion
+    static __device__ __forceinline__ vec zero() { return fd_zero4(); }
+    static __device__ __forceinline__ vec ld(const T *p) { return fd_ld4(p); }
+    static __device__ __forceinline__ raw ldraw(const T *p) { return fd_ldraw4(p); }
+    static __device__ __forceinline__ vec cvt(raw r) { return fd_cvt4(T{}, r); }
+    static __device__ __forceinline__ void st(T *p, vec v) { fd_st4(p, v); }
+    static __device__ __forceinline__ vec ldf(const float *p) { return fd_ld4(p); }          // fp32 tables / taps (global or LDS)
+    static __device__ __forceinline__ void stf(float *p, vec v) { fd_st4(p, v); }
+    static __device__ __forceinline__ vec lds_ld(const lds_t *p) { return fd_ld4(p); }
+    static __device__ __forceinline__ void lds_st(lds_t *p, vec v) { fd_st4(p, v); }
+    static __device__ __forceinline__ void lds_st_raw(lds_t *p, raw r) { fd_st4(p, fd_cvt4(T{}, r)); }
+    static __device__ __forceinline__ vec round(vec v) { return fd_round4(T{}, v); }          // value a T store will hold
+    static __device__ __forceinline__ vec lds_round(vec v) { return v; }                      // value an LDS patch store will hold
+};
+template <typename T> struct fd_lane<T, 8> {
+    static constexpr int n = 8;
+    typedef fd_f32x8 vec;
+    typedef T lds_t;
+    typedef fd_u16x8 raw;
+    static __device__ __forceinline__ vec zero() { return fd_zero8(); }
+    static __device__ __forceinline__ raw ldraw(const T *p) { return *reinterpret_cast<const fd_u16x8 *>(p); }
+    static __device__ __forceinline__ vec cvt(raw r) { return fd_cvt8(T{}, r); }
+    static __device__ __forceinline__ vec ld(const T *p) { return cvt(ldraw(p)); }
+    static __device__ __forceinline__ void st(T *p, vec v) { *reinterpret_cast<fd_u16x8 *>(p) = fd_pack8v(T{}, v); }
+    static __device__ __forceinline__ vec ldf(const float *p)
+    {
+        const fd_f32x4 a = fd_ld4(p), b = fd_ld4(p + 4);
+        vec v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        return v;
+    }
+    static __device__ __forceinline__ void stf(float *p, vec v)
+    {
+        const fd_f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        fd_st4(p, a); fd_st4(p + 4, b);
+    }
+    static __device__ __forceinline__ vec lds_ld(const lds_t *p) { return cvt(*reinterpret_cast<const fd_u16x8 *>(p)); }
+    static __device__ __forceinline__ void lds_st(lds_t *p, vec v) { *reinterpret_cast<fd_u16x8 *>(p) = fd_pack8v(T{}, v); }
+    static __device__ __forceinline__ void lds_st_raw(lds_t *p, raw r) { *reinterpret_cast<fd_u16x8 *>(p) = r; }
+    static __device__ __forceinline__ vec round(vec v) { return cvt(fd_pack8v(T{}, v)); }
+    static __device__ __forceinline__ vec lds_round(vec v) { return cvt(fd_pack8v(T{}, v)); }
+};
+
 // ---- device-coherent accesses ("last arriver" reductions: stream-K partial tiles, fused two-level reductions of the train step) ----
 // Device-coherent accesses for partial results and their arrival counters.  MI355X has one L2 per XCD and the L2s are not coherent
 // with each other inside a kernel; an agent-scope FENCE would make them so by writing back / invalidating the whole L2

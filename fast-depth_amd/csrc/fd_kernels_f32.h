@@ -175,20 +175,25 @@ fd_stem3x3s2(const float *__restrict__ x, const float *__restrict__ wp, const fl
 // row it pulls 3*S+K input vectors from LDS once and reuses them across the K taps and 4 outputs.
 // The upsampled / summed tensor is never written to HBM.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int K, int S, int MODE, int ACT>
+// N = channels per work-item (fd_lane, fd_device.h): 4 = fp32 patches, 16 bytes per lane in LDS; 8 (16-bit T only) = patches kept in the storage
+// type, 16 bytes per lane in memory and in LDS.  PSTR is the patch pitch in LDS elements (floats for N = 4, 16-bit words for N = 8).
+template <typename T, int K, int S, int MODE, int ACT, int N>
 __global__ void __launch_bounds__(256)
 fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ wp,
           const float *__restrict__ bias, T *__restrict__ out, int Hin, int Win, int Ho, int Wo, int C,
           int cbq, int TH, int TW, int tiles_x, int csplit, int PSTR)
 {
+    typedef fd_lane<T, N> LN;
+    typedef typename LN::vec vec;
+    typedef typename LN::raw raw;
+    typedef typename LN::lds_t lds_t;
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;                       // input columns feeding 4 adjacent outputs
     FD_DYN_SMEM(smem_raw);
-    float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4;       // PSTR: bank-conflict-free row pitch of the patch image (host: pick_patch_pitch)
+    const int lanes_c = 1 << cbq, CB = lanes_c * N;       // PSTR: bank-conflict-free row pitch of the patch image (host: pick_patch_pitch)
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
-    float *s_in = smem;                                   // [TH_in*TW_in][PSTR]
-    float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]
+    lds_t *s_in = reinterpret_cast<lds_t *>(smem_raw);    // [TH_in*TW_in][PSTR]
+    float *s_w = reinterpret_cast<float *>(smem_raw + ((size_t)TH_in * TW_in * PSTR * sizeof(lds_t) + 15) / 16 * 16);   // [K*K][CB]
     float *s_b = s_w + K * K * CB;                        // [CB]
     const fd_blk3 blk = fd_xcd_image_map();                // all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2
     const int ty = blk.x / tiles_x, tx = blk.x - ty * tiles_x;
@@ -196,16 +201,16 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
-    const int cg = c0 + c4 * 4;                            // first global channel of this lane
+    const int cg = c0 + c4 * N;                            // first global channel of this lane
     const bool c_ok = cg < C;
 
     // taps and bias of this channel block: requested now, written to LDS after the patch loads have been issued -- one round trip at the head of
     // the workgroup instead of two (K*K*lanes_c <= 200 vectors: one per work-item)
     const bool w_item = tid < K * K * lanes_c;
     const int w_t = tid >> cbq, w_cc = tid & (lanes_c - 1);
-    fd_f32x4 w_reg = fd_zero4(), b_reg = fd_zero4();
-    if (w_item && c0 + w_cc * 4 < C) w_reg = fd_ld4(wp + (long)w_t * C + c0 + w_cc * 4);
-    if (tid < lanes_c && c0 + tid * 4 < C) b_reg = fd_ld4(bias + c0 + tid * 4);
+    vec w_reg = LN::zero(), b_reg = LN::zero();
+    if (w_item && c0 + w_cc * N < C) w_reg = LN::ldf(wp + (long)w_t * C + c0 + w_cc * N);
+    if (tid < lanes_c && c0 + tid * N < C) b_reg = LN::ldf(bias + c0 + tid * N);
 
     // Staging with memory-level parallelism: U patch pixels per work-item are requested back to back (2*U
     // independent 16-byte loads in flight in MODE 2) before any of them is consumed; a load -> add -> ds_write
@@ -214,7 +219,7 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
     constexpr int U = 8;
     fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
-        fd_f32x4 v[U], sk[U];
+        raw v[U], sk[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -222,51 +227,56 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
             const int iy = wk.iy, ix = wk.ix;
             wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
-            sk[u] = fd_zero4();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
             // branch-free: the address is clamped into the image / tensor and every lane loads unconditionally (all 2*U loads go out
             // back to back; measured -30 % on the train-mode twin of this kernel); the zero padding is applied when the value is stored
             const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
             const int qg = c_ok ? cg : 0;
             if (MODE == 0) {
-                v[u] = fd_ld4(in + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                v[u] = LN::ldraw(in + (((long)n * Hin + qy) * Win + qx) * C + qg);
             } else {
                 const int Hs = Hin >> 1, Ws = Win >> 1;
                 if (MODE == 3) {
                     // channel concatenation cat(up2(in), skip): channels [0, csplit) come from the low-resolution tensor (pitch
-                    // csplit), the rest from the skip tensor (pitch C - csplit); a lane's 4 channels never straddle (csplit % 4 == 0)
-                    if (qg < csplit) v[u] = fd_ld4(in + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * csplit + qg);
-                    else v[u] = fd_ld4(skip + (((long)n * Hin + qy) * Win + qx) * (C - csplit) + (qg - csplit));
+                    // csplit), the rest from the skip tensor (pitch C - csplit); a lane's N channels never straddle (csplit % N == 0)
+                    if (qg < csplit) v[u] = LN::ldraw(in + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * csplit + qg);
+                    else v[u] = LN::ldraw(skip + (((long)n * Hin + qy) * Win + qx) * (C - csplit) + (qg - csplit));
                 } else {
-                    v[u] = fd_ld4(in + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C + qg);
-                    if (MODE == 2) sk[u] = fd_ld4(skip + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                    v[u] = LN::ldraw(in + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C + qg);
+                    if (MODE == 2) sk[u] = LN::ldraw(skip + (((long)n * Hin + qy) * Win + qx) * C + qg);
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            if (px < npx_in) fd_st4(s_in + px * PSTR + c4 * 4, ok[u] ? (MODE == 2 ? v[u] + sk[u] : v[u]) : fd_zero4());
+            if (px < npx_in) {
+                lds_t *dst = s_in + px * PSTR + c4 * N;
+                // (N = 8: the up2(low) + skip sum is rounded to the storage type on its way into LDS; plain inputs are copied bit for bit)
+                if (MODE == 2) LN::lds_st(dst, ok[u] ? LN::cvt(v[u]) + LN::cvt(sk[u]) : LN::zero());
+                else if (ok[u]) LN::lds_st_raw(dst, v[u]);
+                else LN::lds_st(dst, LN::zero());
+            }
         }
     }
-    if (w_item) fd_st4(s_w + w_t * CB + w_cc * 4, w_reg);
-    if (tid < lanes_c) fd_st4(s_b + tid * 4, b_reg);
+    if (w_item) LN::stf(s_w + w_t * CB + w_cc * N, w_reg);
+    if (tid < lanes_c) LN::stf(s_b + tid * N, b_reg);
     __syncthreads();
 
     const int TWS = TW >> 2, nstrips = TH * TWS;
-    const fd_f32x4 b4 = fd_ld4(s_b + c4 * 4);
+    const vec b4 = LN::ldf(s_b + c4 * N);
     for (int s = pt; s < nstrips; s += npt) {
         const int oy = s / TWS, ox = (s - oy * TWS) * 4;
-        fd_f32x4 acc[4] = {b4, b4, b4, b4};
+        vec acc[4] = {b4, b4, b4, b4};
 #pragma unroll 1   // one filter row in flight: keeps the kernel at <=128 VGPRs (>=4 waves/SIMD hide the LDS latency)
         for (int ky = 0; ky < K; ++ky) {
-            const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
-            fd_f32x4 r[NIN];
+            const lds_t *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * N;
+            vec r[NIN];
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+            for (int i = 0; i < NIN; ++i) r[i] = LN::lds_ld(row + i * PSTR);
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const fd_f32x4 w = fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+                const vec w = LN::ldf(s_w + (ky * K + kx) * CB + c4 * N);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] += r[j * S + kx] * w;
             }
@@ -276,7 +286,7 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gx = ox0 + ox + j;
-                if (gx < Wo) fd_st4(out + (((long)n * Ho + gy) * Wo + gx) * C + cg, fd_act4<ACT>(acc[j]));
+                if (gx < Wo) LN::st(out + (((long)n * Ho + gy) * Wo + gx) * C + cg, fd_act4<ACT>(acc[j]));
             }
         }
     }

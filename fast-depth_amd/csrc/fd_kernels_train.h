@@ -38,20 +38,6 @@ __device__ __forceinline__ fd_f32x4 fd_bn_act4(fd_f32x4 z, fd_f32x4 s, fd_f32x4 
 {
     return fd_act4<ACT>(z * s + t);
 }
-// value a T-typed store will hold: the batch statistics are taken over the STORED (rounded) z, so that forward
-// normalisation and the BatchNorm backward see exactly the same tensor
-__device__ __forceinline__ fd_f32x4 fd_round4(float, fd_f32x4 v) { return v; }
-__device__ __forceinline__ fd_f32x4 fd_round4(fd_bf16, fd_f32x4 v)
-{
-    fd_f32x4 r = {fd_bf16_to_f32(fd_f32_to_bf16(v.x)), fd_bf16_to_f32(fd_f32_to_bf16(v.y)), fd_bf16_to_f32(fd_f32_to_bf16(v.z)), fd_bf16_to_f32(fd_f32_to_bf16(v.w))};
-    return r;
-}
-__device__ __forceinline__ fd_f32x4 fd_round4(fd_half, fd_f32x4 v)
-{
-    fd_f32x4 r = {(float)(_Float16)v.x, (float)(_Float16)v.y, (float)(_Float16)v.z, (float)(_Float16)v.w};
-    return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Stem, train mode, forward.  A workgroup owns 256 consecutive output pixels [p0, p1) of ONE
 // image (grid: blocks per image x images, fd_xcd_image_map2 -- neighbouring blocks' input bands overlap, so an image stays on one XCD's L2).

@@ -35,7 +35,7 @@ int defer_weights(BwdCtx &c, const float *part, int nrows, int n, int KK, int C,
 // CU); the upsampled modes produce 2 x 2 blocks per low-resolution pixel and need an even count
 inline int dw_dgrad_rows(const fd_train_plan *p, const TLayer &L)
 {
-    if (p->flags & FD_PLAN_TUNE_DW_TH8) return 8;
+    if (p->tune & FD_TUNE_DW_TH8) return 8;
     // 3x3 stride-1 units: 14 rows where they divide the map (same reasoning as the forward kernel's larger tiles: fewer, fatter workgroups; the
     // dz patch of 16 x 18 pixels = 41.5 KB stays below the 44.4 KB the paired weight-gradient role needs anyway)
     // (measured, bf16 step: conv1 55.3 -> 52.1 us, conv3 59.2 -> 55.1, conv5 35.3 -> 32.7, 14x14 maps 20.5 -> 19.5)
@@ -107,7 +107,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const int ncb_w = ceil_div(L.d.cin, 4 << L.cbq);
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);     // the backward-weights kernel's own output tiles (the forward's may be larger)
     int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ncb_w * c.p->B / FD_DW_WGRAD_TARGET_WGS)));
-    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = btx;
+    if (c.p->tune & FD_TUNE_WGRAD_TILE_ROWS) tpw = btx;
     const int groups_x = ceil_div(btx, tpw);
     tpw = ceil_div(btx, groups_x);
     const dim3 wgrid(groups_x * bty, ncb_w, c.p->B);
@@ -171,7 +171,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);
     int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ceil_div(L.d.cin, cb) * c.p->B / FD_DW_WGRAD_TARGET_WGS)));
-    if (c.p->flags & FD_PLAN_WGRAD_TILE_ROWS) tpw = btx;
+    if (c.p->tune & FD_TUNE_WGRAD_TILE_ROWS) tpw = btx;
     const int groups_x = ceil_div(btx, tpw);
     tpw = ceil_div(btx, groups_x);
     a.w_th = L.bth; a.w_tw = L.btw; a.w_tiles_x = btx; a.w_tpw = tpw; a.w_gx = groups_x * bty; a.w_gy = ceil_div(L.d.cin, cb);
@@ -185,10 +185,10 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     {
         const int cgn = L.d.cin / 4;
         const bool rows_ok = K == 3 && S == 2 && MODE == 0 && L.d.cin % 4 == 0 && cgn >= 8 && cgn <= 64 && (cgn & (cgn - 1)) == 0 &&
-                             (((long)L.out_h * L.out_w >= 28 * 28 && sizeof(T) == 2) || (c.p->flags & FD_PLAN_TUNE_DW_FORCE_ROWS));
+                             (((long)L.out_h * L.out_w >= 28 * 28 && sizeof(T) == 2) || (c.p->tune & FD_TUNE_DW_FORCE_ROWS));
         // measured (us, rows pair vs single-staging kernel): bf16 conv2.0 48.9 + 16.8 vs 79.3, conv4.0 33.4 + 11.0 vs 48.2, conv6.0 (14x14 outputs) 23.4 + 7.8 vs 29.6;
         // fp32 conv2.0 69.0 + 26.7 vs 96.2, conv4.0 40.7 + 15.3 vs 55.2 (equal: both forms move the fp32 bytes at the same rate) -> 16-bit plans, maps >= 28x28
-        if (rows_ok && !(c.p->flags & (FD_PLAN_TUNE_DW_NO_ROWS | FD_PLAN_TUNE_DW_BWD_PAIR | FD_PLAN_TUNE_DW_BWD1))) {
+        if (rows_ok && !(c.p->tune & (FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_BWD_PAIR | FD_TUNE_DW_BWD1))) {
             const int gxd = ceil_div((long)L.in_w * cgn, 256), h2 = L.in_h / 2;
             int th2 = h2;
             while (th2 > 2 && (long)gxd * ceil_div(h2, th2) * c.p->B < 1024) th2 = (th2 + 1) / 2;
@@ -213,8 +213,8 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     // 31.2 + 20.3 vs 52.8 us, conv3.0 34.8 + 20.5 vs 56.4, conv5.0 22.1 + 14.6 vs 33.1 -- the pair stays)
     // measured (bf16, batch 32): the single-staging kernel wins on the stride-2 units (conv2.0 84 vs 103 us, conv4.0 50 vs 57, conv6.0 31 vs 35) and
     // loses on the stride-1 3x3 ones (conv1.0 68 vs 57, 14x14 maps 22.4 vs 19.5: two tap phases back to back in one workgroup at lower residency);
-    // the 5x5 units tie.  FD_PLAN_TUNE_DW_BWD1 forces it everywhere (tests), FD_PLAN_TUNE_DW_BWD_PAIR nowhere.
-    if (!(c.p->flags & FD_PLAN_TUNE_DW_BWD_PAIR) && (S == 2 || (c.p->flags & FD_PLAN_TUNE_DW_BWD1))) {
+    // the 5x5 units tie.  FD_TUNE_DW_BWD1 forces it everywhere (tests), FD_TUNE_DW_BWD_PAIR nowhere.
+    if (!(c.p->tune & FD_TUNE_DW_BWD_PAIR) && (S == 2 || (c.p->tune & FD_TUNE_DW_BWD1))) {
         // ONE workgroup per input-space tile stages the dz patch and the forward-input patch once and produces both gradients (fd_dw_bwd1)
         const int oth = a.d_th / S, otw = a.d_tw / S;
         const int th_in1 = (oth - 1) * S + K, tw_in1 = (otw - 1) * S + K;
@@ -285,9 +285,9 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     splits = ceil_div(M, rows);
     if ((size_t)splits * N * K > L.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small");
     // backward data: 64 x 128 tiles of G_in when there are >= 128 input channels and that still leaves >= 200 workgroups: every dz fragment feeds two MFMAs
-    const bool pair = !(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING));
+    const bool pair = !(c.p->flags & FD_PLAN_NO_BWD_PAIRING) && !(c.p->tune & FD_TUNE_NO_PW_PAIRING);
     int tn = (K >= 128 && (long)ceil_div(M, 64) * ceil_div(K, 128) >= 200) ? 2 : 1;
-    if (pair && !(c.p->flags & FD_PLAN_TUNE_PW_PAIR_TN2)) tn = 1;   // paired launch: 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74: the weight-gradient workgroups share it) -- measured 554 vs 583 us per bf16 step
+    if (pair && !(c.p->tune & FD_TUNE_PW_PAIR_TN2)) tn = 1;   // paired launch: 64 x 64 backward-data tiles (49 KB of LDS per workgroup instead of 74: the weight-gradient workgroups share it) -- measured 554 vs 583 us per bf16 step
     const int m_tiles = ceil_div(M, 64), k_tiles = ceil_div(K, 64 * tn);
     const size_t lds_d = FD_PW_DGRAD_H16_RING(L.n64, tn) + (size_t)4 * 64 * tn * 4;     // ring of min(3, N tiles) stages (>= the epilogue's fp32 tiles) + statistics
     const bool add = P.skip_consumer >= 0;
@@ -352,7 +352,7 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
     const unsigned n_dgrad = (unsigned)((m_tiles + 7) / 8 * 8 * k_tiles);
     *nblk = m_tiles;
     int rc;
-    if (!(c.p->flags & (FD_PLAN_NO_BWD_PAIRING | FD_PLAN_TUNE_NO_PW_PAIRING))) {
+    if (!(c.p->flags & FD_PLAN_NO_BWD_PAIRING) && !(c.p->tune & FD_TUNE_NO_PW_PAIRING)) {
         const size_t lds = std::max(lds_w, lds_d);
         const int tiles_w = n_tiles * k_tiles;
         const dim3 grid(n_dgrad + (unsigned)(tiles_w * splits));

@@ -82,7 +82,7 @@ struct TLayer {
 struct fd_train_plan {
     std::vector<TLayer> layers;
     int B = 0, H = 0, W = 0, dtype = FD_F32;
-    uint32_t flags = 0;
+    uint32_t flags = 0, tune = 0;    // public plan flags (include/fastdepth_hip.h) / private tuning mask (fd_tuning.h)
     size_t esz = 4;                  // bytes per stored activation / activation-gradient element
     size_t ws_bytes = 0, part_off = 0, part_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
     unsigned char *ws = nullptr;
@@ -252,13 +252,17 @@ extern "C" {
 int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
                          int32_t dtype, uint32_t flags, fd_train_plan **out_plan)
 {
+    const uint32_t tune = fd_take_tuning();                  // (consumed even when the creation fails)
     if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
+    if (tune & ~FD_TUNE_ALL) return fail(FD_ERR_INVALID, "unknown tuning bits 0x%x", tune & ~FD_TUNE_ALL);
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
     if (dtype != FD_F32 && dtype != FD_BF16)
         return fail(FD_ERR_INVALID, "train plan: dtype %d not supported (fp32 or bf16; fp16 gradients would need loss scaling)", dtype);
+    if (flags & ~FD_PLAN_ALL_FLAGS) return fail(FD_ERR_INVALID, "unknown plan flag bits 0x%x", flags & ~FD_PLAN_ALL_FLAGS);
     fd_train_plan *p = new fd_train_plan();
     p->B = batch; p->H = height; p->W = width; p->dtype = dtype; p->flags = flags;
+    p->tune = tune;
     const bool h16 = dtype != FD_F32;
     const size_t esz = h16 ? 2 : 4;
     p->esz = esz;
@@ -311,12 +315,12 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);
             L.mode = d.upsample ? (d.skip >= 0 ? (concat ? 3 : 2) : 1) : 0;
             L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
-            const int cb_max = (flags & FD_PLAN_TUNE_DW_CB16) ? 16 : 32;
+            const int cb_max = (tune & FD_TUNE_DW_CB16) ? 16 : 32;
             const int cb = d.cin >= cb_max ? cb_max : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             L.cbq = ilog2(cb / 4);
             const bool k5 = d.ksize == 5;
             L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : (k5 ? FD_T_DW5_FTW : 16));
-            L.th = (flags & FD_PLAN_TUNE_DW_TH8) ? std::min(L.out_h, 8) : ceil_div(L.out_h, ceil_div(L.out_h, k5 ? FD_T_DW5_FTH : 8));   // balanced rows: 14 -> 7 + 7 instead of 8 + 6 (both tiles full, smaller patches: one more workgroup per CU)
+            L.th = (tune & FD_TUNE_DW_TH8) ? std::min(L.out_h, 8) : ceil_div(L.out_h, ceil_div(L.out_h, k5 ? FD_T_DW5_FTH : 8));   // balanced rows: 14 -> 7 + 7 instead of 8 + 6 (both tiles full, smaller patches: one more workgroup per CU)
             // The backward kernels keep these tiles (L.bth / L.btw).  The FORWARD kernel takes larger ones on stride-1 units: a workgroup's life is dominated
             // by fixed costs (tap / table loads ~2 us, barriers, the reduction: 4 us even with no patch loads or stores at all --
             // tools/microbench/dwtrain.hip), so fewer, fatter workgroups win until the patch staging takes too many load rounds:
@@ -324,16 +328,16 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             L.bth = L.th; L.btw = L.tw;
             if (k5) { L.btw = std::min((L.out_w + 3) / 4 * 4, FD_T_DW5_WTW); L.bth = ceil_div(L.out_h, ceil_div(L.out_h, FD_T_DW5_WTH)); }
             // (5x5 weight-gradient tiles of 4 rows -- 32 KB of LDS instead of 53 -- measured slower: decode_conv5 156 -> 169 us)
-            if (d.ksize == 5 && (flags & FD_PLAN_TUNE_DW_WGRAD_TH4)) L.bth = ceil_div(L.out_h, ceil_div(L.out_h, 4));
+            if (d.ksize == 5 && (tune & FD_TUNE_DW_WGRAD_TH4)) L.bth = ceil_div(L.out_h, ceil_div(L.out_h, 4));
             // (3x3 stride-1 weight-gradient tiles of 7 rows -- 39.5 KB instead of 44.4: four resident workgroups per CU -- measured neutral in the paired launch)
             // (3x3 units only: the 5x5 decoder units LOSE with larger tiles -- 34 -> 50 us at 56x56, their patch staging takes too many load rounds)
-            if (d.stride == 1 && d.ksize == 3 && !(flags & FD_PLAN_TUNE_DW_SMALL_TILES)) {
+            if (d.stride == 1 && d.ksize == 3 && !(tune & FD_TUNE_DW_SMALL_TILES)) {
                 L.th = L.out_h <= 14 ? L.out_h : (L.out_h <= 56 ? 14 : 16);
                 L.tw = L.out_w <= 16 ? (L.out_w + 3) / 4 * 4 : (L.out_w <= 56 ? 28 : 16);
             }
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
-            L.pstr = L.bpstr = cb + 4 + 4 * (int)((flags >> 26) & 3);       // (FD_PLAN_TUNE_DW_PITCH: +4 / +8 / +12 floats)
+            L.pstr = L.bpstr = cb + 4 + 4 * (int)((tune / FD_TUNE_DW_PITCH4) & 3);       // (FD_TUNE_DW_PITCH4 / 8: +4 / +8 / +12 floats)
             L.lds = (std::max((size_t)th_in * tw_in * L.pstr, (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
@@ -342,7 +346,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 const int cg = d.cin / 4;
                 const bool rows_ok = d.ksize == 3 && L.mode == 0 && d.cin % 4 == 0 && cg >= 8 && cg <= 64 && (cg & (cg - 1)) == 0;
                 // measured (bf16, us, rows vs tiled): conv1.0 19.2 / 22.9, conv2.0 15.1 / 29.2, conv3.0 19.0 / 21.1, conv4.0 10.5 / 15.1, conv5.0 (256 channels) 13.8 / 11.7
-                if (rows_ok && !(flags & FD_PLAN_TUNE_DW_NO_ROWS) && (((long)L.out_h * L.out_w >= 28 * 28 && cg <= 32) || (flags & FD_PLAN_TUNE_DW_FORCE_ROWS))) {
+                if (rows_ok && !(tune & FD_TUNE_DW_NO_ROWS) && (((long)L.out_h * L.out_w >= 28 * 28 && cg <= 32) || (tune & FD_TUNE_DW_FORCE_ROWS))) {
                     const int gx = ceil_div((long)L.out_w * cg, 256);
                     int th = L.out_h;
                     while (th > 4 && (long)gx * ceil_div(L.out_h, th) * batch < 1024) th = (th + 1) / 2;

@@ -1,0 +1,39 @@
+// fd_tuning.h -- PRIVATE tuning / test mask of libfastdepth_hip.so.  Not part of the boundary (include/fastdepth_hip.h): a caller
+// of the library never needs any of this.  The bits select kernel variants for A/B measurements (tools/gpu_ab.sh) and let the small
+// shapes of the test tiers exercise kernels that the plan would otherwise only pick at full size.
+//
+// Hand-over: fd_tuning_next(mask) stores the mask in a thread-local slot; the NEXT fd_plan_create / fd_train_plan_create /
+// fd_plan_import of the same thread consumes it (and resets the slot to 0), so plans created by anybody who does not call the hook are
+// untouched.  The hook is exported from the shared library but declared only here; fast-depth_amd/fastdepth_hip/capi.py mirrors the
+// values as FD_TUNE_* (Python ints shifted above bit 32 so that a single `flags=` argument can carry both masks).
+#pragma once
+#include <stdint.h>
+
+#define FD_TUNE_WGRAD_TILE_ROWS 1u        /* train: depthwise weight-gradient workgroups always walk a whole row of tiles (small test shapes exercise the tile loop) */
+#define FD_TUNE_FORCE_GEMM16 2u           /* every pointwise layer with cout % 4 == 0 on the one-workgroup-per-CU GEMM (fd_pw_gemm16_*), whatever its shape */
+#define FD_TUNE_FORCE_EPILOGUE_FUSION 4u  /* 16-bit plans: fd_pw_gemm16_h16 + fused depthwise consumer for every eligible pair */
+#define FD_TUNE_FORCE_UNIT_FUSION 8u      /* fd_dwpw_f32 for every eligible depthwise + pointwise pair whatever the map size */
+#define FD_TUNE_NO_PW_PAIRING 16u         /* train: pair only the depthwise units' backward kernels, not the pointwise GEMMs */
+#define FD_TUNE_PW_PAIR_TN2 32u           /* 16-bit train: the paired pointwise backward keeps 64 x 128 backward-data tiles */
+#define FD_TUNE_DW_BWD1 64u               /* train: every depthwise unit's backward runs as the single-staging kernel fd_dw_bwd1 */
+#define FD_TUNE_DW_BWD_PAIR 128u          /* train: every depthwise unit's backward runs as the paired launch fd_dw_bwd */
+#define FD_TUNE_DW_SMALL_TILES 256u       /* train: the depthwise FORWARD kernel keeps the 7..8 x 16 tiles of the backward kernels */
+#define FD_TUNE_DW_PITCH4 512u            /* train: LDS patch pitch +4 floats (PITCH8: +8; both: +12).  PITCH8 must stay PITCH4 << 1 */
+#define FD_TUNE_DW_PITCH8 1024u
+#define FD_TUNE_DW_WGRAD_TH4 2048u        /* train: 5x5 weight-gradient workgroups take output tiles of 4 rows */
+#define FD_TUNE_DW_NO_ROWS 4096u          /* train: the 3x3 depthwise kernels always run LDS-tiled (no register-window kernels) */
+#define FD_TUNE_DW_FORCE_ROWS 8192u       /* tests: the register-window kernels on every eligible 3x3 unit whatever the map size */
+#define FD_TUNE_DW_TH8 16384u             /* train: depthwise tiles of 8 rows with a ragged last tile instead of balanced row counts */
+#define FD_TUNE_DW_CB16 32768u            /* train: depthwise kernels work on 16-channel blocks instead of 32 */
+#define FD_TUNE_NO_DW_H8 65536u           /* 16-bit plans: the LDS-tiled depthwise kernels keep fp32 patches and 4 channels per work-item (round-1..3 form)
+                                             instead of storage-typed patches and 8 channels (16 bytes) per work-item */
+#define FD_TUNE_ALL 131071u
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the mask applies to the next plan this thread creates (then resets to 0); unknown bits are rejected by that creation */
+void fd_tuning_next(uint32_t mask);
+#ifdef __cplusplus
+}
+#endif

@@ -19,28 +19,60 @@ class _DtypeMap(dict):
 DTYPE_OF = _DtypeMap()      # torch dtype -> fd_dtype (torch imported lazily: this module is also used by tests without torch tensors)
 FD_OP_STEM, FD_OP_DW, FD_OP_PW = 0, 1, 2
 FD_ACT_NONE, FD_ACT_RELU, FD_ACT_RELU6 = 0, 1, 2
+# public plan flags (include/fastdepth_hip.h)
 FD_PLAN_KEEP_ACTIVATIONS = 1
-FD_PLAN_WGRAD_TILE_ROWS = 8
-FD_PLAN_FORCE_GEMM16 = 16
 FD_PLAN_NO_GEMM16 = 64
-FD_PLAN_NO_ROWS8 = 128
+FD_PLAN_NO_ROWS8 = 256
 FD_PLAN_NO_EPILOGUE_FUSION = 512
 FD_PLAN_NO_UNIT_FUSION = 1024
-FD_PLAN_FORCE_UNIT_FUSION = 2048
 FD_PLAN_NO_BWD_PAIRING = 4096
-FD_PLAN_FORCE_EPILOGUE_FUSION = 8192
-FD_PLAN_TUNE_NO_PW_PAIRING = 65536
-FD_PLAN_TUNE_PW_PAIR_TN2 = 131072
-FD_PLAN_TUNE_DW_CB16 = 262144
-FD_PLAN_TUNE_DW_TH8 = 524288
-FD_PLAN_TUNE_DW_BWD_PAIR = 8388608
-FD_PLAN_TUNE_DW_BWD1 = 16777216
-FD_PLAN_TUNE_DW_SMALL_TILES = 33554432
-FD_PLAN_TUNE_DW_PITCH4 = 67108864
-FD_PLAN_TUNE_DW_PITCH8 = 134217728
-FD_PLAN_TUNE_DW_WGRAD_TH4 = 268435456
-FD_PLAN_TUNE_DW_NO_ROWS = 536870912
-FD_PLAN_TUNE_DW_FORCE_ROWS = 1073741824
+# private tuning / test mask (csrc/fd_tuning.h), handed to the library through fd_tuning_next before the plan is created.  The Python
+# mirrors are shifted above bit 32 so that ONE `flags=` integer can carry both masks: create_plan() below splits it.
+_TUNE_SHIFT = 32
+FD_TUNE_WGRAD_TILE_ROWS = 1 << _TUNE_SHIFT
+FD_TUNE_FORCE_GEMM16 = 2 << _TUNE_SHIFT
+FD_TUNE_FORCE_EPILOGUE_FUSION = 4 << _TUNE_SHIFT
+FD_TUNE_FORCE_UNIT_FUSION = 8 << _TUNE_SHIFT
+FD_TUNE_NO_PW_PAIRING = 16 << _TUNE_SHIFT
+FD_TUNE_PW_PAIR_TN2 = 32 << _TUNE_SHIFT
+FD_TUNE_DW_BWD1 = 64 << _TUNE_SHIFT
+FD_TUNE_DW_BWD_PAIR = 128 << _TUNE_SHIFT
+FD_TUNE_DW_SMALL_TILES = 256 << _TUNE_SHIFT
+FD_TUNE_DW_PITCH4 = 512 << _TUNE_SHIFT
+FD_TUNE_DW_PITCH8 = 1024 << _TUNE_SHIFT
+FD_TUNE_DW_WGRAD_TH4 = 2048 << _TUNE_SHIFT
+FD_TUNE_DW_NO_ROWS = 4096 << _TUNE_SHIFT
+FD_TUNE_DW_FORCE_ROWS = 8192 << _TUNE_SHIFT
+FD_TUNE_DW_TH8 = 16384 << _TUNE_SHIFT
+FD_TUNE_DW_CB16 = 32768 << _TUNE_SHIFT
+FD_TUNE_NO_DW_H8 = 65536 << _TUNE_SHIFT
+
+
+def create_plan(lib, train, descs, n, batch, height, width, fd_dtype, flags, handle_ref):
+    """fd_plan_create / fd_train_plan_create with a combined flags integer: the low 32 bits are the public plan flags, the bits above
+    are the private tuning mask (FD_TUNE_*), passed through fd_tuning_next -- which only this thread's next creation consumes."""
+    tuning = int(flags) >> _TUNE_SHIFT
+    if tuning:
+        lib.fd_tuning_next(tuning)
+    fn = lib.fd_train_plan_create if train else lib.fd_plan_create
+    return fn(descs, n, batch, height, width, fd_dtype, int(flags) & 0xFFFFFFFF, handle_ref)
+
+
+def parse_flags(text):
+    """'NO_DW_H8|NO_BWD_PAIRING' / '0x200' / '' -> the combined flags integer create_plan() takes (names without their FD_PLAN_ / FD_TUNE_ prefix)."""
+    v = 0
+    for tok in str(text).replace(",", "|").split("|"):
+        tok = tok.strip()
+        if not tok:
+            continue
+        g = globals()
+        if "FD_PLAN_" + tok in g:
+            v |= g["FD_PLAN_" + tok]
+        elif "FD_TUNE_" + tok in g:
+            v |= g["FD_TUNE_" + tok]
+        else:
+            v |= int(tok, 0)
+    return v
 
 
 class LayerDesc(ctypes.Structure):
@@ -78,6 +110,8 @@ def load(path=None):
     vp, i32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32
     lib.fd_plan_create.argtypes = [ctypes.POINTER(LayerDesc), i32, i32, i32, i32, i32, u32, ctypes.POINTER(vp)]
     lib.fd_plan_create.restype = ctypes.c_int
+    lib.fd_tuning_next.argtypes = [u32]       # private hook (csrc/fd_tuning.h), not part of include/fastdepth_hip.h
+    lib.fd_tuning_next.restype = None
     lib.fd_plan_destroy.argtypes = [vp]
     lib.fd_plan_destroy.restype = None
     lib.fd_plan_workspace_bytes.argtypes = [vp]

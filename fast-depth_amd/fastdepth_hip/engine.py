@@ -31,7 +31,7 @@ class _Plan:
         n = len(self.layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         handle = ctypes.c_void_p()
-        capi.check(L, L.fd_plan_create(descs, n, batch, height, width, _DTYPES[engine.dtype],
+        capi.check(L, capi.create_plan(L, False, descs, n, batch, height, width, _DTYPES[engine.dtype],
                                        (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | engine.plan_flags, ctypes.byref(handle)), "fd_plan_create")
         self.dtype = engine.dtype
         self.handle = handle

@@ -47,7 +47,7 @@ class _TrainPlan:
         n = len(layers)
         descs = (capi.LayerDesc * n)(*[l.desc for l in layers])
         handle = ctypes.c_void_p()
-        capi.check(L, L.fd_train_plan_create(descs, n, batch, height, width, capi.DTYPE_OF[dtype], _TrainPlan.default_flags, ctypes.byref(handle)), "fd_train_plan_create")
+        capi.check(L, capi.create_plan(L, True, descs, n, batch, height, width, capi.DTYPE_OF[dtype], _TrainPlan.default_flags, ctypes.byref(handle)), "fd_train_plan_create")
         self.handle = handle
         nbytes = L.fd_train_plan_workspace_bytes(handle)
         self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)

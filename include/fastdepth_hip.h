@@ -51,31 +51,17 @@ enum fd_op {
 };
 enum fd_act { FD_ACT_NONE = 0, FD_ACT_RELU = 1, FD_ACT_RELU6 = 2 };
 
-/* plan flags */
-#define FD_PLAN_KEEP_ACTIVATIONS 1u /* one private buffer per layer output (needed for fd_layer_output); default: lifetime-based reuse */
-#define FD_PLAN_WGRAD_TILE_ROWS 8u  /* train plans: depthwise weight-gradient workgroups always walk a whole row of tiles (default: only when that still leaves >= ~1536 workgroups); lets small test shapes exercise the tile loop */
-#define FD_PLAN_FORCE_GEMM16 16u     /* every fp32 pointwise layer with cout % 4 == 0 runs on fd_pw_gemm16_f32 (16x16x4 MFMA, one workgroup per CU), whatever its shape: lets small test shapes exercise that kernel; default: only where one round of workgroups covers the layer */
-#define FD_PLAN_NO_EPILOGUE_FUSION 512u /* never evaluate a depthwise layer in the epilogue of its pointwise producer (A/B measurements, tests of the unfused kernels) */
-#define FD_PLAN_FORCE_EPILOGUE_FUSION 8192u /* 16-bit plans: fd_pw_gemm16_h16 + fused depthwise consumer for every eligible pair (default: only where it was measured to pay: 14x14 maps, one round of workgroups); lets small test shapes exercise the kernel */
-#define FD_PLAN_NO_UNIT_FUSION 1024u   /* never run a depthwise + pointwise unit of a large map as one kernel (fd_dwpw_f32): A/B measurements, tests of the unfused kernels */
-#define FD_PLAN_FORCE_UNIT_FUSION 2048u /* fd_dwpw_f32 for every eligible depthwise + pointwise pair whatever the map size: lets small test shapes exercise that kernel */
-#define FD_PLAN_NO_BWD_PAIRING 4096u   /* train plans: launch a unit's backward-data and backward-weights kernels one after the other instead of as one paired launch (A/B measurements, tests of the separate kernels) */
-#define FD_PLAN_TUNE_NO_PW_PAIRING 65536u  /* tuning aid (train plans): pair only the depthwise units' backward kernels, not the pointwise GEMMs */
-#define FD_PLAN_TUNE_PW_PAIR_TN2 131072u   /* tuning aid (16-bit train plans): the paired pointwise backward launch keeps the 64 x 128 backward-data tiles of the unpaired kernel (74 KB of LDS per workgroup instead of 49) */
-#define FD_PLAN_TUNE_DW_BWD1 16777216u     /* tuning aid / tests (train plans): every depthwise unit's backward runs as the single-staging kernel fd_dw_bwd1 (default: the stride-2 units only, where it was measured to pay) */
-#define FD_PLAN_TUNE_DW_BWD_PAIR 8388608u  /* tuning aid (train plans): a depthwise unit's backward runs as the paired launch of its two separate kernels (fd_dw_bwd) instead of the single-staging kernel fd_dw_bwd1 (which the stride-2 units use by default) */
-#define FD_PLAN_TUNE_DW_SMALL_TILES 33554432u /* tuning aid (train plans): the depthwise FORWARD kernel keeps the 7..8 x 16 output tiles of the backward kernels instead of its larger ones (14 x 28, 16 x 16, whole 14 x 14 frames) */
-#define FD_PLAN_TUNE_DW_PITCH4 67108864u   /* tuning aid (train plans): the depthwise kernels' LDS patch pitch is 4 floats (PITCH8: 8; both: 12) above the default */
-#define FD_PLAN_TUNE_DW_PITCH8 134217728u
-#define FD_PLAN_TUNE_DW_WGRAD_TH4 268435456u /* tuning aid (train plans): the 5x5 depthwise weight-gradient workgroups take output tiles of 4 rows instead of 7..8 (32 KB of LDS instead of 53) */
-#define FD_PLAN_TUNE_DW_NO_ROWS 536870912u   /* tuning aid (train plans): the 3x3 depthwise forward always runs on the LDS-tiled kernel (default: the register-window kernel fd_dw3_rows_train on the large maps with 32 ... 256 channels) */
-#define FD_PLAN_TUNE_DW_FORCE_ROWS 1073741824u /* tests: the register-window kernel on every eligible 3x3 unit whatever the map size */
-#define FD_PLAN_TUNE_DW_TH8 524288u        /* tuning aid (train plans): depthwise tiles of 8 rows with a ragged last tile (round 1/2) instead of balanced row counts */
-#define FD_PLAN_TUNE_DW_CB16 262144u       /* tuning aid (train plans): depthwise kernels work on 16-channel blocks instead of 32 (half the LDS per workgroup, twice the workgroups) */
-#define FD_PLAN_NO_ROWS8 128u        /* 16-bit plans: the 3x3 depthwise layers run on the 4-channel register-window kernel instead of the 8-channel one (A/B measurements, tests) */
-#define FD_PLAN_NO_GEMM16 64u        /* never use fd_pw_gemm16_f32 (A/B measurements against the 32x32x2 kernel) */
-/* (bits 4, 32 and 128 selected round-1 / round-2 experiments -- a separable-unit kernel, a stream-K GEMM, side-stream weight gradients -- that were
- * measured no faster and have been removed; DESIGN.md section 10 keeps the measurements.) */
+/* plan flags (fd_plan_create / fd_train_plan_create).  Unknown bits are rejected.  The kernel-selection switches used for A/B
+ * measurements and by the test tiers are NOT part of this boundary: they live in fast-depth_amd/csrc/fd_tuning.h. */
+#define FD_PLAN_KEEP_ACTIVATIONS 1u     /* one private buffer per layer output (needed for fd_layer_output / fd_train_layer_tensor); default: lifetime-based reuse */
+#define FD_PLAN_NO_GEMM16 64u           /* fallback: never use the one-workgroup-per-CU pointwise GEMMs (fd_pw_gemm16_*); the first-generation 64x64-tile GEMM runs every pointwise layer */
+#define FD_PLAN_NO_ROWS8 256u           /* fallback (16-bit plans): the 3x3 depthwise layers run on the 4-channel register-window kernel instead of the 8-channel one */
+#define FD_PLAN_NO_EPILOGUE_FUSION 512u /* fallback: never evaluate a depthwise layer in the epilogue of its pointwise producer, nor the head on a GEMM's output tile */
+#define FD_PLAN_NO_UNIT_FUSION 1024u    /* fallback: never run a depthwise + pointwise unit of a large map as one kernel (fd_dwpw_f32) */
+#define FD_PLAN_NO_BWD_PAIRING 4096u    /* fallback (train plans): a unit's backward-data and backward-weights kernels as two launches instead of one paired launch */
+#define FD_PLAN_ALL_FLAGS (1u | 64u | 256u | 512u | 1024u | 4096u)
+/* (bit values are never reused: 4, 8, 16, 32, 128, 2048, 8192 and everything from 65536 up selected experiments and tuning aids of rounds 1-3
+ * and are rejected now; deploy bundles written by those library versions carry the magic "FDPLAN1" and are refused by fd_plan_import.) */
 
 typedef struct fd_layer_desc {
     int32_t op;       /* enum fd_op */

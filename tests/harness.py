@@ -39,7 +39,7 @@ class CPlan:
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         self.h = ctypes.c_void_p()
         b, _, hh, ww = x.shape
-        capi.check(L, L.fd_plan_create(descs, n, b, hh, ww, fd_dtype, (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | flags,
+        capi.check(L, capi.create_plan(L, False, descs, n, b, hh, ww, fd_dtype, (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | flags,
                                        ctypes.byref(self.h)), "fd_plan_create")
         nbytes = L.fd_plan_workspace_bytes(self.h)
         self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
@@ -143,7 +143,7 @@ class CTrainPlan:
         descs = (capi.LayerDesc * n)(*[l.desc for l in self.layers])
         self.h = ctypes.c_void_p()
         b, _, hh, ww = x.shape
-        capi.check(L, L.fd_train_plan_create(descs, n, b, hh, ww, capi.DTYPE_OF[dtype], (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | flags, ctypes.byref(self.h)), "fd_train_plan_create")
+        capi.check(L, capi.create_plan(L, True, descs, n, b, hh, ww, capi.DTYPE_OF[dtype], (capi.FD_PLAN_KEEP_ACTIVATIONS if keep else 0) | flags, ctypes.byref(self.h)), "fd_train_plan_create")
         nbytes = L.fd_train_plan_workspace_bytes(self.h)
         self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.dev)
         base = (self.ws.data_ptr() + 255) // 256 * 256

@@ -47,6 +47,51 @@ def test_plan_api_without_a_gpu():
     assert b"multiples of 32" in lib.fd_last_error()
 
 
+def test_public_flags_and_private_tuning_mask():
+    """The public header keeps only the flags a caller needs; unknown bits (incl. every retired round-1..3 value) are rejected by both plan
+    constructors; the kernel-selection switches of the tests / A-B tools travel through the private hook fd_tuning_next (csrc/fd_tuning.h),
+    which is exported but NOT declared in include/fastdepth_hip.h, applies to the next creation only and rejects unknown bits too."""
+    from fastdepth_hip import capi
+    src = open(HEADER).read()
+    public = dict(re.findall(r"#define (FD_PLAN_[A-Z0-9_]+) \(?(\d+)u", src))
+    assert set(public) == {"FD_PLAN_KEEP_ACTIVATIONS", "FD_PLAN_NO_GEMM16", "FD_PLAN_NO_ROWS8", "FD_PLAN_NO_EPILOGUE_FUSION", "FD_PLAN_NO_UNIT_FUSION",
+                           "FD_PLAN_NO_BWD_PAIRING", "FD_PLAN_ALL_FLAGS"}, public
+    assert "TUNE" not in src.replace("fd_tuning.h", "") and "FORCE" not in src
+    for name, val in public.items():
+        if name != "FD_PLAN_ALL_FLAGS":
+            assert getattr(capi, name) == int(val), name
+    tuning = dict(re.findall(r"#define (FD_TUNE_[A-Z0-9_]+) (\d+)u", open(os.path.join(REPO, "fast-depth_amd", "csrc", "fd_tuning.h")).read()))
+    for name, val in tuning.items():
+        if name != "FD_TUNE_ALL":
+            assert getattr(capi, name) == int(val) << 32, name
+    assert int(tuning["FD_TUNE_ALL"]) == sum(int(v) for k, v in tuning.items() if k != "FD_TUNE_ALL")
+    lib = capi.load()
+    assert "fd_tuning_next" not in declared_functions() and hasattr(lib, "fd_tuning_next")
+    import torch  # noqa: F401  (plan.py needs the module tree)
+    import models
+    from fastdepth_hip import plan as plan_mod
+    m = models.MobileNetSkipAdd((64, 64), pretrained=False)
+    layers = plan_mod.layers_of(m)
+    n = len(layers)
+    descs = (capi.LayerDesc * n)(*[l.desc for l in layers])
+    h = ctypes.c_void_p()
+    for bad in (4, 8, 16, 32, 128, 2048, 8192, 65536, 1 << 20, 1 << 30):
+        for train in (False, True):
+            assert capi.create_plan(lib, train, descs, n, 1, 64, 64, capi.FD_F32, bad, ctypes.byref(h)) == -1, (bad, train)
+            assert b"unknown plan flag" in lib.fd_last_error()
+    # unknown tuning bits are refused; a refused creation still consumes the mask: the next plain creation succeeds
+    assert capi.create_plan(lib, False, descs, n, 1, 64, 64, capi.FD_F32, (1 << 30) << 32, ctypes.byref(h)) == -1
+    assert b"unknown tuning" in lib.fd_last_error()
+    assert capi.create_plan(lib, False, descs, n, 1, 64, 64, capi.FD_F32, 0, ctypes.byref(h)) == 0
+    lib.fd_plan_destroy(h)
+    # the mask reaches the plan it was set for (kernel choice visible in the plan's description) and no later one
+    assert capi.create_plan(lib, False, descs, n, 2, 64, 64, capi.FD_F32, capi.FD_TUNE_FORCE_GEMM16, ctypes.byref(h)) == 0
+    forced = sum(lib.fd_plan_kernel_info(h, i).startswith(b"pw_gemm16") for i in range(n)); lib.fd_plan_destroy(h)
+    assert capi.create_plan(lib, False, descs, n, 2, 64, 64, capi.FD_F32, 0, ctypes.byref(h)) == 0
+    plain = sum(lib.fd_plan_kernel_info(h, i).startswith(b"pw_gemm16") for i in range(n)); lib.fd_plan_destroy(h)
+    assert forced > plain
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from fastdepth_hip import capi
     with pytest.raises(capi.FastDepthError):

@@ -42,7 +42,7 @@ def test_emulated_gemm16_matches_oracle(name, plan, b, hw):
     h, w = (hw, hw) if isinstance(hw, int) else hw
     m = small_model(plan[0], plan[1], seed=21)
     x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(8))
-    err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), flags=harness.capi.FD_PLAN_FORCE_GEMM16)
+    err, per_layer, info = harness.compare_with_oracle("emu", m, x, torch.device("cpu"), flags=harness.capi.FD_TUNE_FORCE_GEMM16)
     used = [s for s in info if s.startswith("pw_gemm16")]
     assert len(used) == 18, info
     if name == "ragged":
@@ -70,7 +70,7 @@ def test_emulated_dwpw_units_match_oracle(b, hw):
     m = small_model(UNITS[0], UNITS[1], seed=31).eval()
     x = torch.rand(b, 3, *hw, generator=torch.Generator().manual_seed(9))
     y_ref, taps_ref = oracle.forward(m.state_dict(), x.numpy(), taps=True)
-    cp = harness.CPlan("emu", m, x, keep=True, flags=harness.capi.FD_PLAN_FORCE_UNIT_FUSION)
+    cp = harness.CPlan("emu", m, x, keep=True, flags=harness.capi.FD_TUNE_FORCE_UNIT_FUSION)
     info = cp.info()
     y = cp.forward(x).numpy()
     units = [i for i, s in enumerate(info) if s.startswith("dwpw<")]
@@ -189,10 +189,10 @@ def test_emulated_skip_concat_sibling_forward():
 
 
 @pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
-@pytest.mark.parametrize("name,plan,b,hw,flags", [("tiny", TINY, 2, (64, 64), harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION), ("tiny5", TINY, 5, (64, 64), harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION),
-                                                  ("ragged", RAGGED, 2, (64, 64), harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION),
-                                                  ("ragged_forced", RAGGED, 2, (32, 96), harness.capi.FD_PLAN_FORCE_GEMM16),
-                                                  ("tiny_forced", TINY, 3, (64, 64), harness.capi.FD_PLAN_FORCE_GEMM16)])
+@pytest.mark.parametrize("name,plan,b,hw,flags", [("tiny", TINY, 2, (64, 64), harness.capi.FD_TUNE_FORCE_EPILOGUE_FUSION), ("tiny5", TINY, 5, (64, 64), harness.capi.FD_TUNE_FORCE_EPILOGUE_FUSION),
+                                                  ("ragged", RAGGED, 2, (64, 64), harness.capi.FD_TUNE_FORCE_EPILOGUE_FUSION),
+                                                  ("ragged_forced", RAGGED, 2, (32, 96), harness.capi.FD_TUNE_FORCE_GEMM16),
+                                                  ("tiny_forced", TINY, 3, (64, 64), harness.capi.FD_TUNE_FORCE_GEMM16)])
 def test_emulated_16bit_gemm16_and_fused_epilogues(name, plan, b, hw, flags, dtype, ulp):
     """fd_pw_gemm16_h16 (16x16x32 MFMA, whole frames per workgroup, depthwise consumer in the epilogue) against the first-generation 16-bit
     kernels (fd_pw_gemm_h16 + separate depthwise launches) on the same plan: both round the pointwise output to the storage type before the
@@ -209,7 +209,7 @@ def test_emulated_16bit_gemm16_and_fused_epilogues(name, plan, b, hw, flags, dty
     used = [s for s in info if s.startswith("pw_gemm16")]
     fused = [s for s in info if "evaluated in the epilogue" in s]
     assert not any(s.startswith("pw_gemm16") for s in old.info())
-    if flags == cap.FD_PLAN_FORCE_GEMM16:
+    if flags == cap.FD_TUNE_FORCE_GEMM16:
         assert len(used) == 18, info
     else:
         assert len(used) >= 6 and len(fused) == len(used), info           # picked exactly where a consumer fuses
@@ -240,3 +240,35 @@ def test_emulated_16bit_head_on_the_last_gemm(name, plan, dtype):
     ya, yb = fused.forward(x), plain.forward(x)
     assert ya.shape == (3, 1, 64, 96) and harness.rel_err(ya.numpy(), yb.numpy()) < 2e-6
     fused.close(); plain.close()
+
+
+WIDE = ((16, 32, 64, 64, 128, 128, 40, 40, 40, 40, 40, 40, 48, 16), (200, 128, 64, 32, 16, 1))   # 64-channel depthwise blocks (cb = 64), a padded pruned width, a 16-channel block
+
+
+@pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("b,hw", [(2, (64, 64)), (1, (64, 96))])
+def test_emulated_16bit_depthwise_8_channels_per_work_item(b, hw, dtype, ulp):
+    """16-bit plans run the LDS-tiled depthwise layers (the decoder's 5x5 units: plain, on up2, on up2 + skip) with storage-typed LDS patches and
+    8 channels (16 bytes) per work-item (fd_dwconv<T, ..., 8>); FD_TUNE_NO_DW_H8 keeps the fp32-patch / 4-channel form.  Plain and upsampled inputs
+    are copied into LDS bit for bit and the taps accumulate in fp32 in the same order, so those layers agree exactly; the up2(low) + skip sum is
+    rounded to the storage type on its way into LDS (the 4-channel form keeps it in fp32): one extra rounding of the conv input."""
+    m = small_model(WIDE[0], WIDE[1], seed=44).eval()
+    x = torch.rand(b, 3, hw[0], hw[1], generator=torch.Generator().manual_seed(13))
+    cap = harness.capi
+    new = harness.CPlan("emu", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_EPILOGUE_FUSION)
+    old = harness.CPlan("emu", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_EPILOGUE_FUSION | cap.FD_TUNE_NO_DW_H8)
+    info = new.info()
+    h8 = [i for i, s in enumerate(info) if s.startswith("dwconv<") and "8 channels per work-item" in s]
+    assert len(h8) == 5 and {info[i].split("tile ")[1].split(" ")[0].split("x")[2] for i in h8} >= {"64", "32", "16"}, info
+    assert not any("8 channels per work-item" in s for s in old.info())
+    y_new, y_old = new.forward(x), old.forward(x)
+    prev_exact = True
+    for i in range(len(new.layers) - 1):
+        a, r = new.tap(i).double(), old.tap(i).double()
+        d = float((a - r).abs().max()) / max(float(r.abs().max()), 1e-30)
+        if i in h8 and prev_exact and "mode2" not in info[i]:
+            assert d == 0.0, (i, info[i], d)                  # same inputs, bit-for-bit staging, same accumulation order
+        assert d <= 3.0 * ulp, (i, info[i], d)
+        prev_exact = prev_exact and d == 0.0
+    assert harness.rel_err(y_new.numpy(), y_old.numpy()) < 6 * ulp
+    new.close(); old.close()

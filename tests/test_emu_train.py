@@ -146,14 +146,14 @@ def assert_local_parity(rep, dtype):
     assert {"z", "bn_table", "running", "bn_grads", "conv_wgrad", "g_src", "skip_grad", "pred", "g_head"} <= set(rep)
 
 
-@pytest.mark.parametrize("name,plan,dtype,flags", [("tiny", TINY, torch.float32, 0), ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_WGRAD_TILE_ROWS),
+@pytest.mark.parametrize("name,plan,dtype,flags", [("tiny", TINY, torch.float32, 0), ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_WGRAD_TILE_ROWS),
                                                    ("ragged", RAGGED, torch.bfloat16, 0), ("tiny_wide", TINY, torch.float32, 0),
                                                    ("tiny_sat6", TINY, torch.float32, 0), ("ragged_sat6", RAGGED, torch.bfloat16, 0),
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_NO_BWD_PAIRING),
-                                                   ("tiny", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD_PAIR),
-                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_BWD1),
-                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_PITCH4 | capi.FD_PLAN_TUNE_DW_PITCH8 | capi.FD_PLAN_TUNE_DW_WGRAD_TH4),
-                                                   ("tiny", TINY, torch.float32, capi.FD_PLAN_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.bfloat16, capi.FD_PLAN_TUNE_DW_FORCE_ROWS)])
+                                                   ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_DW_BWD_PAIR),
+                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_BWD1),
+                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_PITCH4 | capi.FD_TUNE_DW_PITCH8 | capi.FD_TUNE_DW_WGRAD_TH4),
+                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.bfloat16, capi.FD_TUNE_DW_FORCE_ROWS)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     """Every unit's forward and backward kernels on their own stored inputs against an fp64 single-unit autograd reference
     (harness.local_train_parity): the rigorous check of the bf16 train plan, whose end-to-end
@@ -165,7 +165,7 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     h, w = (160, 224) if name == "tiny_wide" else ((224, 32) if name == "tiny_tall" else (64, 64))   # tiny_tall: map heights 112 ... 7 (the 14-row backward-data tiles; H must be a multiple of 32)
     # tiny_wide: > 256 partial rows per reduction (280 for conv1.3 / decode_conv5.1) -> the sliced (last-arriver) path
     # (default plans: a stride-2 depthwise unit's backward is ONE single-staging kernel (fd_dw_bwd1), the other depthwise units' two kernels and a
-    # pointwise unit's two GEMMs share a paired launch; FD_PLAN_TUNE_DW_BWD1 / _PAIR: the single-staging kernel everywhere / nowhere;
+    # pointwise unit's two GEMMs share a paired launch; FD_TUNE_DW_BWD1 / _PAIR: the single-staging kernel everywhere / nowhere;
     # FD_PLAN_NO_BWD_PAIRING: every kernel on its own)
     x = torch.rand(2, 3, h, w, generator=g)
     target = 2.0 + torch.rand(2, 1, h, w, generator=g)
@@ -210,7 +210,7 @@ def test_emulated_val_transform_gather():
         capi.check(L, L.fd_val_transform(rgb.data_ptr(), depth.data_ptr(), 2, 480, 640, 224, 224, ymap.data_ptr(), xmap.data_ptr(), x.data_ptr(), None, None), "fd_val_transform")
 
 
-@pytest.mark.parametrize("dtype,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD1)])
+@pytest.mark.parametrize("dtype,flags", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, capi.FD_TUNE_DW_BWD1)])
 def test_emulated_skip_concat_train_step_layer_local(dtype, flags):
     """Row f-3: train step of the concatenating sibling (depthwise MODE 3 in the train forward, backward-data and backward-weights
     kernels: two channel ranges read from / differentiated into two tensors), small widths, layer-local fp64 check."""

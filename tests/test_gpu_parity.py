@@ -265,7 +265,7 @@ def test_forced_gemm16_layerwise(pruned, b):
     torch.manual_seed(70 + b)
     m = harness.randomize_bn(models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if pruned else None), 71 + b)
     x = inputs.batch_variants(inputs.load_sample()[0], b, seed=6)
-    err, per_layer, info = harness.compare_with_oracle("hip", m, x, torch.device("cuda"), flags=harness.capi.FD_PLAN_FORCE_GEMM16)
+    err, per_layer, info = harness.compare_with_oracle("hip", m, x, torch.device("cuda"), flags=harness.capi.FD_TUNE_FORCE_GEMM16)
     assert sum(s.startswith("pw_gemm16") for s in info) == 18, info
     bad = [(i, e, info[i]) for i, e in enumerate(per_layer) if not e < TOL]
     assert not bad and err < TOL, bad
@@ -290,7 +290,7 @@ def test_dwpw_units_layerwise(b, h, w):
     m = harness.randomize_bn(models.MobileNetSkipAdd((h, w), pretrained=False), 91 + b).eval()
     x = torch.rand(b, 3, h, w, generator=torch.Generator().manual_seed(92 + b))
     y_ref, taps_ref = oracle.forward(m.state_dict(), x.numpy(), taps=True)
-    cp = harness.CPlan("hip", m, x.cuda(), keep=True, flags=harness.capi.FD_PLAN_FORCE_UNIT_FUSION)
+    cp = harness.CPlan("hip", m, x.cuda(), keep=True, flags=harness.capi.FD_TUNE_FORCE_UNIT_FUSION)
     info = cp.info()
     y = cp.forward(x.cuda()).cpu().numpy()
     assert sum(s.startswith("dwpw<") for s in info) == 5, info
@@ -401,8 +401,8 @@ def test_forward_graph_replay_equals_eager_forward(b, streams):
 
 
 @pytest.mark.parametrize("dtype,ulp", [(torch.float16, 2.0 ** -10), (torch.bfloat16, 2.0 ** -7)])
-@pytest.mark.parametrize("pruned,b,flags", [(False, 32, 0), (False, 32, harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION), (True, 64, harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION),
-                                            (True, 5, harness.capi.FD_PLAN_FORCE_EPILOGUE_FUSION), (False, 3, harness.capi.FD_PLAN_FORCE_GEMM16), (True, 2, harness.capi.FD_PLAN_FORCE_GEMM16)])
+@pytest.mark.parametrize("pruned,b,flags", [(False, 32, 0), (False, 32, harness.capi.FD_TUNE_FORCE_EPILOGUE_FUSION), (True, 64, harness.capi.FD_TUNE_FORCE_EPILOGUE_FUSION),
+                                            (True, 5, harness.capi.FD_TUNE_FORCE_EPILOGUE_FUSION), (False, 3, harness.capi.FD_TUNE_FORCE_GEMM16), (True, 2, harness.capi.FD_TUNE_FORCE_GEMM16)])
 def test_16bit_gemm16_fused_epilogues_vs_first_generation_kernels(pruned, b, flags, dtype, ulp):
     """fd_pw_gemm16_h16 (whole frames per workgroup, depthwise consumers in the GEMM epilogue: 9 launches and their round trips fewer per
     forward) at BASELINE's sizes -- unpruned batch 32 and the pruned plan at batch 64 (configs[4]: irregular channel counts) -- against the
@@ -420,7 +420,7 @@ def test_16bit_gemm16_fused_epilogues_vs_first_generation_kernels(pruned, b, fla
     info = new.info()
     used = [s for s in info if s.startswith("pw_gemm16")]
     fused = [s for s in info if "evaluated in the epilogue" in s]
-    if flags == cap.FD_PLAN_FORCE_GEMM16:
+    if flags == cap.FD_TUNE_FORCE_GEMM16:
         assert len(used) == 18, info
     elif flags:
         assert len(used) == 9 and len(fused) == 9, info               # conv6.3 ... conv13.3, decode_conv1.1, each with the next depthwise layer

@@ -115,7 +115,7 @@ def test_train_step_layer_local_parity_full_size(pruned, dtype, sat6):
     x, tgt = _batch(2)
     from fastdepth_hip import capi
     # (pruned case: weight-gradient tile rows; saturating cases: every depthwise unit through the single-staging backward kernel, 5x5 + upsample + skip included)
-    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype, flags=capi.FD_PLAN_WGRAD_TILE_ROWS if pruned else (capi.FD_PLAN_TUNE_DW_BWD1 if sat6 else 0))
+    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype, flags=capi.FD_TUNE_WGRAD_TILE_ROWS if pruned else (capi.FD_TUNE_DW_BWD1 if sat6 else 0))
     assert_local_parity(rep, dtype)
     if sat6:
         assert harness.LAST_SAT6_FRAC > 0.005, harness.LAST_SAT6_FRAC
@@ -131,7 +131,7 @@ def test_no_skip_sibling_train_step_layer_local():
     m.decoder.conv6[1].bias.data.fill_(2.8)
     x, tgt = _batch(2, seed=6)
     from fastdepth_hip import capi
-    for dtype, flags in ((torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, capi.FD_PLAN_TUNE_DW_BWD1)):      # (DW_BWD1: MODE 1 through the single-staging backward kernel)
+    for dtype, flags in ((torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, capi.FD_TUNE_DW_BWD1)):      # (DW_BWD1: MODE 1 through the single-staging backward kernel)
         rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype, flags=flags)
         rep.setdefault("skip_grad", (0.0, "none"))                       # no skip tensors in this model
         assert_local_parity(rep, dtype)

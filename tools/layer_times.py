@@ -6,11 +6,11 @@ sys.path.insert(0, os.path.join(REPO, "fast-depth_amd")); sys.path.insert(0, REP
 import numpy as np, torch
 import models
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--pruned", action="store_true"); ap.add_argument("--dtype", default="f32"); ap.add_argument("--plan-flags", type=lambda v: int(v, 0), default=0); ap.add_argument("--lib", default=None); a = ap.parse_args()
+ap.add_argument("--pruned", action="store_true"); ap.add_argument("--dtype", default="f32"); ap.add_argument("--plan-flags", type=str, default="0"); ap.add_argument("--lib", default=None); a = ap.parse_args()
 from fastdepth_hip import capi
 if a.lib: capi.DEFAULT_LIB = os.path.abspath(a.lib)       # a tools/build_variant.py build instead of the product library
 from fastdepth_hip.engine import Engine
-Engine.default_plan_flags = a.plan_flags
+Engine.default_plan_flags = capi.parse_flags(a.plan_flags)
 torch.manual_seed(0)
 m = models.MobileNetSkipAdd((224, 224), pretrained=False, channels=models.PRUNED_CHANNELS if a.pruned else None).eval().cuda()
 x = torch.rand(a.batch, 3, 224, 224, device="cuda")

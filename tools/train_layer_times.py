@@ -8,10 +8,10 @@ import models
 from fastdepth_hip import capi
 from fastdepth_hip.train import TrainEngine
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--dtype", default="bf16"); ap.add_argument("--plan-flags", type=lambda v: int(v, 0), default=0); ap.add_argument("--summary", action="store_true"); ap.add_argument("--lib", default=None); a = ap.parse_args()
+ap.add_argument("--dtype", default="bf16"); ap.add_argument("--plan-flags", type=str, default="0"); ap.add_argument("--summary", action="store_true"); ap.add_argument("--lib", default=None); a = ap.parse_args()
 if a.lib: capi.DEFAULT_LIB = os.path.abspath(a.lib)       # a tools/build_variant.py build instead of the product library
 from fastdepth_hip import train as _train
-_train._TrainPlan.default_flags = a.plan_flags
+_train._TrainPlan.default_flags = capi.parse_flags(a.plan_flags)
 torch.manual_seed(0)
 m = models.MobileNetSkipAdd((224, 224), pretrained=False).cuda().train()
 eng = TrainEngine(m, dtype={"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[a.dtype])
@@ -42,7 +42,7 @@ torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.c
 e0.record()
 for _ in range(20): eng.step(x, t)
 e1.record(); torch.cuda.synchronize()
-print("plan flags %d, %s: step %.4f ms (untraced, 20 steps)" % (a.plan_flags, a.dtype, e0.elapsed_time(e1) / 20))
+print("plan flags %s, %s: step %.4f ms (untraced, 20 steps)" % (a.plan_flags, a.dtype, e0.elapsed_time(e1) / 20))
 for f, (n, us) in sorted(by_fam.items(), key=lambda kv: -kv[1][1]): print("  family %-28s %3d launches %8.1f us" % (f, n, us))
 print("total %.1f us in %d launches" % (tot, len(acc)))
 for l in sorted(by_layer): print("layer %3d %-16s %8.1f us" % (l, names[l] if 0 <= l < len(names) else "-", by_layer[l]))
