@@ -95,7 +95,7 @@ def layerwise_bound_ms(stats, mfma_peak_tflops):
     t = 0.0
     for st in stats:
         name, sym, info, nbytes, flops = st[:5]
-        peak = mfma_peak_tflops if "pw_gemm" in sym else MFMA_F32_PEAK_TFLOPS
+        peak = gemm_peak_of(sym, mfma_peak_tflops) if "pw_gemm" in sym else MFMA_F32_PEAK_TFLOPS
         t += max(nbytes / (HBM_PEAK_GBS * 1e9), flops / (peak * 1e12))
     return t * 1e3
 
@@ -108,12 +108,27 @@ def fused_plan_bound_ms(stats, mfma_peak_tflops):
     for name, sym, info, nbytes, flops, needed in stats:
         if not sym:
             continue
-        peak = mfma_peak_tflops if ("pw_gemm" in sym or "dwpw" in sym) else MFMA_F32_PEAK_TFLOPS
+        peak = gemm_peak_of(sym, mfma_peak_tflops) if ("pw_gemm" in sym or "dwpw" in sym) else MFMA_F32_PEAK_TFLOPS
         t += max(needed / (HBM_PEAK_GBS * 1e9), flops / (peak * 1e12))
     return t * 1e3
 
 
 _PMC = None
+# kernel families that contain a matrix product (MFMA): classified MFMA- or HBM-bound by which of the two times is larger, not by name
+_GEMM_FAMILIES = ("gemm", "fd_pw_bwd", "fd_pw_dgrad", "fd_pw_wgrad", "fd_dwpw", "fd_stem")
+
+
+def gemm_peak_of(sym, plan_peak_tflops):
+    """MFMA peak that prices a kernel's flops: the stem kernels and every *_f32 kernel multiply in fp32 (v_mfma_f32_32x32x2_f32 /
+    16x16x4_f32) whatever the plan's storage type; the 16-bit GEMMs run on the 16-bit matrix instructions."""
+    return MFMA_F32_PEAK_TFLOPS if ("stem" in sym or "_f32" in sym) else plan_peak_tflops
+
+
+def pmc_source():
+    pmc_traffic("infer", "")
+    meta = (_PMC or {}).get("_meta") or {}
+    return "profiles/pmc_traffic.json (%s): committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 + WRITE_SIZE per launch; NOT re-measured in this run" % (
+        meta.get("source", "round and run not recorded in the file"))
 
 
 def pmc_traffic(cfg, name):
@@ -132,14 +147,17 @@ def pmc_traffic(cfg, name):
 def roofline_of(entry, sym, mfma_peak_tflops, total_ms, cfg="infer"):
     """entry: {"launches", "ms", "bytes", "flops"} summed over the launches of one kernel symbol / family in ONE step."""
     t_s = entry["ms"] / 1e3
+    mfma_peak_tflops = gemm_peak_of(sym, mfma_peak_tflops)
     hbm_time, mfma_time = entry["bytes"] / (HBM_PEAK_GBS * 1e9), entry["flops"] / (mfma_peak_tflops * 1e12)
-    if "gemm" in sym and mfma_time >= hbm_time:
+    if any(t in sym for t in _GEMM_FAMILIES) and mfma_time >= hbm_time:
         roof = {"bound": "mfma", "achieved": round(entry["flops"] / t_s / 1e12, 3), "peak": mfma_peak_tflops, "unit": "TFLOP/s"}
     else:
         roof = {"bound": "hbm", "achieved": round(entry["bytes"] / t_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
     e = pmc_traffic(cfg, sym)                                # per-launch HBM bytes from the rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE), if collected
     roof["traffic"] = round(e["bytes_per_launch"], 1) if e else None
+    roof["traffic_source"] = pmc_source() if e else None
+    roof["time_at_peak_us"] = {"hbm": round(hbm_time / entry["launches"] * 1e6, 2), "mfma": round(mfma_time / entry["launches"] * 1e6, 2)}
     roof.update({"kernel": sym, "launches_per_step": entry["launches"], "avg_launch_us": round(entry["ms"] * 1e3 / entry["launches"], 2),
                  "share_of_device_time": round(entry["ms"] / total_ms, 4),
                  "algorithmic_per_launch": {"bytes": entry["bytes"] / entry["launches"], "flops": entry["flops"] / entry["launches"]}})
@@ -191,7 +209,7 @@ _TRAIN_MAJOR = ("gemm_train", "dwconv_train", "dw3_rows_train", "stem_train", "h
 _TRAIN_PAIRED = ("head_bwd<", "fd_dw_bwd<", "fd_dw_bwd1<", "fd_pw_bwd_")       # one launch = a unit's backward-data AND backward-weights pass
 
 
-def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes, cfg="train_bf16"):
+def train_profile(teng, xs, tgts, stats, steps, mfma_peak_tflops, param_bytes, cfg="train_bf16"):
     """Per-kernel-family device time of the fused train step (fd_trace: HIP events around every launch), with the algorithmic bytes /
     flops of the unit each launch belongs to."""
     import ctypes
@@ -199,9 +217,10 @@ def train_profile(teng, x, tgt, stats, steps, mfma_peak_tflops, param_bytes, cfg
     L = teng.L
     import torch
     fam = {}
-    for _ in range(steps):
+    x = xs[0]
+    for i in range(steps):
         capi.check(L, L.fd_trace_begin(), "fd_trace_begin")
-        teng.step(x, tgt)
+        teng.step(xs[i % len(xs)], tgts[i % len(tgts)])
         n = ctypes.c_int32()
         recs = (capi.TraceRecord * 4096)()
         capi.check(L, L.fd_trace_end(torch.cuda.current_stream(x.device).cuda_stream, recs, 4096, ctypes.byref(n)), "fd_trace_end")
@@ -488,16 +507,18 @@ def main():
                            force_buckets=force_dist, dtype=dtype, grad_exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32)
 
     gt = torch.Generator().manual_seed(1)
-    tgt = (0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=gt)).to(dev)     # synthetic depth, U[0.7, 10) m
+    # synthetic depth, U[0.7, 10) m: one target per input batch of the ring (the train loops rotate (input, target) pairs like the inference loop)
+    tgt_ring = [(0.7 + 9.3 * torch.rand(args.batch, 1, 224, 224, generator=gt)).to(dev) for _ in range(NRING)]
+    tgt = tgt_ring[0]
 
     def time_train(dtype, tag, steps):
         teng = make_train_engine(dtype)
-        for _ in range(3):
-            loss = teng.step(x, tgt)
+        for i in range(3):
+            loss = teng.step(x_ring[i % NRING], tgt_ring[i % NRING])
         barrier()
         t1 = time.perf_counter()
-        for _ in range(steps):
-            loss = teng.step(x, tgt)
+        for i in range(steps):
+            loss = teng.step(x_ring[(i + 3) % NRING], tgt_ring[(i + 3) % NRING])
         torch.cuda.synchronize()
         t_el = time.perf_counter() - t1
         barrier()
@@ -506,6 +527,7 @@ def main():
         res = {"metric": "frames/sec (224x224) train step: fwd + L1 loss + bwd + gradient all-reduce + SGD(momentum, wd)",
                "value": round(world * args.batch * steps / t_el, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": 3,
                "ms_per_step": round(t_el / steps * 1e3, 4), "dtype": tag, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+               "input_batches_in_rotation": NRING,
                "parallelism": ("dp%d: RCCL all-reduce of the %s gradient vector in %d buckets (cut by finish time) on a side stream, overlapped with backward" % (world, "7.92 MB bf16" if args.grad_exchange == "bf16" else "15.84 MB fp32", len(teng.buckets)))
                               if teng.use_comm else "single GPU"}
         if teng.use_comm:        # how long the collectives take and how much of them backward hides (3 instrumented steps, synchronising)
@@ -521,7 +543,7 @@ def main():
             stats = eng.layer_stats(x)                      # algorithmic bytes / flops per unit at this storage type
             eng.set_dtype(torch.float32)
             peak = MFMA_F32_PEAK_TFLOPS if dtype == torch.float32 else MFMA_H16_PEAK_TFLOPS
-            roof, whole, kernels = train_profile(teng, x, tgt, stats, 3, peak, 4.0 * teng.total, "train_f32" if dtype == torch.float32 else "train_bf16")
+            roof, whole, kernels = train_profile(teng, x_ring, tgt_ring, stats, 3, peak, 4.0 * teng.total, "train_f32" if dtype == torch.float32 else "train_bf16")
             res["roofline"], res["whole_step"], res["kernels"] = roof, whole, kernels[:12]
             res["whole_step"]["frac_of_roofline"] = round(whole["roofline_bound_ms"] / res["ms_per_step"], 4)
         return res
@@ -532,11 +554,11 @@ def main():
             t = time_forward(model, x_ring, args.steps, args.warmup)
         elif args.only in ("f16", "bf16"):
             model.set_compute_dtype(torch.float16 if args.only == "f16" else torch.bfloat16)
-            t = time_forward(model, x, args.steps, args.warmup)
+            t = time_forward(model, x_ring, args.steps, args.warmup)
         elif args.only == "pruned_f16":
             pm = build_model(dev, pruned=True); pm.set_compute_dtype(torch.float16)
-            x64 = torch.rand(64, 3, 224, 224, generator=g).to(dev)
-            t = time_forward(pm, x64, args.steps, args.warmup) / 2.0        # reported per 32 frames for comparability
+            x64_ring = [torch.cat([x_ring[2 * i], x_ring[2 * i + 1]]) for i in range(NRING // 2)] + [torch.rand(64, 3, 224, 224, generator=g).to(dev) for _ in range(NRING - NRING // 2)]
+            t = time_forward(pm, x64_ring, args.steps, args.warmup) / 2.0   # reported per 32 frames for comparability
         else:
             r = time_train(torch.float32 if args.only == "train_f32" else torch.bfloat16, args.only, args.steps)
             t = r["ms_per_step"] * args.steps / 1e3
@@ -571,23 +593,24 @@ def main():
     extras = []
     if args.extra_steps > 0 and world == 1:
         pm = build_model(dev, pruned=True)
-        x64 = torch.rand(64, 3, 224, 224, generator=g).to(dev)
+        x64_ring = [torch.cat([x_ring[2 * i], x_ring[2 * i + 1]]) for i in range(NRING // 2)] + [torch.rand(64, 3, 224, 224, generator=g).to(dev) for _ in range(NRING - NRING // 2)]
+        x64 = x64_ring[0]
         pm.set_compute_dtype(torch.float16)
-        dt = time_forward(pm, x64, args.extra_steps, 5) / args.extra_steps
+        dt = time_forward(pm, x64_ring, args.extra_steps, 5) / args.extra_steps
         r64, w64, _, _ = inference_profile(pm._engine(), x64, 3, MFMA_H16_PEAK_TFLOPS, "pruned_f16")
         w64["frac_of_roofline"] = round(w64["roofline_bound_ms"] / (dt * 1e3), 4)
         w64["frac_of_fused_plan_bound"] = round(w64["fused_plan_bound_ms"] / (dt * 1e3), 4)
         extras.append({"config": "configs[4]: pruned plan (mobilenet-nnconv5dw-skipadd-pruned), batch=64, fp16 storage / fp32 accumulate, inference",
-                       "value": round(64 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f16", "roofline": r64, "whole_step": w64})
+                       "value": round(64 / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": "f16", "input_batches_in_rotation": NRING, "roofline": r64, "whole_step": w64})
         del pm
         for dtype, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
             model.set_compute_dtype(dtype)
-            dt = time_forward(model, x, args.extra_steps, 5) / args.extra_steps
+            dt = time_forward(model, x_ring, args.extra_steps, 5) / args.extra_steps
             r16, w16, _, _ = inference_profile(eng, x, 3, MFMA_H16_PEAK_TFLOPS, tag)
             w16["frac_of_roofline"] = round(w16["roofline_bound_ms"] / (dt * 1e3), 4)
             w16["frac_of_fused_plan_bound"] = round(w16["fused_plan_bound_ms"] / (dt * 1e3), 4)
             extras.append({"config": "unpruned, batch=32, %s storage / fp32 accumulate, inference" % tag, "value": round(args.batch / dt, 1),
-                           "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": tag, "roofline": r16, "whole_step": w16})
+                           "unit": "frames/s", "ms_per_step": round(dt * 1e3, 4), "dtype": tag, "input_batches_in_rotation": NRING, "roofline": r16, "whole_step": w16})
         model.set_compute_dtype(torch.float32)
         x1 = x[:1].contiguous()
         dt = time_forward(model, x1, args.extra_steps, 5, fn=lambda: eng.forward_graph(x1)) / args.extra_steps

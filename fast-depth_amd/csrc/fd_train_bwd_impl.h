@@ -193,6 +193,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             int th2 = h2;
             while (th2 > 2 && (long)gxd * ceil_div(h2, th2) * c.p->B < 1024) th2 = (th2 + 1) / 2;
             const int gyd = ceil_div(h2, th2);
+            if ((size_t)gxd * gyd * c.p->B * 2 * L.d.cin * 4 > c.p->part_bytes) return fail(FD_ERR_STATE, "BatchNorm partial buffer too small for the stride-2 register-window backward kernel");
             FD_LAUNCH((fd_dw3s2_dgrad_rows<T, ACT1, ADD_SG>), dim3(gxd, gyd, c.p->B), dim3(256), 0, c.s, a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.part,
                       L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, th2);
             int rcr = check_launch("fd_dw3s2_dgrad_rows");
@@ -509,7 +510,10 @@ int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t 
 int fd_cast_gradients(const void *src, void *dst, int64_t numel, int32_t to_bf16, void *stream)
 {
     if (!src || !dst || numel <= 0) return fail(FD_ERR_INVALID, "fd_cast_gradients: null/empty argument");
-    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;       // 16-byte fp32 side / 8-byte bf16 side accesses
+    // 4 values per work-item: 16-byte accesses on the fp32 side, 8-byte accesses on the bf16 side -- each side is tested against ITS access width
+    // (bucket starts are multiples of 4 elements: a bf16 pointer at 8 mod 16 is fine and must not drop the whole bucket to one element per work-item)
+    const uintptr_t p32 = reinterpret_cast<uintptr_t>(to_bf16 ? src : dst), p16 = reinterpret_cast<uintptr_t>(to_bf16 ? dst : src);
+    const bool al = (p32 & 15) == 0 && (p16 & 7) == 0;
     const long n4 = al ? (long)(numel >> 2) : 0;
     const unsigned nb = (unsigned)std::min<long>(2048, ceil_div((long)std::max<int64_t>(numel / 4, 1), 256));
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -419,6 +419,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         // (the depthwise backward-data kernel leaves one row of the PRODUCER's statistics per input-space tile: sized for the smallest tile a build
         // switch may select, 4 rows x 8 columns)
         if (d.op == FD_OP_DW) max_part = std::max(max_part, (size_t)ceil_div(L.in_w, 8) * ceil_div(L.in_h, 4) * batch * d.cin);
+        // (the register-window backward-data kernel of the stride-2 units, fd_dw3s2_dgrad_rows: one row of 2 * C floats per 256 (input column,
+        // channel group) pairs x strip of >= 2 low-resolution rows x image -- more rows than the tiled kernels leave once C > 128)
+        if (d.op == FD_OP_DW && d.stride == 2) max_part = std::max(max_part, (size_t)ceil_div((long)L.in_w * (d.cin / 4), 256) * ceil_div(L.in_h / 2, 2) * batch * 2 * d.cin);
         max_width = std::max(max_width, (size_t)2 * d.cout);
         if (d.op == FD_OP_DW) max_width = std::max(max_width, (size_t)d.ksize * d.ksize * d.cin);
         if (d.op == FD_OP_STEM) max_width = std::max(max_width, (size_t)27 * d.cout);

@@ -227,9 +227,10 @@ def test_emulated_skip_concat_train_step_layer_local(dtype, flags):
 
 
 def test_autograd_function_returns_gradients():
-    """The drop-in autograd entry point (TrainFunction) hands its gradients to autograd: `.grad` adopts a view of the flat buffer (no
-    copy), a second backward accumulates (old + new), torch.autograd.grad / tensor hooks see the gradients, frozen parameters get
-    none, and a backward against a workspace that a later forward overwrote is refused."""
+    """The drop-in autograd entry point (TrainFunction) hands its gradients to autograd: nothing the caller gets (`.grad`, the result of
+    torch.autograd.grad, a hook's argument) aliases the plan's flat gradient buffer -- values held across a later backward stay put --, a
+    second backward accumulates (old + new), torch.autograd.grad / tensor hooks see the gradients, frozen parameters get none, and a backward
+    against a workspace that a later forward overwrote is refused."""
     from fastdepth_hip.train import TrainCore, autograd_forward
     L = harness.get_lib("emu")
     m = small_model(TINY[0], TINY[1], seed=3).train()
@@ -242,9 +243,10 @@ def test_autograd_function_returns_gradients():
     m.conv1[0].weight.register_hook(lambda gr: seen.append(gr.clone()))
     params = [p for p in m.parameters() if p.requires_grad]
     base = core.flat_grad.untyped_storage().data_ptr()
-    # 1) plain backward: .grad is a view of the flat buffer, the hook fired with the same values
+    # 1) plain backward: .grad holds the gradients but never the plan's buffer itself; the hook fired with the same values
     loss = (autograd_forward(core, x1) - tgt).abs().mean(); loss.backward()
-    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in params)
+    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() != base for p in params)
+    held = params[0].grad                                            # a reference a caller keeps across later backwards
     assert m.conv3[3].weight.grad is None
     assert len(seen) == 1 and torch.equal(seen[0], m.conv1[0].weight.grad)
     g1 = [p.grad.clone() for p in params]
@@ -254,7 +256,12 @@ def test_autograd_function_returns_gradients():
     assert all(t is not None for t in got)
     g2 = [t.clone() for t in got]
     assert any(not torch.equal(a, b) for a, b in zip(g1, g2))
-    assert all(torch.equal(p.grad, a) for p, a in zip(params, g1))   # .grad kept step 1's values (moved off the buffer), untouched by autograd.grad
+    assert all(torch.equal(p.grad, a) for p, a in zip(params, g1))   # .grad kept step 1's values, untouched by autograd.grad
+    assert held is params[0].grad and torch.equal(held, g1[0])
+    # ... and the tensors autograd.grad returned survive the NEXT backward of the same model unchanged
+    loss = (autograd_forward(core, x1) - tgt).abs().mean()
+    again = torch.autograd.grad(loss, params)
+    assert all(torch.equal(t, b) for t, b in zip(got, g2)) and all(torch.equal(t, a) for t, a in zip(again, g1))
     # 3) accumulation without zero_grad: old + new
     loss = (autograd_forward(core, x2) - tgt).abs().mean(); loss.backward()
     for p, a, b in zip(params, g1, g2):

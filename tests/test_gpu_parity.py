@@ -126,6 +126,36 @@ def test_16bit_storage_golden_case(dtype, tol, mtol):
         assert harness.rel_err(m(x.cuda()).cpu().numpy(), y_ref.numpy()) < TOL      # switching back re-plans in fp32
 
 
+@pytest.mark.parametrize("dtype,tol,mtol_d1,mtol_rmse", [(torch.float16, 4e-3, 2e-3, 1e-2), (torch.bfloat16, 3e-2, 2e-3, 1e-2)])
+def test_16bit_default_plan_batch32_vs_oracle(dtype, tol, mtol_d1, mtol_rmse):
+    """The plan `bench.py` times as `other_configs` fp16 / bf16 B=32 (unpruned, DEFAULT flags) compared DIRECTLY with the oracle: the fp32 torch
+    restatement in 8-frame chunks, as test_full_batch32_vs_oracle_and_properties does for the fp32 plan.  Asserts through plan.info() that the
+    round-3 / round-4 kernels are the ones that ran: fd_pw_gemm16_h16 with fused depthwise epilogues, the head on decode_conv5.1's GEMM tile,
+    the 8-channel register-window 3x3 kernel and the 8-channel storage-typed 5x5 depthwise kernel.  Element-wise bound `tol`; delta1 within
+    `mtol_d1` and RMSE within `mtol_rmse` (relative) of the oracle's, per frame against the sample depth map."""
+    m, _, _, _ = inputs.golden_case("base_s0")
+    x = inputs.batch_variants(inputs.load_sample()[0], 32, seed=0)
+    p = torch_ref.params_from_state(m.state_dict())
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        y_ref = torch.cat([torch_ref.forward(p, x[i:i + 8]) for i in range(0, 32, 8)])
+    mg = m.cuda().set_compute_dtype(dtype)
+    with torch.no_grad():
+        y = mg(x.cuda()).cpu()
+    info = [st[2] for st in mg._engine().layer_stats(x.cuda())]
+    assert sum(s.startswith("pw_gemm16") and "fused dw" in s for s in info) >= 6, info
+    assert any("head on its output tile" in s for s in info), info
+    assert any(s.startswith("dw3_rows8") for s in info), info
+    assert sum(s.startswith("dwconv<k5") and "8 channels per work-item" in s for s in info) >= 3, info
+    assert harness.rel_err(y.numpy(), y_ref.numpy()) < tol
+    depth = inputs.load_sample()[1].numpy()
+    for i in (0, 5, 17, 31):
+        got, want = metrics.evaluate(y[i:i + 1].numpy(), depth), metrics.evaluate(y_ref[i:i + 1].numpy(), depth)
+        assert abs(got["delta1"] - want["delta1"]) <= mtol_d1 * max(abs(want["delta1"]), 1e-6) + 1e-6, (i, got["delta1"], want["delta1"])
+        assert abs(got["rmse"] - want["rmse"]) <= mtol_rmse * max(abs(want["rmse"]), 1e-6) + 1e-6, (i, got["rmse"], want["rmse"])
+    mg.set_compute_dtype(torch.float32)
+
+
 def test_pruned_fp16_batch64_config5():
     """BASELINE.json configs[4]: pruned plan (irregular channel counts, multiples of 8), batch 64, fp16."""
     models = inputs.product_models()

@@ -256,6 +256,15 @@ def test_train_step_layer_local_parity_batch32(dtype):
     tp.close()
     y, flat = _product_plan_gradients(m, x, tgt, dtype)
     assert torch.equal(y, y_keep) and torch.equal(flat, flat_keep)
+    if dtype == torch.bfloat16:
+        # end to end at configs[2]'s size: the first-step loss of the bf16 plan against the fp64 oracle's train-mode forward on the same
+        # parameters and batch (chunks would change the batch statistics: the oracle runs all 32 frames at once).  2e-2 as at batch 8.
+        p64 = torch_ref.params_from_state(m.state_dict(), torch.float64)
+        with torch.no_grad():
+            y64 = torch_ref.forward(p64, x.double(), train=True)
+        loss64 = float((y64 - tgt.double()).abs().mean())
+        loss_hip = float((y.double() - tgt.double()).abs().mean())
+        assert abs(loss_hip - loss64) <= 2e-2 * loss64, (loss_hip, loss64)
 
 
 def test_train_forward_backward_parity_batch32():

@@ -56,4 +56,5 @@ for cfg in ("infer", "train_f32", "train_bf16", "f16", "bf16", "pruned_f16"):
         traffic[cfg] = {k: {"bytes_per_launch": (2.0 * e["FETCH_SIZE"][0] / max(e["FETCH_SIZE"][1], 1) + e["WRITE_SIZE"][0] / max(e["WRITE_SIZE"][1], 1)) * 1024.0,
                             "launches_in_pmc_run": e["FETCH_SIZE"][1]} for k, e in sorted(per.items())}
 if traffic:
+    traffic["_meta"] = {"source": "round %s, gpurun_out/%s -> profiles/%s/<configuration>/pmc_{FETCH,WRITE}_SIZE_per_kernel.csv" % (rnd, tag, rnd)}
     json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
