@@ -528,7 +528,9 @@ def main():
                "value": round(world * args.batch * steps / t_el, 1), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": 3,
                "ms_per_step": round(t_el / steps * 1e3, 4), "dtype": tag, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                "input_batches_in_rotation": NRING,
-               "parallelism": ("dp%d: RCCL all-reduce of the %s gradient vector in %d buckets (cut by finish time) on a side stream, overlapped with backward" % (world, "7.92 MB bf16" if args.grad_exchange == "bf16" else "15.84 MB fp32", len(teng.buckets)))
+               "parallelism": ("dp%d: RCCL all-reduce of the %s gradient vector in %d buckets (cut by finish time) on a side stream, overlapped with backward; collectives issued by %s" % (
+                   world, "7.92 MB bf16" if args.grad_exchange == "bf16" else "15.84 MB fp32", len(teng.buckets),
+                   "libfastdepth_hip.so itself (fd_train_backward_allreduce: one call per step, RCCL bound at run time)" if teng.comm is not None else "torch.distributed, one call per bucket"))
                               if teng.use_comm else "single GPU"}
         if teng.use_comm:        # how long the collectives take and how much of them backward hides (3 instrumented steps, synchronising)
             cs = []

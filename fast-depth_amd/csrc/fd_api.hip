@@ -591,7 +591,11 @@ int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch,
             }
             // 16-bit plans: 8 channels (16 bytes) per work-item and patches kept in the storage type -- a 64-channel block has the LDS footprint
             // (and the instruction count) of the 32-channel fp32 block; FD_TUNE_NO_DW_H8 keeps the 4-channel / fp32-patch form for A/B runs
-            const bool h8 = dtype != FD_F32 && d.cin % 8 == 0 && (!concat || L.csplit % 8 == 0) && !(tune & FD_TUNE_NO_DW_H8);
+            // Measured (fp16, batch 32, us, 8-channel vs 4-channel form): decode_conv5.0 46.5 vs 49.4, decode_conv4.0 28.3 vs 29.4 -- but decode_conv3.0
+            // 18.4 vs 16.7, decode_conv1.0 11.0 vs 7.8: half the workgroups only pays where many rounds of them remain, so the plan takes it for
+            // the 5x5 units on maps of >= 56 x 56 with whole 64-channel blocks (FD_TUNE_FORCE_DW_H8: wherever eligible -- tests)
+            const bool h8_ok = dtype != FD_F32 && d.cin % 8 == 0 && (!concat || L.csplit % 8 == 0) && !(tune & FD_TUNE_NO_DW_H8);
+            const bool h8 = h8_ok && ((tune & FD_TUNE_FORCE_DW_H8) || (d.ksize == 5 && d.cin % 64 == 0 && (long)L.out_h * L.out_w >= 56 * 56));
             L.dw_n = h8 ? 8 : 4;
             int cb = d.cin >= 32 ? 32 : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
             if (h8 && d.cin >= 64 && ceil_div(d.cin, 64) * 64 <= ceil_div(d.cin, 32) * 32) cb = 64;   // (pruned widths: the block size that pads the channel count least)

@@ -223,6 +223,20 @@ struct fd_px_walk {
 };
 __device__ __forceinline__ fd_f32x4 fd_zero4() { fd_f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
+// Element index of (image n, row y, column x, channel c) of an NHWC tensor [.][H][W][C].  The image part is wave-uniform (n comes from the
+// workgroup number: scalar unit); the within-image part fits 32 bits (the plans reject images of >= 2^32 elements) and its two multiplications are
+// 24 x 24 bit (y * W + x < 2^24, C < 2^24: v_mul_u32_u24, full rate).  The plain 64-bit expression cost 8 quarter-rate v_mul_lo_u32 / v_mad_u64_u32 per
+// staged pixel -- a quarter of the VALU instructions of the depthwise kernels, which PMC shows to be VALU-issue bound (71 % busy).
+#ifdef FD_EMU
+inline unsigned fd_mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }      // (masks as the hardware does: an overflow shows up in the CPU tier)
+#else
+__device__ __forceinline__ unsigned fd_mul24(unsigned a, unsigned b) { return __umul24(a, b); }
+#endif
+__device__ __forceinline__ long fd_nhwc(int n, int H, int y, int W, int x, int C, int c)
+{
+    return (long)n * H * W * C + (long)(fd_mul24(fd_mul24((unsigned)y, (unsigned)W) + (unsigned)x, (unsigned)C) + (unsigned)c);
+}
+
 // ---- lane vectors of the LDS-tiled depthwise kernels --------------------------------------------------------------------------------
 // A work-item of those kernels owns N consecutive channels of a pixel.  fd_lane<T, 4>: the round-1 form -- 4 channels, LDS patches kept in
 // fp32 (16 bytes per lane in LDS; 16 bytes per lane in memory only when T is float).  fd_lane<T, 8> (T a 16-bit storage type): 8 channels

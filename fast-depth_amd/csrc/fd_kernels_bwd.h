@@ -28,7 +28,7 @@
 #define FD_CF_MU 2
 #define FD_CF_C2 3
 __device__ __forceinline__ float fd_dz(float g, float z, float cA, float c1, float mu, float c2) { return cA * ((g - c1) - (z - mu) * c2); }
-__device__ __forceinline__ fd_f32x4 fd_dz4(fd_f32x4 g, fd_f32x4 z, fd_f32x4 cA, fd_f32x4 c1, fd_f32x4 mu, fd_f32x4 c2) { return cA * ((g - c1) - (z - mu) * c2); }
+template <typename V> __device__ __forceinline__ V fd_dz4(V g, V z, V cA, V c1, V mu, V c2) { return cA * ((g - c1) - (z - mu) * c2); }   // V: fd_f32x4 or fd_f32x8
 
 template <int ACT>
 __device__ __forceinline__ float fd_actmask(float y)
@@ -41,6 +41,14 @@ template <int ACT>
 __device__ __forceinline__ fd_f32x4 fd_actmask4(fd_f32x4 y)
 {
     fd_f32x4 r = {fd_actmask<ACT>(y.x), fd_actmask<ACT>(y.y), fd_actmask<ACT>(y.z), fd_actmask<ACT>(y.w)};
+    return r;
+}
+template <int ACT>
+__device__ __forceinline__ fd_f32x8 fd_actmask4(fd_f32x8 y)
+{
+    fd_f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = fd_actmask<ACT>(y[j]);
     return r;
 }
 
@@ -683,7 +691,7 @@ fd_pw_bwd_f32(const float *__restrict__ G, const float *__restrict__ Z, const fl
 // ------------------------------------------------------------------------------------------------
 // (body: bm = logical (tile, channel block, image) of this workgroup, grid_x = tiles per image -- the plain kernel passes fd_xcd_image_map() /
 // gridDim.x, the paired launch fd_dw_bwd its own numbering)
-template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N>
 __device__ __forceinline__ void
 fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
@@ -692,9 +700,12 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
+    typedef fd_lane<T, N> LN;
+    typedef typename LN::vec vec;
+    typedef typename LN::lds_t lds_t;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;
+    const int lanes_c = 1 << cbq, CB = lanes_c * N, PSTR = pstr;
     // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
     // (bm: all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2)
     const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
@@ -703,27 +714,27 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
     const int oyb = (iy0 + P - (K - 1) >= 0) ? (iy0 + P - (K - 1)) / S : -((-(iy0 + P - (K - 1)) + S - 1) / S);
     const int oxb = (ix0 + P - (K - 1) >= 0) ? (ix0 + P - (K - 1)) / S : -((-(ix0 + P - (K - 1)) + S - 1) / S);
     const int PH = (iy0 + TH - 1 + P) / S - oyb + 1, PW = (ix0 + TW - 1 + P) / S - oxb + 1;
-    float *s_dz = smem;                                   // [PH*PW][PSTR]
-    float *s_w = smem + PH * PW * PSTR;                   // [K*K][CB]
+    lds_t *s_dz = reinterpret_cast<lds_t *>(smem_raw);    // [PH*PW][PSTR]  (N = 8: dz rounded to the storage type, as fd_bn_bwd_apply_h16 does for the GEMMs)
+    float *s_w = reinterpret_cast<float *>(smem_raw + fd_lds_patch_bytes<lds_t>(PH * PW, PSTR));   // [K*K][CB]
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
-    const int cg = c0 + c4 * 4;
+    const int cg = c0 + c4 * N;
     const bool c_ok = cg < C;
     // the taps of this channel block (w[c][tap] -> s_w[tap][c]): requested now, written to LDS after the patch loads have been issued, so that the two
     // global round trips overlap instead of following each other (a workgroup's life is a chain of such latencies, not arithmetic)
-    constexpr int NWREG = (K * K * 32 + 255) / 256;
+    constexpr int NWREG = (K * K * 8 * N + 255) / 256;     // CB <= 8 * N channels
     float wreg[NWREG];
 #pragma unroll
     for (int j = 0; j < NWREG; ++j) {
         const int i = tid + 256 * j, t = i / CB, cc = i - t * CB;
         wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
-    fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
-    if (c_ok) { cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg); }
+    vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
+    if (c_ok) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = 8;
     fd_px_walk wk(pt, npt, PW);
     for (int base = pt; base < npx; base += npt * U) {
-        fd_f32x4 g[U], z[U];
+        vec g[U], z[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -734,14 +745,14 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             ok[u] = px < npx && c_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
             {   // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
                 const int qy = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), qx = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
-                const long o = (((long)n * Ho + qy) * Wo + qx) * C + (c_ok ? cg : 0);
-                g[u] = fd_ld4(G + o); z[u] = fd_ld4(Z + o);
+                const long o = fd_nhwc(n, Ho, qy, Wo, qx, C, (c_ok ? cg : 0));
+                g[u] = LN::ld(G + o); z[u] = LN::ld(Z + o);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            if (px < npx) fd_st4(s_dz + px * PSTR + c4 * 4, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : fd_zero4());
+            if (px < npx) LN::lds_st(s_dz + px * PSTR + c4 * N, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : LN::zero());
         }
     }
 #pragma unroll
@@ -753,11 +764,11 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
     // into its skip-gradient buffer, masked later by the skip source's own consumer)
     const bool to_skip = MODE == 3 && cg >= csplit;
     const int Cp = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = to_skip ? cg - csplit : cg;
-    fd_f32x4 sc = fd_zero4(), sh = fd_zero4(), mu = fd_zero4(), is = fd_zero4();
-    if (c_ok && !to_skip) { sc = fd_ld4(st_in + FD_ST_SCALE * Cp + cg); sh = fd_ld4(st_in + FD_ST_SHIFT * Cp + cg); mu = fd_ld4(st_in + FD_ST_MEAN * Cp + cg); is = fd_ld4(st_in + FD_ST_INVSTD * Cp + cg); }
-    fd_f32x4 ssum = fd_zero4(), ssx = fd_zero4();
+    vec sc = LN::zero(), sh = LN::zero(), mu = LN::zero(), is = LN::zero();
+    if (c_ok && !to_skip) { sc = LN::ldf(st_in + FD_ST_SCALE * Cp + cg); sh = LN::ldf(st_in + FD_ST_SHIFT * Cp + cg); mu = LN::ldf(st_in + FD_ST_MEAN * Cp + cg); is = LN::ldf(st_in + FD_ST_INVSTD * Cp + cg); }
+    vec ssum = LN::zero(), ssx = LN::zero();
     auto din_at = [&](int iy, int ix) {                    // gradient w.r.t. the conv input at tile-local (iy, ix)
-        fd_f32x4 acc = fd_zero4();
+        vec acc = LN::zero();
         const int gy = iy0 + iy, gx = ix0 + ix;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
@@ -769,7 +780,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
                 const int nx = gx + P - kx;
                 if (S == 2 && (nx & 1)) continue;
                 const int pxx = (S == 2 ? (nx >> 1) : nx) - oxb;
-                acc += fd_ld4(s_dz + (py * PW + pxx) * PSTR + c4 * 4) * fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+                acc += LN::lds_ld(s_dz + (py * PW + pxx) * PSTR + c4 * N) * LN::ldf(s_w + (ky * K + kx) * CB + c4 * N);
             }
         }
         return acc;
@@ -782,24 +793,24 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             const int iy = st / TWS, ix = (st - iy * TWS) * 4;
             const int gy = iy0 + iy;
             if (!c_ok || gy >= Hin) continue;
-            fd_f32x4 z[4], sgv[4];
+            vec z[4], sgv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                      // requested before the tap loop; clamped column, validity re-checked at the store
                 const int gx = ix0 + ix + j, qx = gx < Win ? gx : Win - 1;
-                const long o = (((long)n * Hin + gy) * Win + qx) * C + cg;
-                z[j] = fd_ld4(Zin + o);
-                sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
+                const long o = fd_nhwc(n, Hin, gy, Win, qx, C, cg);
+                z[j] = LN::ld(Zin + o);
+                sgv[j] = ADD_SG ? LN::ld(SG + o) : LN::zero();
             }
-            fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
+            vec acc[4] = {LN::zero(), LN::zero(), LN::zero(), LN::zero()};
 #pragma unroll UNR_TAPROWS
             for (int a = 0; a < K; ++a) {
-                const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
-                fd_f32x4 r[K + 3];
+                const lds_t *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * N;
+                vec r[K + 3];
 #pragma unroll
-                for (int i = 0; i < K + 3; ++i) r[i] = fd_ld4(row + i * PSTR);
+                for (int i = 0; i < K + 3; ++i) r[i] = LN::lds_ld(row + i * PSTR);
 #pragma unroll
                 for (int b = 0; b < K; ++b) {
-                    const fd_f32x4 wv = fd_ld4(s_w + ((K - 1 - a) * K + (K - 1 - b)) * CB + c4 * 4);
+                    const vec wv = LN::ldf(s_w + ((K - 1 - a) * K + (K - 1 - b)) * CB + c4 * N);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] += r[j + b] * wv;
                 }
@@ -808,11 +819,11 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             for (int j = 0; j < 4; ++j) {
                 const int gx = ix0 + ix + j;
                 if (gx >= Win) continue;
-                const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
-                fd_f32x4 v = acc[j];
+                const long o = fd_nhwc(n, Hin, gy, Win, gx, C, cg);
+                vec v = acc[j];
                 if (ADD_SG) v += sgv[j];
-                v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z[j] * sc + sh));
-                fd_st4(Gin + o, v);
+                v = LN::round(v * fd_actmask4<ACT_IN>(z[j] * sc + sh));
+                LN::st(Gin + o, v);
                 ssum += v; ssx += v * ((z[j] - mu) * is);
             }
         }
@@ -821,14 +832,14 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             const int iy = p / TW, ix = p - iy * TW;
             const int gy = iy0 + iy, gx = ix0 + ix;
             if (!c_ok || gy >= Hin || gx >= Win) continue;
-            const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
-            const fd_f32x4 z = fd_ld4(Zin + o);                 // requested before the tap loop: the latency hides behind the LDS work
-            fd_f32x4 sgv = fd_zero4();
-            if (ADD_SG) sgv = fd_ld4(SG + o);
-            fd_f32x4 v = din_at(iy, ix);
+            const long o = fd_nhwc(n, Hin, gy, Win, gx, C, cg);
+            const vec z = LN::ld(Zin + o);                 // requested before the tap loop: the latency hides behind the LDS work
+            vec sgv = LN::zero();
+            if (ADD_SG) sgv = LN::ld(SG + o);
+            vec v = din_at(iy, ix);
             if (ADD_SG) v += sgv;
-            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
-            fd_st4(Gin + o, v);
+            v = LN::round(v * fd_actmask4<ACT_IN>(z * sc + sh));
+            LN::st(Gin + o, v);
             ssum += v; ssx += v * ((z - mu) * is);
         }
     } else {
@@ -837,63 +848,63 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             const int ly = p / TW2, lx = p - ly * TW2;
             const int gy = iy0 + 2 * ly, gx = ix0 + 2 * lx;     // top-left full-res position of the 2x2 block
             if (!c_ok || gy >= Hin || gx >= Win) continue;
-            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * Cp + (to_skip ? 0 : cg);
-            const fd_f32x4 z = fd_ld4(Zin + ol);                // requested before the tap loop (unused by the lanes that feed the skip tensor)
-            fd_f32x4 d00, d01, d10, d11;
+            const long ol = fd_nhwc(n, Hs, (gy >> 1), Ws, (gx >> 1), Cp, (to_skip ? 0 : cg));
+            const vec z = LN::ld(Zin + ol);                // requested before the tap loop (unused by the lanes that feed the skip tensor)
+            vec d00, d01, d10, d11;
             if (S == 1) {
                 // the four positions of the block read a (K+1) x (K+1) window of the dz patch: walk it row by row, every row feeds
                 // the block's upper row with tap row ky = K-1-r and its lower row with ky = K-r (one pass over LDS, few registers)
-                d00 = fd_zero4(); d01 = fd_zero4(); d10 = fd_zero4(); d11 = fd_zero4();
+                d00 = LN::zero(); d01 = LN::zero(); d10 = LN::zero(); d11 = LN::zero();
                 const int pyb = gy + P - (K - 1) - oyb, pxb = gx + P - (K - 1) - oxb;
 #pragma unroll 1
                 for (int r = 0; r <= K; ++r) {
-                    fd_f32x4 v[K + 1];
-                    const float *row = s_dz + ((pyb + r) * PW + pxb) * PSTR + c4 * 4;
+                    vec v[K + 1];
+                    const lds_t *row = s_dz + ((pyb + r) * PW + pxb) * PSTR + c4 * N;
 #pragma unroll
-                    for (int c = 0; c <= K; ++c) v[c] = fd_ld4(row + c * PSTR);
+                    for (int c = 0; c <= K; ++c) v[c] = LN::lds_ld(row + c * PSTR);
                     if (r < K) {
-                        const float *wr = s_w + (K - 1 - r) * K * CB + c4 * 4;
+                        const float *wr = s_w + (K - 1 - r) * K * CB + c4 * N;
 #pragma unroll
-                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d00 += v[K - 1 - kx] * wv; d01 += v[K - kx] * wv; }
+                        for (int kx = 0; kx < K; ++kx) { const vec wv = LN::ldf(wr + kx * CB); d00 += v[K - 1 - kx] * wv; d01 += v[K - kx] * wv; }
                     }
                     if (r > 0) {
-                        const float *wr = s_w + (K - r) * K * CB + c4 * 4;
+                        const float *wr = s_w + (K - r) * K * CB + c4 * N;
 #pragma unroll
-                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d10 += v[K - 1 - kx] * wv; d11 += v[K - kx] * wv; }
+                        for (int kx = 0; kx < K; ++kx) { const vec wv = LN::ldf(wr + kx * CB); d10 += v[K - 1 - kx] * wv; d11 += v[K - kx] * wv; }
                     }
                 }
             } else {
                 d00 = din_at(2 * ly, 2 * lx); d01 = din_at(2 * ly, 2 * lx + 1); d10 = din_at(2 * ly + 1, 2 * lx); d11 = din_at(2 * ly + 1, 2 * lx + 1);
             }
             if (MODE == 2 || to_skip) {
-                const long o = (((long)n * Hin + gy) * Win + gx) * C2 + cl;
-                fd_st4(SGout + o, d00); fd_st4(SGout + o + C2, d01);
-                fd_st4(SGout + o + (long)Win * C2, d10); fd_st4(SGout + o + (long)Win * C2 + C2, d11);
+                const long o = fd_nhwc(n, Hin, gy, Win, gx, C2, cl);
+                LN::st(SGout + o, d00); LN::st(SGout + o + C2, d01);
+                LN::st(SGout + o + (long)Win * C2, d10); LN::st(SGout + o + (long)Win * C2 + C2, d11);
                 if (to_skip) continue;
             }
-            fd_f32x4 v = (d00 + d01) + (d10 + d11);
-            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
-            fd_st4(Gin + ol, v);
+            vec v = (d00 + d01) + (d10 + d11);
+            v = LN::round(v * fd_actmask4<ACT_IN>(z * sc + sh));
+            LN::st(Gin + ol, v);
             ssum += v; ssx += v * ((z - mu) * is);
         }
     }
     float *red = smem;
     if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
         const long blk = (long)bm.z * grid_x + bm.x;
-        if (c0 + tid * 4 < Cp) {
-            fd_st4(part + blk * 2 * Cp + c0 + tid * 4, ssum);
-            fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, ssx);
+        if (c0 + tid * N < Cp) {
+            LN::stf(part + blk * 2 * Cp + c0 + tid * N, ssum);
+            LN::stf(part + blk * 2 * Cp + Cp + c0 + tid * N, ssx);
         }
     }
 }
-template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N>
 __global__ void __launch_bounds__(256)
 fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr)
 {
-    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit, pstr,
+    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG, N>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit, pstr,
                                                     fd_xcd_image_map(), (int)gridDim.x);
 }
 
@@ -904,7 +915,7 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
 // outputs is staged next to it.  A work-item then owns ONE tap row of 4 channels and walks a share of the output strips; the
 // shares are summed through LDS once per workgroup, which writes wpart[blk][K*K][C].
 // ------------------------------------------------------------------------------------------------
-template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N>
 __device__ __forceinline__ void
 fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
@@ -913,12 +924,15 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
+    typedef fd_lane<T, N> LN;
+    typedef typename LN::vec vec;
+    typedef typename LN::lds_t lds_t;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;
+    const int lanes_c = 1 << cbq, CB = lanes_c * N, PSTR = pstr;
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
-    float *s_in = smem;                                    // [TH_in*TW_in][PSTR] activated input patch; reused for the final reduction
-    float *s_dz = smem + TH_in * TW_in * PSTR;             // [TH*TW][PSTR]       dz of the tile's outputs (0 outside the image)
+    lds_t *s_in = reinterpret_cast<lds_t *>(smem_raw);     // [TH_in*TW_in][PSTR] activated input patch; reused for the final reduction
+    lds_t *s_dz = s_in + TH_in * TW_in * PSTR;             // [TH*TW][PSTR]       dz of the tile's outputs (0 outside the image)
     // a workgroup walks `tpw` horizontally adjacent tiles and keeps its tap sums in registers across them: one workgroup
     // reduction and one partial row per `tpw` tiles
     const int groups_x = (tiles_x + tpw - 1) / tpw;
@@ -927,7 +941,7 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     const int oy0 = ty * TH;
     const int iy0 = oy0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
-    const int cg = c0 + c4 * 4;
+    const int cg = c0 + c4 * N;
     const bool c_ok = cg < C;
     int tab_c = c_ok ? cg : 0;                             // channel offset of this work-item's table entries (re-read per tile, see FD_OPAQUE)
     const bool from_skip = MODE == 3 && cg >= csplit;      // MODE 3: cat(up2(a_in), a_skip), see fd_dwconv_train
@@ -938,9 +952,9 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     const int ngroups = npt / K;
     const int ky = pt % K, pg = pt / K;
     const bool worker = pg < ngroups;
-    fd_f32x4 acc[K];
+    vec acc[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) acc[t] = fd_zero4();
+    for (int t = 0; t < K; ++t) acc[t] = LN::zero();
 #pragma unroll 1
     for (int ti = 0; ti < tpw; ++ti) {
     const int tx = tgx * tpw + ti;
@@ -951,7 +965,7 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     // so that their latency overlaps the staging loads instead of following the barrier
     const int TWS = TW >> 2, nstrips = TH * TWS;
     constexpr bool PREFETCH = true;
-    decltype(fd_ldraw4(G)) g0[4], z0[4];
+    typename LN::raw g0[4], z0[4];
     {
         const int oy = pt / TWS, ox = (pt - oy * TWS) * 4;
 #pragma unroll
@@ -959,23 +973,23 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
             const int gy = oy0 + oy, gx = ox0 + ox + j;
             if (PREFETCH) {                                   // branch-free: clamped address, validity is re-checked where the value is used
                 const int qy = gy < Ho ? gy : Ho - 1, qx = gx < Wo ? gx : Wo - 1;
-                const long o = (((long)n * Ho + qy) * Wo + qx) * C + (c_ok ? cg : 0);
-                g0[j] = fd_ldraw4(G + o); z0[j] = fd_ldraw4(Z + o);
+                const long o = fd_nhwc(n, Ho, qy, Wo, qx, C, (c_ok ? cg : 0));
+                g0[j] = LN::ldraw(G + o); z0[j] = LN::ldraw(Z + o);
             }
         }
     }
     FD_OPAQUE(tab_c);
     int tab_l = c_ok ? cl : 0;
     FD_OPAQUE(tab_l);
-    fd_f32x4 s1, t1, s2 = fd_zero4(), t2 = fd_zero4();
-    if (from_skip) { s1 = fd_ld4(st2 + FD_ST_SCALE * C2 + tab_l); t1 = fd_ld4(st2 + FD_ST_SHIFT * C2 + tab_l); }
-    else { s1 = fd_ld4(st1 + FD_ST_SCALE * C1 + tab_l); t1 = fd_ld4(st1 + FD_ST_SHIFT * C1 + tab_l); }
-    if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + tab_c); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + tab_c); }
+    vec s1, t1, s2 = LN::zero(), t2 = LN::zero();
+    if (from_skip) { s1 = LN::ldf(st2 + FD_ST_SCALE * C2 + tab_l); t1 = LN::ldf(st2 + FD_ST_SHIFT * C2 + tab_l); }
+    else { s1 = LN::ldf(st1 + FD_ST_SCALE * C1 + tab_l); t1 = LN::ldf(st1 + FD_ST_SHIFT * C1 + tab_l); }
+    if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + tab_c); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
     constexpr int U = 4;
     fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
-        fd_f32x4 v[U], sk[U];
+        vec v[U], sk[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -983,44 +997,44 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
             const int iy = wk.iy, ix = wk.ix;
             wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
-            sk[u] = fd_zero4();
+            sk[u] = LN::zero();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
             // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
             const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
             const int ql = c_ok ? cl : 0, qg = c_ok ? cg : 0;
             if (MODE == 0) {
-                v[u] = fd_ld4(zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                v[u] = LN::ld(zin + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             } else {
                 const int Hs = Hin >> 1, Ws = Win >> 1;
-                if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C2 + ql);
-                else v[u] = fd_ld4(zin + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C1 + ql);
-                if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                if (from_skip) v[u] = LN::ld(zskip + fd_nhwc(n, Hin, qy, Win, qx, C2, ql));
+                else v[u] = LN::ld(zin + fd_nhwc(n, Hs, (qy >> 1), Ws, (qx >> 1), C1, ql));
+                if (MODE == 2) sk[u] = LN::ld(zskip + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
             if (px < npx_in) {
-                fd_f32x4 a = fd_zero4();
+                vec a = LN::zero();
                 if (ok[u]) {
                     a = from_skip ? fd_bn_act4<ACT2>(v[u], s1, t1) : fd_bn_act4<ACT1>(v[u], s1, t1);
                     if (MODE == 2) a += fd_bn_act4<ACT2>(sk[u], s2, t2);
                 }
-                fd_st4(s_in + px * PSTR + c4 * 4, a);
+                LN::lds_st(s_in + px * PSTR + c4 * N, a);
             }
         }
     }
     // dz of this work-item's output strip (pixel-thread pt stages strip pt: TH*TW/4 <= npt) -> s_dz
     FD_OPAQUE(tab_c);
     {
-        const fd_f32x4 cA = fd_ld4(coef + FD_CF_A * C + tab_c), c1 = fd_ld4(coef + FD_CF_C1 * C + tab_c), cM = fd_ld4(coef + FD_CF_MU * C + tab_c), c2 = fd_ld4(coef + FD_CF_C2 * C + tab_c);
+        const vec cA = LN::ldf(coef + FD_CF_A * C + tab_c), c1 = LN::ldf(coef + FD_CF_C1 * C + tab_c), cM = LN::ldf(coef + FD_CF_MU * C + tab_c), c2 = LN::ldf(coef + FD_CF_C2 * C + tab_c);
         if (pt < nstrips) {
             const int oy = pt / TWS, ox = (pt - oy * TWS) * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = c_ok && oy0 + oy < Ho && ox0 + ox + j < Wo;
-                const fd_f32x4 dz = fd_dz4(fd_cvt4(T{}, g0[j]), fd_cvt4(T{}, z0[j]), cA, c1, cM, c2);
-                fd_st4(s_dz + (oy * TW + ox + j) * PSTR + c4 * 4, ok ? dz : fd_zero4());
+                const vec dz = fd_dz4(LN::cvt(g0[j]), LN::cvt(z0[j]), cA, c1, cM, c2);
+                LN::lds_st(s_dz + (oy * TW + ox + j) * PSTR + c4 * N, ok ? dz : LN::zero());
             }
         }
     }
@@ -1028,13 +1042,13 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     if (worker) {
         for (int s = pg; s < nstrips; s += ngroups) {
             const int oy = s / TWS, ox = (s - oy * TWS) * 4;
-            const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
-            const float *dzp = s_dz + (oy * TW + ox) * PSTR + c4 * 4;
-            fd_f32x4 r[NIN], dz[4];
+            const lds_t *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * N;
+            const lds_t *dzp = s_dz + (oy * TW + ox) * PSTR + c4 * N;
+            vec r[NIN], dz[4];
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+            for (int i = 0; i < NIN; ++i) r[i] = LN::lds_ld(row + i * PSTR);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dz[j] = fd_ld4(dzp + j * PSTR);
+            for (int j = 0; j < 4; ++j) dz[j] = LN::lds_ld(dzp + j * PSTR);
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
 #pragma unroll
@@ -1047,27 +1061,27 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     float *red = smem;
     if (worker) {
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) fd_st4(red + ((pg * K * K + ky * K + kx) * lanes_c + c4) * 4, acc[kx]);
+        for (int kx = 0; kx < K; ++kx) LN::stf(red + ((pg * K * K + ky * K + kx) * lanes_c + c4) * N, acc[kx]);
     }
     __syncthreads();
     const long blk = (long)bm.z * grid_x + bm.x;
     for (int i = tid; i < K * K * lanes_c; i += 256) {
         const int t = i >> cbq, cc = i & (lanes_c - 1);
-        if (c0 + cc * 4 < C) {
-            fd_f32x4 a = fd_zero4();
-            for (int g = 0; g < ngroups; ++g) a += fd_ld4(red + ((g * K * K + t) * lanes_c + cc) * 4);
-            fd_st4(wpart + (blk * K * K + t) * C + c0 + cc * 4, a);
+        if (c0 + cc * N < C) {
+            vec a = LN::zero();
+            for (int g = 0; g < ngroups; ++g) a += LN::ldf(red + ((g * K * K + t) * lanes_c + cc) * N);
+            LN::stf(wpart + (blk * K * K + t) * C + c0 + cc * N, a);
         }
     }
 }
-template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N>
 __global__ void __launch_bounds__(256)
 fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
                 int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, int pstr)
 {
-    fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(zin, st1, zskip, st2, G, Z, coef, wpart, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, tpw, csplit, pstr,
+    fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2, N>(zin, st1, zskip, st2, G, Z, coef, wpart, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, tpw, csplit, pstr,
                                                 fd_xcd_image_map(), (int)gridDim.x);
 }
 
@@ -1102,7 +1116,7 @@ template <typename T> struct fd_dw_bwd_args {
     int w_th, w_tw, w_tiles_x, w_tpw, w_gx, w_gy;      // backward-weights: OUTPUT-space tiles, tpw of them per workgroup
     int B;
 };
-template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG, int N>
 __global__ void __launch_bounds__(256)
 fd_dw_bwd(const fd_dw_bwd_args<T> a)
 {
@@ -1110,16 +1124,16 @@ fd_dw_bwd(const fd_dw_bwd_args<T> a)
     fd_blk3 bm = pb.b;
     if (pb.role == 0) {
         bm.y = bm.x / a.d_gx; bm.x -= bm.y * a.d_gx;
-        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG, N>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
                                                       a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, bm, a.d_gx);
     } else {
         bm.y = bm.x / a.w_gx; bm.x -= bm.y * a.w_gx;
-        fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+        fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2, N>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
                                                     a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, a.pstr, bm, a.w_gx);
     }
 }
 
-template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, int N>
 __device__ __forceinline__ void
 fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
@@ -1129,9 +1143,12 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
+    typedef fd_lane<T, N> LN;
+    typedef typename LN::vec vec;
+    typedef typename LN::lds_t lds_t;
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;
+    const int lanes_c = 1 << cbq, CB = lanes_c * N, PSTR = pstr;
     // output (dz) positions that can touch input rows [iy0, iy0+TH): oy in [floor((iy0+P-(K-1))/S) .. floor((iy0+TH-1+P)/S)]
     // (bm: all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2)
     const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
@@ -1144,28 +1161,28 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
     const int OTH = TH / S, OTW = TW / S, oy0 = iy0 / S, ox0 = ix0 / S;
     const int TH_in = (OTH - 1) * S + K, TW_in = (OTW - 1) * S + K;
     const int jy0 = oy0 * S - P, jx0 = ox0 * S - P;       // input position of patch pixel (0, 0)
-    float *s_dz = smem;                                   // [PH*PW][PSTR]        dz of every output that touches the tile (0 outside the image)
-    float *s_in = smem + PH * PW * PSTR;                  // [TH_in*TW_in][PSTR]  the activated forward input under the owned outputs (0 = padding)
-    float *s_w = s_in + TH_in * TW_in * PSTR;             // [K*K][CB]
+    lds_t *s_dz = reinterpret_cast<lds_t *>(smem_raw);    // [PH*PW][PSTR]        dz of every output that touches the tile (0 outside the image)
+    lds_t *s_in = s_dz + PH * PW * PSTR;                  // [TH_in*TW_in][PSTR]  the activated forward input under the owned outputs (0 = padding)
+    float *s_w = reinterpret_cast<float *>(smem_raw + fd_lds_patch_bytes<lds_t>(PH * PW + TH_in * TW_in, PSTR));   // [K*K][CB]
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
-    const int cg = c0 + c4 * 4;
+    const int cg = c0 + c4 * N;
     const bool c_ok = cg < C;
     // the taps of this channel block (w[c][tap] -> s_w[tap][c]): requested now, written to LDS after the patch loads have been issued, so that the two
     // global round trips overlap instead of following each other (a workgroup's life is a chain of such latencies, not arithmetic)
-    constexpr int NWREG = (K * K * 32 + 255) / 256;
+    constexpr int NWREG = (K * K * 8 * N + 255) / 256;     // CB <= 8 * N channels
     float wreg[NWREG];
 #pragma unroll
     for (int j = 0; j < NWREG; ++j) {
         const int i = tid + 256 * j, t = i / CB, cc = i - t * CB;
         wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
-    fd_f32x4 cA = fd_zero4(), c1 = fd_zero4(), cM = fd_zero4(), c2 = fd_zero4();
-    if (c_ok) { cA = fd_ld4(coef + FD_CF_A * C + cg); c1 = fd_ld4(coef + FD_CF_C1 * C + cg); cM = fd_ld4(coef + FD_CF_MU * C + cg); c2 = fd_ld4(coef + FD_CF_C2 * C + cg); }
+    vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
+    if (c_ok) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = 8;
     fd_px_walk wk(pt, npt, PW);
     for (int base = pt; base < npx; base += npt * U) {
-        fd_f32x4 g[U], z[U];
+        vec g[U], z[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1176,30 +1193,30 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
             ok[u] = px < npx && c_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
             {   // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
                 const int qy = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), qx = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
-                const long o = (((long)n * Ho + qy) * Wo + qx) * C + (c_ok ? cg : 0);
-                g[u] = fd_ld4(G + o); z[u] = fd_ld4(Z + o);
+                const long o = fd_nhwc(n, Ho, qy, Wo, qx, C, (c_ok ? cg : 0));
+                g[u] = LN::ld(G + o); z[u] = LN::ld(Z + o);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            if (px < npx) fd_st4(s_dz + px * PSTR + c4 * 4, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : fd_zero4());
+            if (px < npx) LN::lds_st(s_dz + px * PSTR + c4 * N, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : LN::zero());
         }
     }
     {   // ---- the forward input patch, re-created on load as in fd_dwconv_train: act(z_in * s + t), nearest x2, + / cat skip ----
         const bool from_skip = MODE == 3 && cg >= csplit;
         const int C1w = MODE == 3 ? csplit : C, C2w = MODE == 3 ? C - csplit : C, clw = from_skip ? cg - csplit : cg;
-        fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
+        vec s1 = LN::zero(), t1 = LN::zero(), s2 = LN::zero(), t2 = LN::zero();
         if (c_ok) {
-            if (from_skip) { s1 = fd_ld4(st_skip + FD_ST_SCALE * C2w + clw); t1 = fd_ld4(st_skip + FD_ST_SHIFT * C2w + clw); }
-            else { s1 = fd_ld4(st_in + FD_ST_SCALE * C1w + clw); t1 = fd_ld4(st_in + FD_ST_SHIFT * C1w + clw); }
-            if (MODE == 2) { s2 = fd_ld4(st_skip + FD_ST_SCALE * C + cg); t2 = fd_ld4(st_skip + FD_ST_SHIFT * C + cg); }
+            if (from_skip) { s1 = LN::ldf(st_skip + FD_ST_SCALE * C2w + clw); t1 = LN::ldf(st_skip + FD_ST_SHIFT * C2w + clw); }
+            else { s1 = LN::ldf(st_in + FD_ST_SCALE * C1w + clw); t1 = LN::ldf(st_in + FD_ST_SHIFT * C1w + clw); }
+            if (MODE == 2) { s2 = LN::ldf(st_skip + FD_ST_SCALE * C + cg); t2 = LN::ldf(st_skip + FD_ST_SHIFT * C + cg); }
         }
         const int npx_in = TH_in * TW_in;
         constexpr int UI = 4;
         fd_px_walk wi(pt, npt, TW_in);
         for (int base = pt; base < npx_in; base += npt * UI) {
-            fd_f32x4 v[UI], sk[UI];
+            vec v[UI], sk[UI];
             bool oki[UI];
 #pragma unroll
             for (int u = 0; u < UI; ++u) {
@@ -1207,29 +1224,29 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
                 const int iy = wi.iy, ix = wi.ix;
                 wi.next();
                 const int gy = jy0 + iy, gx = jx0 + ix;
-                sk[u] = fd_zero4();
+                sk[u] = LN::zero();
                 oki[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
                 const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
                 const int ql = c_ok ? clw : 0, qg = c_ok ? cg : 0;
                 if (MODE == 0) {
-                    v[u] = fd_ld4(Zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                    v[u] = LN::ld(Zin + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
                 } else {
                     const int Hs = Hin >> 1, Ws = Win >> 1;
-                    if (from_skip) v[u] = fd_ld4(Zskip + (((long)n * Hin + qy) * Win + qx) * C2w + ql);
-                    else v[u] = fd_ld4(Zin + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C1w + ql);
-                    if (MODE == 2) sk[u] = fd_ld4(Zskip + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                    if (from_skip) v[u] = LN::ld(Zskip + fd_nhwc(n, Hin, qy, Win, qx, C2w, ql));
+                    else v[u] = LN::ld(Zin + fd_nhwc(n, Hs, (qy >> 1), Ws, (qx >> 1), C1w, ql));
+                    if (MODE == 2) sk[u] = LN::ld(Zskip + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
                 }
             }
 #pragma unroll
             for (int u = 0; u < UI; ++u) {
                 const int px = base + u * npt;
                 if (px < npx_in) {
-                    fd_f32x4 av = fd_zero4();
+                    vec av = LN::zero();
                     if (oki[u]) {
                         av = from_skip ? fd_bn_act4<ACT2>(v[u], s1, t1) : fd_bn_act4<ACT_IN>(v[u], s1, t1);
                         if (MODE == 2) av += fd_bn_act4<ACT2>(sk[u], s2, t2);
                     }
-                    fd_st4(s_in + px * PSTR + c4 * 4, av);
+                    LN::lds_st(s_in + px * PSTR + c4 * N, av);
                 }
             }
         }
@@ -1243,11 +1260,11 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
     // into its skip-gradient buffer, masked later by the skip source's own consumer)
     const bool to_skip = MODE == 3 && cg >= csplit;
     const int Cp = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = to_skip ? cg - csplit : cg;
-    fd_f32x4 sc = fd_zero4(), sh = fd_zero4(), mu = fd_zero4(), is = fd_zero4();
-    if (c_ok && !to_skip) { sc = fd_ld4(st_in + FD_ST_SCALE * Cp + cg); sh = fd_ld4(st_in + FD_ST_SHIFT * Cp + cg); mu = fd_ld4(st_in + FD_ST_MEAN * Cp + cg); is = fd_ld4(st_in + FD_ST_INVSTD * Cp + cg); }
-    fd_f32x4 ssum = fd_zero4(), ssx = fd_zero4();
+    vec sc = LN::zero(), sh = LN::zero(), mu = LN::zero(), is = LN::zero();
+    if (c_ok && !to_skip) { sc = LN::ldf(st_in + FD_ST_SCALE * Cp + cg); sh = LN::ldf(st_in + FD_ST_SHIFT * Cp + cg); mu = LN::ldf(st_in + FD_ST_MEAN * Cp + cg); is = LN::ldf(st_in + FD_ST_INVSTD * Cp + cg); }
+    vec ssum = LN::zero(), ssx = LN::zero();
     auto din_at = [&](int iy, int ix) {                    // gradient w.r.t. the conv input at tile-local (iy, ix)
-        fd_f32x4 acc = fd_zero4();
+        vec acc = LN::zero();
         const int gy = iy0 + iy, gx = ix0 + ix;
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
@@ -1259,7 +1276,7 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
                 const int nx = gx + P - kx;
                 if (S == 2 && (nx & 1)) continue;
                 const int pxx = (S == 2 ? (nx >> 1) : nx) - oxb;
-                acc += fd_ld4(s_dz + (py * PW + pxx) * PSTR + c4 * 4) * fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+                acc += LN::lds_ld(s_dz + (py * PW + pxx) * PSTR + c4 * N) * LN::ldf(s_w + (ky * K + kx) * CB + c4 * N);
             }
         }
         return acc;
@@ -1272,24 +1289,24 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
             const int iy = st / TWS, ix = (st - iy * TWS) * 4;
             const int gy = iy0 + iy;
             if (!c_ok || gy >= Hin) continue;
-            fd_f32x4 z[4], sgv[4];
+            vec z[4], sgv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                      // requested before the tap loop; clamped column, validity re-checked at the store
                 const int gx = ix0 + ix + j, qx = gx < Win ? gx : Win - 1;
-                const long o = (((long)n * Hin + gy) * Win + qx) * C + cg;
-                z[j] = fd_ld4(Zin + o);
-                sgv[j] = ADD_SG ? fd_ld4(SG + o) : fd_zero4();
+                const long o = fd_nhwc(n, Hin, gy, Win, qx, C, cg);
+                z[j] = LN::ld(Zin + o);
+                sgv[j] = ADD_SG ? LN::ld(SG + o) : LN::zero();
             }
-            fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
+            vec acc[4] = {LN::zero(), LN::zero(), LN::zero(), LN::zero()};
 #pragma unroll UNR_TAPROWS
             for (int a = 0; a < K; ++a) {
-                const float *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * 4;
-                fd_f32x4 r[K + 3];
+                const lds_t *row = s_dz + ((iy + a) * PW + ix) * PSTR + c4 * N;
+                vec r[K + 3];
 #pragma unroll
-                for (int i = 0; i < K + 3; ++i) r[i] = fd_ld4(row + i * PSTR);
+                for (int i = 0; i < K + 3; ++i) r[i] = LN::lds_ld(row + i * PSTR);
 #pragma unroll
                 for (int b = 0; b < K; ++b) {
-                    const fd_f32x4 wv = fd_ld4(s_w + ((K - 1 - a) * K + (K - 1 - b)) * CB + c4 * 4);
+                    const vec wv = LN::ldf(s_w + ((K - 1 - a) * K + (K - 1 - b)) * CB + c4 * N);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] += r[j + b] * wv;
                 }
@@ -1298,11 +1315,11 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
             for (int j = 0; j < 4; ++j) {
                 const int gx = ix0 + ix + j;
                 if (gx >= Win) continue;
-                const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
-                fd_f32x4 v = acc[j];
+                const long o = fd_nhwc(n, Hin, gy, Win, gx, C, cg);
+                vec v = acc[j];
                 if (ADD_SG) v += sgv[j];
-                v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z[j] * sc + sh));
-                fd_st4(Gin + o, v);
+                v = LN::round(v * fd_actmask4<ACT_IN>(z[j] * sc + sh));
+                LN::st(Gin + o, v);
                 ssum += v; ssx += v * ((z[j] - mu) * is);
             }
         }
@@ -1311,14 +1328,14 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
             const int iy = p / TW, ix = p - iy * TW;
             const int gy = iy0 + iy, gx = ix0 + ix;
             if (!c_ok || gy >= Hin || gx >= Win) continue;
-            const long o = (((long)n * Hin + gy) * Win + gx) * C + cg;
-            const fd_f32x4 z = fd_ld4(Zin + o);                 // requested before the tap loop: the latency hides behind the LDS work
-            fd_f32x4 sgv = fd_zero4();
-            if (ADD_SG) sgv = fd_ld4(SG + o);
-            fd_f32x4 v = din_at(iy, ix);
+            const long o = fd_nhwc(n, Hin, gy, Win, gx, C, cg);
+            const vec z = LN::ld(Zin + o);                 // requested before the tap loop: the latency hides behind the LDS work
+            vec sgv = LN::zero();
+            if (ADD_SG) sgv = LN::ld(SG + o);
+            vec v = din_at(iy, ix);
             if (ADD_SG) v += sgv;
-            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
-            fd_st4(Gin + o, v);
+            v = LN::round(v * fd_actmask4<ACT_IN>(z * sc + sh));
+            LN::st(Gin + o, v);
             ssum += v; ssx += v * ((z - mu) * is);
         }
     } else {
@@ -1327,43 +1344,43 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
             const int ly = p / TW2, lx = p - ly * TW2;
             const int gy = iy0 + 2 * ly, gx = ix0 + 2 * lx;     // top-left full-res position of the 2x2 block
             if (!c_ok || gy >= Hin || gx >= Win) continue;
-            const long ol = (((long)n * Hs + (gy >> 1)) * Ws + (gx >> 1)) * Cp + (to_skip ? 0 : cg);
-            const fd_f32x4 z = fd_ld4(Zin + ol);                // requested before the tap loop (unused by the lanes that feed the skip tensor)
-            fd_f32x4 d00, d01, d10, d11;
+            const long ol = fd_nhwc(n, Hs, (gy >> 1), Ws, (gx >> 1), Cp, (to_skip ? 0 : cg));
+            const vec z = LN::ld(Zin + ol);                // requested before the tap loop (unused by the lanes that feed the skip tensor)
+            vec d00, d01, d10, d11;
             if (S == 1) {
                 // the four positions of the block read a (K+1) x (K+1) window of the dz patch: walk it row by row, every row feeds
                 // the block's upper row with tap row ky = K-1-r and its lower row with ky = K-r (one pass over LDS, few registers)
-                d00 = fd_zero4(); d01 = fd_zero4(); d10 = fd_zero4(); d11 = fd_zero4();
+                d00 = LN::zero(); d01 = LN::zero(); d10 = LN::zero(); d11 = LN::zero();
                 const int pyb = gy + P - (K - 1) - oyb, pxb = gx + P - (K - 1) - oxb;
 #pragma unroll 1
                 for (int r = 0; r <= K; ++r) {
-                    fd_f32x4 v[K + 1];
-                    const float *row = s_dz + ((pyb + r) * PW + pxb) * PSTR + c4 * 4;
+                    vec v[K + 1];
+                    const lds_t *row = s_dz + ((pyb + r) * PW + pxb) * PSTR + c4 * N;
 #pragma unroll
-                    for (int c = 0; c <= K; ++c) v[c] = fd_ld4(row + c * PSTR);
+                    for (int c = 0; c <= K; ++c) v[c] = LN::lds_ld(row + c * PSTR);
                     if (r < K) {
-                        const float *wr = s_w + (K - 1 - r) * K * CB + c4 * 4;
+                        const float *wr = s_w + (K - 1 - r) * K * CB + c4 * N;
 #pragma unroll
-                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d00 += v[K - 1 - kx] * wv; d01 += v[K - kx] * wv; }
+                        for (int kx = 0; kx < K; ++kx) { const vec wv = LN::ldf(wr + kx * CB); d00 += v[K - 1 - kx] * wv; d01 += v[K - kx] * wv; }
                     }
                     if (r > 0) {
-                        const float *wr = s_w + (K - r) * K * CB + c4 * 4;
+                        const float *wr = s_w + (K - r) * K * CB + c4 * N;
 #pragma unroll
-                        for (int kx = 0; kx < K; ++kx) { const fd_f32x4 wv = fd_ld4(wr + kx * CB); d10 += v[K - 1 - kx] * wv; d11 += v[K - kx] * wv; }
+                        for (int kx = 0; kx < K; ++kx) { const vec wv = LN::ldf(wr + kx * CB); d10 += v[K - 1 - kx] * wv; d11 += v[K - kx] * wv; }
                     }
                 }
             } else {
                 d00 = din_at(2 * ly, 2 * lx); d01 = din_at(2 * ly, 2 * lx + 1); d10 = din_at(2 * ly + 1, 2 * lx); d11 = din_at(2 * ly + 1, 2 * lx + 1);
             }
             if (MODE == 2 || to_skip) {
-                const long o = (((long)n * Hin + gy) * Win + gx) * C2 + cl;
-                fd_st4(SGout + o, d00); fd_st4(SGout + o + C2, d01);
-                fd_st4(SGout + o + (long)Win * C2, d10); fd_st4(SGout + o + (long)Win * C2 + C2, d11);
+                const long o = fd_nhwc(n, Hin, gy, Win, gx, C2, cl);
+                LN::st(SGout + o, d00); LN::st(SGout + o + C2, d01);
+                LN::st(SGout + o + (long)Win * C2, d10); LN::st(SGout + o + (long)Win * C2 + C2, d11);
                 if (to_skip) continue;
             }
-            fd_f32x4 v = (d00 + d01) + (d10 + d11);
-            v = fd_round4(T{}, v * fd_actmask4<ACT_IN>(z * sc + sh));
-            fd_st4(Gin + ol, v);
+            vec v = (d00 + d01) + (d10 + d11);
+            v = LN::round(v * fd_actmask4<ACT_IN>(z * sc + sh));
+            LN::st(Gin + ol, v);
             ssum += v; ssx += v * ((z - mu) * is);
         }
     }
@@ -1372,20 +1389,20 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
     constexpr int NIN = 3 * S + K;
     const int ngroups = npt / K, ky_w = pt % K, pg = pt / K;
     const bool worker = pg < ngroups;
-    fd_f32x4 wacc[K];
+    vec wacc[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) wacc[t] = fd_zero4();
+    for (int t = 0; t < K; ++t) wacc[t] = LN::zero();
     if (worker) {
         const int OTWS = OTW >> 2, nstrips = OTH * OTWS;
         for (int s = pg; s < nstrips; s += ngroups) {
             const int oy = s / OTWS, ox = (s - oy * OTWS) * 4;
-            const float *row = s_in + ((oy * S + ky_w) * TW_in + ox * S) * PSTR + c4 * 4;
-            const float *dzp = s_dz + ((oy0 + oy - oyb) * PW + (ox0 + ox - oxb)) * PSTR + c4 * 4;
-            fd_f32x4 r[NIN], dzv[4];
+            const lds_t *row = s_in + ((oy * S + ky_w) * TW_in + ox * S) * PSTR + c4 * N;
+            const lds_t *dzp = s_dz + ((oy0 + oy - oyb) * PW + (ox0 + ox - oxb)) * PSTR + c4 * N;
+            vec r[NIN], dzv[4];
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+            for (int i = 0; i < NIN; ++i) r[i] = LN::lds_ld(row + i * PSTR);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dzv[j] = fd_ld4(dzp + j * PSTR);
+            for (int j = 0; j < 4; ++j) dzv[j] = LN::lds_ld(dzp + j * PSTR);
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
 #pragma unroll
@@ -1395,26 +1412,26 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
     float *red = smem;
     if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
         const long blk = (long)bm.z * grid_x + bm.x;
-        if (c0 + tid * 4 < Cp) {
-            fd_st4(part + blk * 2 * Cp + c0 + tid * 4, ssum);
-            fd_st4(part + blk * 2 * Cp + Cp + c0 + tid * 4, ssx);
+        if (c0 + tid * N < Cp) {
+            LN::stf(part + blk * 2 * Cp + c0 + tid * N, ssum);
+            LN::stf(part + blk * 2 * Cp + Cp + c0 + tid * N, ssx);
         }
     }
     // the pixel groups' tap sums meet in LDS: red[pg][ky*K + kx][c4] (fixed order -> deterministic); one partial row per tile
     __syncthreads();
     if (worker) {
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) fd_st4(red + ((pg * K * K + ky_w * K + kx) * lanes_c + c4) * 4, wacc[kx]);
+        for (int kx = 0; kx < K; ++kx) LN::stf(red + ((pg * K * K + ky_w * K + kx) * lanes_c + c4) * N, wacc[kx]);
     }
     __syncthreads();
     {
         const long blk = (long)bm.z * grid_x + bm.x;
         for (int i = tid; i < K * K * lanes_c; i += 256) {
             const int t = i >> cbq, cc = i & (lanes_c - 1);
-            if (c0 + cc * 4 < C) {
-                fd_f32x4 a = fd_zero4();
-                for (int g = 0; g < ngroups; ++g) a += fd_ld4(red + ((g * K * K + t) * lanes_c + cc) * 4);
-                fd_st4(wpart + (blk * K * K + t) * C + c0 + cc * 4, a);
+            if (c0 + cc * N < C) {
+                vec a = LN::zero();
+                for (int g = 0; g < ngroups; ++g) a += LN::ldf(red + ((g * K * K + t) * lanes_c + cc) * N);
+                LN::stf(wpart + (blk * K * K + t) * C + c0 + cc * N, a);
             }
         }
     }
@@ -1426,11 +1443,11 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
 // both patches once (all loads of a work-item in flight together), runs the backward-data taps and the weight-gradient taps from LDS, and
 // leaves the producer's gradient, its BatchNorm partial sums and one weight-gradient partial row.  Tiles are INPUT-space (TH x TW, multiples of
 // the stride); an output belongs to the tile its receptive field starts in.
-template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, int N>
 __global__ void __launch_bounds__(256)
 fd_dw_bwd1(const fd_dw_bwd_args<T> a)
 {
-    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
+    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG, N>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
                                                          a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, fd_xcd_image_map(), (int)gridDim.x);
 }
 
@@ -1495,7 +1512,7 @@ fd_dw3s2_dgrad_rows(const T *__restrict__ G, const T *__restrict__ Z, const floa
     fd_f32x4 dA, dB, nA, nB;
     load_dz(b0, dA, dB);
     for (int b = b0; b < b1; ++b) {
-        const long o0 = (((long)n * Hin + 2 * b) * Win + x) * C + cg, o1 = o0 + (long)Win * C;
+        const long o0 = fd_nhwc(n, Hin, 2 * b, Win, x, C, cg), o1 = o0 + (long)Win * C;
         const fd_f32x4 z0 = fd_ld4(Zin + o0), z1 = fd_ld4(Zin + o1);              // requested together with the next dz row
         fd_f32x4 g0 = fd_zero4(), g1 = fd_zero4();
         if (ADD_SG) { g0 = fd_ld4(SG + o0); g1 = fd_ld4(SG + o1); }
@@ -1636,7 +1653,7 @@ fd_stem_wgrad(const float *__restrict__ x, const T *__restrict__ G, const T *__r
                     const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
                     const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
                     const int qy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), qx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);   // branch-free: clamp, load, select
-                    const float v = x[(((long)n * 3 + c) * H + qy) * W + qx];
+                    const float v = x[fd_nhwc(n, 3, c, H, qy, W, qx)];
                     s_in[tid * 33 + (c * 3 + ky) * 3 + kx] = ok ? v : 0.0f;
                 }
         for (int c = 0; c < Cout; c += 4) {

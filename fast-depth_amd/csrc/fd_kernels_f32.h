@@ -233,17 +233,17 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
             const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
             const int qg = c_ok ? cg : 0;
             if (MODE == 0) {
-                v[u] = LN::ldraw(in + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                v[u] = LN::ldraw(in + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             } else {
                 const int Hs = Hin >> 1, Ws = Win >> 1;
                 if (MODE == 3) {
                     // channel concatenation cat(up2(in), skip): channels [0, csplit) come from the low-resolution tensor (pitch
                     // csplit), the rest from the skip tensor (pitch C - csplit); a lane's N channels never straddle (csplit % N == 0)
-                    if (qg < csplit) v[u] = LN::ldraw(in + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * csplit + qg);
-                    else v[u] = LN::ldraw(skip + (((long)n * Hin + qy) * Win + qx) * (C - csplit) + (qg - csplit));
+                    if (qg < csplit) v[u] = LN::ldraw(in + fd_nhwc(n, Hs, (qy >> 1), Ws, (qx >> 1), csplit, qg));
+                    else v[u] = LN::ldraw(skip + fd_nhwc(n, Hin, qy, Win, qx, (C - csplit), (qg - csplit)));
                 } else {
-                    v[u] = LN::ldraw(in + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C + qg);
-                    if (MODE == 2) sk[u] = LN::ldraw(skip + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                    v[u] = LN::ldraw(in + fd_nhwc(n, Hs, (qy >> 1), Ws, (qx >> 1), C, qg));
+                    if (MODE == 2) sk[u] = LN::ldraw(skip + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
                 }
             }
         }
@@ -286,7 +286,7 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gx = ox0 + ox + j;
-                if (gx < Wo) LN::st(out + (((long)n * Ho + gy) * Wo + gx) * C + cg, fd_act4<ACT>(acc[j]));
+                if (gx < Wo) LN::st(out + fd_nhwc(n, Ho, gy, Wo, gx, C, cg), fd_act4<ACT>(acc[j]));
             }
         }
     }

@@ -33,8 +33,15 @@ __device__ int fd_dw_abl;                                 // ablation bits (micr
 #define FD_ST_MEAN 2
 #define FD_ST_INVSTD 3
 
-template <int ACT>
-__device__ __forceinline__ fd_f32x4 fd_bn_act4(fd_f32x4 z, fd_f32x4 s, fd_f32x4 t)
+// bytes of an LDS patch image of npx pixels at pitch pstr (LDS elements), at least 8 KiB (the region doubles as fp32 reduction scratch) and a
+// multiple of 16 bytes (the fp32 tap table follows it)
+template <typename LT> __device__ __forceinline__ size_t fd_lds_patch_bytes(int npx, int pstr)
+{
+    const size_t b = (size_t)npx * pstr * sizeof(LT);
+    return b < 8192 ? 8192 : (b + 15) / 16 * 16;
+}
+template <int ACT, typename V>
+__device__ __forceinline__ V fd_bn_act4(V z, V s, V t)          // V: fd_f32x4 or fd_f32x8 (fd_lane)
 {
     return fd_act4<ACT>(z * s + t);
 }
@@ -183,20 +190,28 @@ fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__res
 // butterfly adds them (fixed order), the four wave sums meet through `red` (>= 4 * lanes_c * 8 floats of LDS that no work-item still reads).
 // Work-items tid < lanes_c return true and hold the totals.  (Probe, tools/microbench/dwtrain.hip: the former 32-step serial LDS walk of lanes_c
 // work-items was 1.2 us of a 6.2 us workgroup life.)
-__device__ __forceinline__ bool fd_wg_sum_by_channel_group(fd_f32x4 &a, fd_f32x4 &b, float *red, int lanes_c, int tid)
+template <typename V>                                     // V: fd_f32x4 or fd_f32x8 (NV floats per channel group)
+__device__ __forceinline__ bool fd_wg_sum_by_channel_group(V &a, V &b, float *red, int lanes_c, int tid)
 {
+    constexpr int NV = sizeof(V) / sizeof(float);
     for (int m = lanes_c; m < 64; m <<= 1) {
-        a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
-        b.x += __shfl_xor(b.x, m); b.y += __shfl_xor(b.y, m); b.z += __shfl_xor(b.z, m); b.w += __shfl_xor(b.w, m);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { a[j] += __shfl_xor(a[j], m); b[j] += __shfl_xor(b[j], m); }
     }
     const int wave = tid >> 6, lane = tid & 63;
     __syncthreads();
-    if (lane < lanes_c) { fd_st4(red + (wave * lanes_c + lane) * 8, a); fd_st4(red + (wave * lanes_c + lane) * 8 + 4, b); }
+    if (lane < lanes_c) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { red[(wave * lanes_c + lane) * 2 * NV + j] = a[j]; red[(wave * lanes_c + lane) * 2 * NV + NV + j] = b[j]; }
+    }
     __syncthreads();
     if (tid >= lanes_c) return false;
-    a = fd_ld4(red + tid * 8); b = fd_ld4(red + tid * 8 + 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) { a += fd_ld4(red + (w * lanes_c + tid) * 8); b += fd_ld4(red + (w * lanes_c + tid) * 8 + 4); }
+    for (int j = 0; j < NV; ++j) { a[j] = red[tid * 2 * NV + j]; b[j] = red[tid * 2 * NV + NV + j]; }
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { a[j] += red[(w * lanes_c + tid) * 2 * NV + j]; b[j] += red[(w * lanes_c + tid) * 2 * NV + NV + j]; }
     return true;
 }
 
@@ -274,7 +289,7 @@ fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, cons
 // weights are the live parameter w[C][K*K]; output is the raw conv result + stats partials
 // part[blk*2*C + {0,C} + c] with blk = image * gridDim.x + tile (logical indices: fd_xcd_image_map).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int K, int S, int MODE, int ACT1, int ACT2>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N>
 __global__ void __launch_bounds__(256)
 fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                     const float *__restrict__ st2, const float *__restrict__ w, T *__restrict__ zout,
@@ -283,12 +298,14 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;           // 3x3: all tap rows of a strip unrolled (their LDS reads in flight together); 5x5: one row at a time (registers)
     constexpr int NIN = 3 * S + K;
+    typedef fd_lane<T, N> LN;
+    typedef typename LN::vec vec;
+    typedef typename LN::lds_t lds_t;
     FD_DYN_SMEM(smem_raw);
-    float *smem = reinterpret_cast<float *>(smem_raw);
-    const int lanes_c = 1 << cbq, CB = lanes_c * 4, PSTR = pstr;   // LDS patch pitch in floats (>= CB + 4, a multiple of 4: chosen by the plan)
+    const int lanes_c = 1 << cbq, CB = lanes_c * N, PSTR = pstr;   // LDS patch pitch in LDS elements (a multiple of 16 bytes: chosen by the plan)
     const int TH_in = (TH - 1) * S + K, TW_in = (TW - 1) * S + K;
-    float *s_in = smem;                                   // [TH_in*TW_in][PSTR]; reused for the stats reduction
-    float *s_w = smem + TH_in * TW_in * PSTR;             // [K*K][CB]
+    lds_t *s_in = reinterpret_cast<lds_t *>(smem_raw);    // [TH_in*TW_in][PSTR] (>= 8 KiB: reused as fp32 scratch by the stats reduction)
+    float *s_w = reinterpret_cast<float *>(smem_raw + fd_lds_patch_bytes<lds_t>(TH_in * TW_in, PSTR));   // [K*K][CB]
     const fd_blk3 bm = fd_xcd_image_map();                 // all tiles / channel blocks of an image on one XCD: halo re-reads hit its L2
     const int ty = bm.x / tiles_x, tx = bm.x - ty * tiles_x;
     const int c0 = bm.y * CB, n = bm.z;
@@ -296,12 +313,12 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
     const int tid = threadIdx.x, c4 = tid & (lanes_c - 1), pt = tid >> cbq, npt = 256 >> cbq;
     FD_DW_PROBE_AT(0);
-    const int cg = c0 + c4 * 4;
+    const int cg = c0 + c4 * N;
     const bool c_ok = cg < C;
 
     // the taps of this channel block (w[c][tap] -> s_w[tap][c]): requested now, written to LDS after the patch loads have been issued, so that the two
     // global round trips overlap instead of following each other (a workgroup's life is a chain of such latencies, not arithmetic)
-    constexpr int NWREG = (K * K * 32 + 255) / 256;
+    constexpr int NWREG = (K * K * 8 * N + 255) / 256;     // CB <= 8 * N channels
     float wreg[NWREG];
 #pragma unroll
     for (int j = 0; j < NWREG; ++j) {
@@ -312,17 +329,17 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     // producer (pitch csplit), the rest from the skip tensor (pitch C - csplit); a lane's 4 channels never straddle
     const bool from_skip = MODE == 3 && cg >= csplit;
     const int C1 = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = from_skip ? cg - csplit : cg;
-    fd_f32x4 s1 = fd_zero4(), t1 = fd_zero4(), s2 = fd_zero4(), t2 = fd_zero4();
+    vec s1 = LN::zero(), t1 = LN::zero(), s2 = LN::zero(), t2 = LN::zero();
     if (c_ok) {
-        if (from_skip) { s1 = fd_ld4(st2 + FD_ST_SCALE * C2 + cl); t1 = fd_ld4(st2 + FD_ST_SHIFT * C2 + cl); }
-        else { s1 = fd_ld4(st1 + FD_ST_SCALE * C1 + cl); t1 = fd_ld4(st1 + FD_ST_SHIFT * C1 + cl); }
-        if (MODE == 2) { s2 = fd_ld4(st2 + FD_ST_SCALE * C + cg); t2 = fd_ld4(st2 + FD_ST_SHIFT * C + cg); }
+        if (from_skip) { s1 = LN::ldf(st2 + FD_ST_SCALE * C2 + cl); t1 = LN::ldf(st2 + FD_ST_SHIFT * C2 + cl); }
+        else { s1 = LN::ldf(st1 + FD_ST_SCALE * C1 + cl); t1 = LN::ldf(st1 + FD_ST_SHIFT * C1 + cl); }
+        if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + cg); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + cg); }
     }
     const int npx_in = TH_in * TW_in;
     constexpr int U = 8;
     fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
-        fd_f32x4 v[U], sk[U];
+        vec v[U], sk[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -330,31 +347,31 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
             const int iy = wk.iy, ix = wk.ix;
             wk.next();
             const int gy = iy0 + iy, gx = ix0 + ix;
-            sk[u] = fd_zero4();
+            sk[u] = LN::zero();
             ok[u] = px < npx_in && c_ok && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
             // branch-free staging: the address is clamped into the image (and the channel group into the tensor) so that every
             // lane issues its load unconditionally -- all U (x2) loads go out back to back; padding is applied when the value is used
             const int qy = gy < 0 ? 0 : (gy >= Hin ? Hin - 1 : gy), qx = gx < 0 ? 0 : (gx >= Win ? Win - 1 : gx);
             const int ql = c_ok ? cl : 0, qg = c_ok ? cg : 0;
             if (MODE == 0) {
-                v[u] = FD_DW_ABL(2) ? fd_zero4() : fd_ld4(zin + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                v[u] = FD_DW_ABL(2) ? LN::zero() : LN::ld(zin + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             } else {
                 const int Hs = Hin >> 1, Ws = Win >> 1;
-                if (from_skip) v[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C2 + ql);
-                else v[u] = fd_ld4(zin + (((long)n * Hs + (qy >> 1)) * Ws + (qx >> 1)) * C1 + ql);
-                if (MODE == 2) sk[u] = fd_ld4(zskip + (((long)n * Hin + qy) * Win + qx) * C + qg);
+                if (from_skip) v[u] = LN::ld(zskip + fd_nhwc(n, Hin, qy, Win, qx, C2, ql));
+                else v[u] = LN::ld(zin + fd_nhwc(n, Hs, (qy >> 1), Ws, (qx >> 1), C1, ql));
+                if (MODE == 2) sk[u] = LN::ld(zskip + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
             if (px < npx_in) {
-                fd_f32x4 a = fd_zero4();                   // zero padding applies to the ACTIVATED tensor
+                vec a = LN::zero();                   // zero padding applies to the ACTIVATED tensor
                 if (ok[u]) {
                     a = from_skip ? fd_bn_act4<ACT2>(v[u], s1, t1) : fd_bn_act4<ACT1>(v[u], s1, t1);
                     if (MODE == 2) a += fd_bn_act4<ACT2>(sk[u], s2, t2);
                 }
-                fd_st4(s_in + px * PSTR + c4 * 4, a);
+                LN::lds_st(s_in + px * PSTR + c4 * N, a);
             }
         }
     }
@@ -365,19 +382,19 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     FD_DW_PROBE_AT(2);
 
     const int TWS = TW >> 2, nstrips = TH * TWS;
-    fd_f32x4 ssum = fd_zero4(), ssq = fd_zero4();
+    vec ssum = LN::zero(), ssq = LN::zero();
     for (int s = pt; s < nstrips; s += npt) {
         const int oy = s / TWS, ox = (s - oy * TWS) * 4;
-        fd_f32x4 acc[4] = {fd_zero4(), fd_zero4(), fd_zero4(), fd_zero4()};
+        vec acc[4] = {LN::zero(), LN::zero(), LN::zero(), LN::zero()};
 #pragma unroll UNR_TAPROWS                              // 3x3: all 3 x NIN patch reads of a strip in flight at once (probe: the tap phase was a chain of LDS latencies)
         for (int ky = 0; ky < K; ++ky) {
-            const float *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * 4;
-            fd_f32x4 r[NIN];
+            const lds_t *row = s_in + ((oy * S + ky) * TW_in + ox * S) * PSTR + c4 * N;
+            vec r[NIN];
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) r[i] = fd_ld4(row + i * PSTR);
+            for (int i = 0; i < NIN; ++i) r[i] = LN::lds_ld(row + i * PSTR);
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const fd_f32x4 wv = fd_ld4(s_w + (ky * K + kx) * CB + c4 * 4);
+                const vec wv = LN::ldf(s_w + (ky * K + kx) * CB + c4 * N);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] += r[j * S + kx] * wv;
             }
@@ -388,8 +405,8 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
             for (int j = 0; j < 4; ++j) {
                 const int gx = ox0 + ox + j;
                 if (gx < Wo) {
-                    const fd_f32x4 zr = fd_round4(T{}, acc[j]);
-                    if (!FD_DW_ABL(1)) fd_st4(zout + (((long)n * Ho + gy) * Wo + gx) * C + cg, zr);
+                    const vec zr = LN::round(acc[j]);
+                    if (!FD_DW_ABL(1)) LN::st(zout + fd_nhwc(n, Ho, gy, Wo, gx, C, cg), zr);
                     ssum += zr; ssq += zr * zr;
                 }
             }
@@ -397,11 +414,11 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     }
     // workgroup partial statistics: fixed-order sum over the pixel-threads that share a channel group
     FD_DW_PROBE_AT(3);
-    if (fd_wg_sum_by_channel_group(ssum, ssq, s_in, lanes_c, tid)) {
+    if (fd_wg_sum_by_channel_group(ssum, ssq, reinterpret_cast<float *>(smem_raw), lanes_c, tid)) {
         const long blk = (long)bm.z * gridDim.x + bm.x;
-        if (c0 + tid * 4 < C) {
-            fd_st4(part + blk * 2 * C + c0 + tid * 4, ssum);
-            fd_st4(part + blk * 2 * C + C + c0 + tid * 4, ssq);
+        if (c0 + tid * N < C) {
+            LN::stf(part + blk * 2 * C + c0 + tid * N, ssum);
+            LN::stf(part + blk * 2 * C + C + c0 + tid * N, ssq);
         }
     }
     FD_DW_PROBE_AT(4);

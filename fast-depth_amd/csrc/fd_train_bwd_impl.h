@@ -48,7 +48,7 @@ inline int dw_dgrad_cols(const TLayer &L) { return L.d.ksize == 5 ? FD_T_DW5_DTW
 // EXACT extent the kernel computes (fd_dw_dgrad_body: PH, PW) -- stride 1: t + K - 1; stride 2: t / 2 + 2.  (Rounds 1-2 requested up to 4 rows and
 // columns more: 58 KB instead of 38 for the 5x5 units = 2 resident workgroups per CU instead of 4.)
 inline int dw_dz_patch(int t, int k, int s) { return (t + k - 2) / s + (s == 2 ? 2 : 1); }
-inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr) { return (std::max((size_t)ph * pw * pstr, (size_t)2048) + (size_t)k * k * cb) * 4; }
+inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr, int le) { return lds_patch_bytes((long)ph * pw, pstr, le) + (size_t)k * k * cb * 4; }
 
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
@@ -64,17 +64,22 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
 {
     TLayer &L = c.p->layers[i];
     TLayer &P = c.p->layers[L.d.src];
-    const int cb = 4 << L.cbq;
+    const int cb = L.dw_n << L.cbq, le = L.dw_n == 8 ? 2 : 4;
+    L.lds_rounding = (L.lds_rounding & ~2) | (L.dw_n == 8 ? 2 : 0);
     const int TH = dw_dgrad_rows(c.p, L), TW = dw_dgrad_cols(L);
     const int tiles_x = ceil_div(L.in_w, TW), tiles_y = ceil_div(L.in_h, TH);
     const int ph = dw_dz_patch(TH, K, S), pw = dw_dz_patch(TW, K, S);
-    const size_t lds = dw_bwd_lds(ph, pw, cb, K, L.bpstr);
+    const size_t lds = dw_bwd_lds(ph, pw, cb, K, L.bpstr, le);
     dim3 grid(tiles_x * tiles_y, ceil_div(L.d.cin, cb), c.p->B);
     const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
-    FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
-              c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
-              twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, tws(c.p, c.p->part_off),
-              L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit, L.bpstr);
+    fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
+        constexpr int NL = decltype(nt)::value;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG, NL>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
+                  c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
+                  twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, tws(c.p, c.p->part_off),
+                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit, L.bpstr);
+    });
     *nblk_out = tiles_x * tiles_y * c.p->B;
     return check_launch("fd_dw_dgrad");
 }
@@ -104,7 +109,7 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
     float *wpart = tws(c.p, L.wp_off);
     // tiles per workgroup (along x): as many as keep >= ~1536 workgroups in flight
-    const int ncb_w = ceil_div(L.d.cin, 4 << L.cbq);
+    const int ncb_w = ceil_div(L.d.cin, L.dw_n << L.cbq);
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);     // the backward-weights kernel's own output tiles (the forward's may be larger)
     int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ncb_w * c.p->B / FD_DW_WGRAD_TARGET_WGS)));
     if (c.p->tune & FD_TUNE_WGRAD_TILE_ROWS) tpw = btx;
@@ -112,16 +117,19 @@ int launch_dw_wgrad_acts(BwdCtx &c, int i)
     tpw = ceil_div(btx, groups_x);
     const dim3 wgrid(groups_x * bty, ncb_w, c.p->B);
     // LDS: activated input patch + dz tile, both [pixels][cb + 4] floats; the final reduction (npt/K groups x K*K taps x cb) reuses it
-    const int cbw = 4 << L.cbq, th_in = (L.bth - 1) * L.d.stride + L.d.ksize, tw_in = (L.btw - 1) * L.d.stride + L.d.ksize;
-    const size_t wlds = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * L.bpstr, (size_t)((256 / (cbw / 4)) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw) * 4;
+    const int cbw = L.dw_n << L.cbq, le = L.dw_n == 8 ? 2 : 4, th_in = (L.bth - 1) * L.d.stride + L.d.ksize, tw_in = (L.btw - 1) * L.d.stride + L.d.ksize;
+    const size_t wlds = std::max(lds_patch_bytes((long)th_in * tw_in + L.bth * L.btw, L.bpstr, le), (size_t)((256 >> L.cbq) / L.d.ksize) * L.d.ksize * L.d.ksize * cbw * 4);
     if (wlds > 64 * 1024) return fail(FD_ERR_INVALID, "depthwise wgrad: LDS request %zu exceeds 64 KiB", wlds);
     const int wblk = groups_x * bty * c.p->B;
 #define FD_DWW(K_, S_, M_)                                                                                                         \
     case K_ * 100 + S_ * 10 + M_:                                                                                                  \
-        FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
-                  Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
-                  twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
-                  L.cbq, L.bth, L.btw, btx, tpw, L.csplit, L.bpstr);                                                          \
+        fd_by_lane_width<T>(L.dw_n, [&](auto nt) {                                                                                \
+            constexpr int NL = decltype(nt)::value;                                                                               \
+            FD_LAUNCH((fd_dw_wgrad<T, K_, S_, M_, ACT1, ACT2, NL>), wgrid, dim3(256), wlds, c.s, twt<T>(c.p, P.z_off), tws(c.p, P.st_off),  \
+                      Kp ? twt<T>(c.p, Kp->z_off) : (const T *)nullptr, Kp ? tws(c.p, Kp->st_off) : (const float *)nullptr,           \
+                      twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), wpart, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin,     \
+                      L.cbq, L.bth, L.btw, btx, tpw, L.csplit, L.bpstr);                                                          \
+        });                                                                                                                        \
         break;
     switch (key) {
         FD_DWW(3, 1, 0) FD_DWW(3, 2, 0) FD_DWW(5, 1, 0) FD_DWW(5, 1, 1) FD_DWW(5, 1, 2) FD_DWW(5, 1, 3)
@@ -154,7 +162,8 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     TLayer &L = c.p->layers[i];
     TLayer &P = c.p->layers[L.d.src];
     const TLayer *Kp = L.d.skip >= 0 ? &c.p->layers[L.d.skip] : nullptr;
-    const int cb = 4 << L.cbq;
+    const int cb = L.dw_n << L.cbq, le = L.dw_n == 8 ? 2 : 4;
+    L.lds_rounding = (L.lds_rounding & ~2) | (L.dw_n == 8 ? 2 : 0);
     fd_dw_bwd_args<T> a{};
     a.G = twt<T>(c.p, L.g_off); a.Z = twt<T>(c.p, L.z_off); a.Zin = twt<T>(c.p, P.z_off);
     a.Zskip = Kp ? twt<T>(c.p, Kp->z_off) : nullptr; a.SG = ADD_SG ? twt<T>(c.p, P.sg_off) : nullptr;
@@ -167,7 +176,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.d_tiles_x = ceil_div(L.in_w, a.d_tw);
     a.d_gx = a.d_tiles_x * ceil_div(L.in_h, a.d_th); a.d_gy = ceil_div(L.d.cin, cb);
     const int ph = dw_dz_patch(a.d_th, K, S), pw = dw_dz_patch(a.d_tw, K, S);
-    const size_t lds_d = dw_bwd_lds(ph, pw, cb, K, L.bpstr);
+    const size_t lds_d = dw_bwd_lds(ph, pw, cb, K, L.bpstr, le);
     // backward-weights geometry (launch_dw_wgrad_acts); the pair keeps roughly the same number of workgroups in flight per role
     const int btx = ceil_div(L.out_w, L.btw), bty = ceil_div(L.out_h, L.bth);
     int tpw = std::max(1, std::min(btx, (int)((long)btx * bty * ceil_div(L.d.cin, cb) * c.p->B / FD_DW_WGRAD_TARGET_WGS)));
@@ -176,7 +185,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     tpw = ceil_div(btx, groups_x);
     a.w_th = L.bth; a.w_tw = L.btw; a.w_tiles_x = btx; a.w_tpw = tpw; a.w_gx = groups_x * bty; a.w_gy = ceil_div(L.d.cin, cb);
     const int th_in = (L.bth - 1) * S + K, tw_in = (L.btw - 1) * S + K;
-    const size_t lds_w = std::max((size_t)(th_in * tw_in + L.bth * L.btw) * L.bpstr, (size_t)((256 / (cb / 4)) / K) * K * K * cb) * 4;
+    const size_t lds_w = std::max(lds_patch_bytes((long)th_in * tw_in + L.bth * L.btw, L.bpstr, le), (size_t)((256 >> L.cbq) / K) * K * K * cb * 4);
     const size_t lds = std::max(lds_d, lds_w);
     if (lds > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 160 KiB", lds);
     const int kk = K * K;
@@ -189,6 +198,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
         // measured (us, rows pair vs single-staging kernel): bf16 conv2.0 48.9 + 16.8 vs 79.3, conv4.0 33.4 + 11.0 vs 48.2, conv6.0 (14x14 outputs) 23.4 + 7.8 vs 29.6;
         // fp32 conv2.0 69.0 + 26.7 vs 96.2, conv4.0 40.7 + 15.3 vs 55.2 (equal: both forms move the fp32 bytes at the same rate) -> 16-bit plans, maps >= 28x28
         if (rows_ok && !(c.p->tune & (FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_BWD_PAIR | FD_TUNE_DW_BWD1))) {
+            L.lds_rounding &= ~2;
             const int gxd = ceil_div((long)L.in_w * cgn, 256), h2 = L.in_h / 2;
             int th2 = h2;
             while (th2 > 2 && (long)gxd * ceil_div(h2, th2) * c.p->B < 1024) th2 = (th2 + 1) / 2;
@@ -220,12 +230,15 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
         const int oth = a.d_th / S, otw = a.d_tw / S;
         const int th_in1 = (oth - 1) * S + K, tw_in1 = (otw - 1) * S + K;
         const int ph1 = (a.d_th + K - 2) / S + 2, pw1 = (a.d_tw + K - 2) / S + 2;          // upper bound of the dz patch
-        const size_t lds1 = std::max((size_t)(ph1 * pw1 + th_in1 * tw_in1) * L.bpstr + (size_t)kk * cb, (size_t)((256 / (cb / 4)) / K) * kk * cb + 2048) * 4;
+        const size_t lds1 = std::max(lds_patch_bytes((long)ph1 * pw1 + th_in1 * tw_in1, L.bpstr, le) + (size_t)kk * cb * 4, (size_t)((256 >> L.cbq) / K) * kk * cb * 4 + 8192);
         if (lds1 > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward: LDS request %zu exceeds 160 KiB", lds1);
         const int wblk1 = a.d_gx * c.p->B;
         if ((size_t)wblk1 * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
-        (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
+        fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
+            constexpr int NL = decltype(nt)::value;
+            (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+            FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
+        });
         int rc1 = check_launch("fd_dw_bwd1");
         if (rc1) return rc1;
         *nblk_out = a.d_gx * c.p->B;
@@ -234,8 +247,11 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const int wblk = a.w_gx * c.p->B;
     if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
     const long total = (long)c.p->B * ((long)a.d_gx * a.d_gy + (long)a.w_gx * a.w_gy);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG>), dim3((unsigned)total), dim3(256), lds, c.s, a);
+    fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
+        constexpr int NL = decltype(nt)::value;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>), dim3((unsigned)total), dim3(256), lds, c.s, a);
+    });
     int rc = check_launch("fd_dw_bwd");
     if (rc) return rc;
     *nblk_out = a.d_gx * c.p->B;
@@ -493,6 +509,183 @@ int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, 
         if (!grads[i].conv_weight || !grads[i].bn_weight || !grads[i].bn_bias) return fail(FD_ERR_INVALID, "layer %d: null gradient pointer", i);
     return plan->dtype == FD_BF16 ? train_backward_t<fd_bf16>(plan, params, grads, n_layers, dy, from_layer, to_layer, stream)
                                   : train_backward_t<float>(plan, params, grads, n_layers, dy, from_layer, to_layer, stream);
+}
+
+int fd_cast_gradients(const void *src, void *dst, int64_t numel, int32_t to_bf16, void *stream);
+
+/* ---- data-parallel gradient exchange issued by the library itself: RCCL all-reduce over xGMI (the reference's only multi-GPU
+ * idiom is torch.nn.DataParallel, imagenet/mobilenet.py:68).  RCCL is bound at RUN time (dlopen "librccl.so.1": inside a torch process that is the
+ * RCCL torch itself loaded, by SONAME; a torch-free host gets the system library), so the library has no link-time dependency on it and loads on
+ * hosts without RCCL.  One communicator + one non-blocking HIP stream + one event per bucket; no host synchronisation anywhere. ---- */
+#ifndef FD_EMU
+#include <dlfcn.h>
+#endif
+struct fd_comm {
+    void *comm = nullptr;                 // ncclComm_t
+    hipStream_t stream = nullptr;         // the collectives' stream
+    std::vector<hipEvent_t> bucket_done;  // recorded on the compute stream after a bucket's last backward kernel
+    hipEvent_t all_done = nullptr, t0 = nullptr, t1 = nullptr, tb = nullptr;   // t0 / t1: first collective issued / last one finished; tb: backward finished on the compute stream (timing enabled)
+    int rank = 0, world = 1;
+    bool timed = false;                   // t0 / t1 hold a pair of the last fd_train_backward_allreduce
+};
+
+extern "C++" {
+namespace {
+#ifndef FD_EMU
+struct fd_nccl_uid { char internal[FD_COMM_ID_BYTES]; };
+struct RcclApi {
+    int (*GetUniqueId)(fd_nccl_uid *) = nullptr;
+    int (*CommInitRank)(void **, int, fd_nccl_uid, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy;
+        return a;
+    }();
+    return api;
+}
+int rccl_fail(const char *what, int rc)
+{
+    const RcclApi &a = rccl();
+    return fail(FD_ERR_HIP, "%s: RCCL error %d (%s)", what, rc, a.GetErrorString ? a.GetErrorString(rc) : "?");
+}
+constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclBfloat16 = 9;    // rccl.h: ncclRedOp_t / ncclDataType_t
+#endif
+}  // namespace
+}  // extern "C++"
+
+int fd_comm_unique_id(void *id_out)
+{
+#ifdef FD_EMU
+    (void)id_out;
+    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
+#else
+    if (!id_out) return fail(FD_ERR_INVALID, "null argument");
+    if (!rccl().ok) return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy)");
+    fd_nccl_uid id{};
+    const int rc = rccl().GetUniqueId(&id);
+    if (rc) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy(id_out, id.internal, FD_COMM_ID_BYTES);
+    return FD_OK;
+#endif
+}
+
+int fd_comm_create(const void *id, int32_t rank, int32_t world, fd_comm **out)
+{
+#ifdef FD_EMU
+    (void)id; (void)rank; (void)world; (void)out;
+    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
+#else
+    if (!id || !out || world <= 0 || rank < 0 || rank >= world) return fail(FD_ERR_INVALID, "fd_comm_create: bad argument (rank %d of %d)", rank, world);
+    if (!rccl().ok) return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded");
+    fd_comm *c = new fd_comm();
+    c->rank = rank; c->world = world;
+    fd_nccl_uid uid{};
+    memcpy(uid.internal, id, FD_COMM_ID_BYTES);
+    int rc = rccl().CommInitRank(&c->comm, world, uid, rank);          // (on the calling thread's current device, like every entry point here)
+    if (rc) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->all_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess || hipEventCreate(&c->tb) != hipSuccess) {
+        fd_comm_destroy(c);
+        return fail(FD_ERR_HIP, "fd_comm_create: stream / event creation failed");
+    }
+    *out = c;
+    return FD_OK;
+#endif
+}
+
+void fd_comm_destroy(fd_comm *c)
+{
+    if (!c) return;
+#ifndef FD_EMU
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    for (hipEvent_t e : c->bucket_done) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->all_done, c->t0, c->t1, c->tb}) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+#endif
+    delete c;
+}
+
+int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers, const void *dy,
+                                fd_comm *comm, const fd_grad_bucket *buckets, int32_t n_buckets, void *stream)
+{
+#ifdef FD_EMU
+    (void)plan; (void)params; (void)grads; (void)n_layers; (void)dy; (void)comm; (void)buckets; (void)n_buckets; (void)stream;
+    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
+#else
+    if (!comm || !buckets || n_buckets <= 0) return fail(FD_ERR_INVALID, "fd_train_backward_allreduce: null communicator / empty bucket list");
+    // the buckets must tile the layers n-1 .. 0 in backward order
+    int expect = n_layers - 1;
+    for (int b = 0; b < n_buckets; ++b) {
+        if (buckets[b].from_layer != expect || buckets[b].to_layer > buckets[b].from_layer || buckets[b].to_layer < 0 || !buckets[b].grad || buckets[b].numel <= 0)
+            return fail(FD_ERR_INVALID, "bucket %d: layers %d..%d do not continue the backward order at %d (or null / empty gradient slice)", b, buckets[b].from_layer, buckets[b].to_layer, expect);
+        expect = buckets[b].to_layer - 1;
+    }
+    if (expect != -1) return fail(FD_ERR_INVALID, "the buckets stop at layer %d: they must cover every layer", expect + 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    while ((int)comm->bucket_done.size() < n_buckets) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
+        comm->bucket_done.push_back(e);
+    }
+    for (int b = 0; b < n_buckets; ++b) {
+        const fd_grad_bucket &k = buckets[b];
+        int rc = fd_train_backward_range(plan, params, grads, n_layers, dy, k.from_layer, k.to_layer, stream);
+        if (rc) return rc;
+        // the bucket's gradients are complete on the compute stream: the collective's stream waits for exactly that point
+        if (hipEventRecord(comm->bucket_done[b], s) != hipSuccess || hipStreamWaitEvent(comm->stream, comm->bucket_done[b], 0) != hipSuccess)
+            return fail(FD_ERR_HIP, "event hand-over to the communication stream failed");
+        if (b == 0) (void)hipEventRecord(comm->t0, comm->stream);
+        int nrc;
+        if (k.grad16) {                                          // 16-bit exchange: convert, all-reduce the bf16 copy, convert back -- all in stream order
+            if ((rc = fd_cast_gradients(k.grad, k.grad16, k.numel, 1, comm->stream))) return rc;
+            nrc = rccl().AllReduce(k.grad16, k.grad16, (size_t)k.numel, kNcclBfloat16, kNcclSum, comm->comm, comm->stream);
+            if (nrc) return rccl_fail("ncclAllReduce", nrc);
+            if ((rc = fd_cast_gradients(k.grad16, k.grad, k.numel, 0, comm->stream))) return rc;
+        } else {
+            nrc = rccl().AllReduce(k.grad, k.grad, (size_t)k.numel, kNcclFloat32, kNcclSum, comm->comm, comm->stream);
+            if (nrc) return rccl_fail("ncclAllReduce", nrc);
+        }
+    }
+    (void)hipEventRecord(comm->tb, s);
+    (void)hipEventRecord(comm->t1, comm->stream);
+    comm->timed = true;
+    // whatever the caller enqueues next on its stream (fd_sgd_step) runs after the last collective
+    if (hipEventRecord(comm->all_done, comm->stream) != hipSuccess || hipStreamWaitEvent(s, comm->all_done, 0) != hipSuccess)
+        return fail(FD_ERR_HIP, "event hand-over from the communication stream failed");
+    return FD_OK;
+#endif
+}
+
+int fd_comm_last_exchange_ms(fd_comm *comm, float *ms_exchange, float *ms_exposed)
+{
+#ifdef FD_EMU
+    (void)comm; (void)ms_exchange; (void)ms_exposed;
+    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
+#else
+    if (!comm || !ms_exchange || !ms_exposed) return fail(FD_ERR_INVALID, "null argument");
+    if (!comm->timed) return fail(FD_ERR_STATE, "no exchange has been issued on this communicator");
+    if (hipEventSynchronize(comm->t1) != hipSuccess || hipEventSynchronize(comm->tb) != hipSuccess || hipEventElapsedTime(ms_exchange, comm->t0, comm->t1) != hipSuccess)
+        return fail(FD_ERR_HIP, "event timing failed");
+    // exposed: how long after the last backward kernel the last collective ended (an event pair in the "wrong" order is a fully hidden exchange)
+    if (hipEventElapsedTime(ms_exposed, comm->tb, comm->t1) != hipSuccess || *ms_exposed < 0.0f) *ms_exposed = 0.0f;
+    return FD_OK;
+#endif
 }
 
 int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t height, int32_t width, int32_t out_h, int32_t out_w,

@@ -52,6 +52,8 @@ struct TLayer {
     int mode = 0;
     int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
+    int dw_n = 4;                                             // channels per work-item of the LDS-tiled depthwise kernels (8: bf16 plans, storage-typed LDS patches; fd_lane)
+    mutable int lds_rounding = 0;                             // fd_train_plan_lds_rounding: set by the launches of the last forward / backward
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
     int rows_th = 0;                                          // > 0: the forward runs on fd_dw3_rows_train with row strips of this height
     int stem_band = 0;                                        // floats of the stem kernels' input band in LDS
@@ -109,10 +111,20 @@ inline RedGeom red_geom(int nrows, long width)
 inline double *red_slices(fd_train_plan *p) { return reinterpret_cast<double *>(p->ws + p->part2_off); }
 inline int *red_counters(fd_train_plan *p) { return reinterpret_cast<int *>(p->ws + p->cnt_off); }
 
+// calls fn(fd_int<4>) or -- 16-bit storage types only -- fn(fd_int<8>): the lane width (fd_lane) of the LDS-tiled depthwise kernels
+template <typename T, typename F> inline void fd_by_lane_width(int n, F &&fn)
+{
+    if constexpr (!std::is_same<T, float>::value) { if (n == 8) { fn(fd_int<8>{}); return; } }
+    fn(fd_int<4>{});
+}
+// host mirror of fd_lds_patch_bytes (fd_kernels_train.h): bytes of an LDS patch image of npx pixels at pitch pstr in elements of `le` bytes
+inline size_t lds_patch_bytes(long npx, int pstr, int le) { return std::max(align_up((size_t)npx * pstr * le, 16), (size_t)8192); }
+
 template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
                     T *zout, float *part, hipStream_t s, int batch)
 {
+    L.lds_rounding = (L.lds_rounding & ~1) | ((!L.rows_th && L.dw_n == 8) ? 1 : 0);
     if (L.rows_th) {                                          // register-window kernel (3x3, plain input, large maps)
         if (L.d.stride == 1) FD_LAUNCH((fd_dw3_rows_train<T, 1, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th);
         else FD_LAUNCH((fd_dw3_rows_train<T, 2, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th);
@@ -121,9 +133,12 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
 #define FD_DWT(K_, S_, M_)                                                                                                   \
     case K_ * 100 + S_ * 10 + M_:                                                                                            \
-        if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-        FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
-                  L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr);                \
+        fd_by_lane_width<T>(L.dw_n, [&](auto nt) {                                                                          \
+            constexpr int NL = decltype(nt)::value;                                                                         \
+            if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+            FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2, NL>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
+                      L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr);            \
+        });                                                                                                                  \
         break;
     switch (key) {
         FD_DWT(3, 1, 0) FD_DWT(3, 2, 0) FD_DWT(5, 1, 0) FD_DWT(5, 1, 1) FD_DWT(5, 1, 2) FD_DWT(5, 1, 3)
@@ -315,9 +330,18 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);
             L.mode = d.upsample ? (d.skip >= 0 ? (concat ? 3 : 2) : 1) : 0;
             L.out_h = L.in_h / d.stride; L.out_w = L.in_w / d.stride;
-            const int cb_max = (tune & FD_TUNE_DW_CB16) ? 16 : 32;
-            const int cb = d.cin >= cb_max ? cb_max : (d.cin >= 16 ? 16 : (d.cin >= 8 ? 8 : 4));
-            L.cbq = ilog2(cb / 4);
+            // bf16 plans CAN run these kernels with 8 channels (16 bytes) per work-item and LDS patches kept in bf16 (fd_lane<T, 8>: a 64-channel block
+            // has the LDS footprint and the per-workgroup instruction count of the 32-channel fp32-patch block) -- FD_TUNE_FORCE_DW_H8.  Measured at batch 32
+            // (round 4, us per launch, 8- vs 4-channel form): paired backward conv1.0 95.6 vs 51.3, conv3.0 83.6 vs 54.4, conv5.0 45.5 vs 32.0, 14x14 units
+            // 25.1 vs 19.3, decode_conv5.0 148.4 vs 151.6, decode_conv4.0 79.6 vs 81.8; forward 208.6 vs 203.7 over the family: the kernels are VALU-issue
+            // bound (PMC: 61 % VALU busy at 23 % parked), not residency bound, and the wider lanes cost registers.  Default: 4.
+            L.dw_n = (h16 && (tune & FD_TUNE_FORCE_DW_H8) && !(tune & FD_TUNE_NO_DW_H8)) ? 8 : 4;
+            const int cb_max = (tune & FD_TUNE_DW_CB16) ? 4 * L.dw_n : 8 * L.dw_n;
+            int cb = L.dw_n;                                      // the largest power-of-two block <= cin, at most cb_max
+            while (cb * 2 <= cb_max && cb * 2 <= d.cin) cb *= 2;
+            if (L.dw_n == 8 && cb == 64 && ceil_div(d.cin, 64) * 64 > ceil_div(d.cin, 32) * 32) cb = 32;     // (pruned widths: the block size that pads the channel count least)
+            L.cbq = ilog2(cb / L.dw_n);
+            const int le = L.dw_n == 8 ? 2 : 4;                   // bytes per LDS patch element
             const bool k5 = d.ksize == 5;
             L.tw = std::min((L.out_w + 3) / 4 * 4, d.stride == 2 ? 8 : (k5 ? FD_T_DW5_FTW : 16));
             L.th = (tune & FD_TUNE_DW_TH8) ? std::min(L.out_h, 8) : ceil_div(L.out_h, ceil_div(L.out_h, k5 ? FD_T_DW5_FTH : 8));   // balanced rows: 14 -> 7 + 7 instead of 8 + 6 (both tiles full, smaller patches: one more workgroup per CU)
@@ -337,8 +361,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
             }
             L.tiles_x = ceil_div(L.out_w, L.tw); L.tiles_y = ceil_div(L.out_h, L.th);
             const int th_in = (L.th - 1) * d.stride + d.ksize, tw_in = (L.tw - 1) * d.stride + d.ksize;
-            L.pstr = L.bpstr = cb + 4 + 4 * (int)((tune / FD_TUNE_DW_PITCH4) & 3);       // (FD_TUNE_DW_PITCH4 / 8: +4 / +8 / +12 floats)
-            L.lds = (std::max((size_t)th_in * tw_in * L.pstr, (size_t)2048) + (size_t)d.ksize * d.ksize * cb) * 4;
+            // pitch in LDS elements: the block's channels + 4 dwords (FD_TUNE_DW_PITCH4 / 8: +4 / +8 / +12 dwords more)
+            L.pstr = L.bpstr = cb + (4 + 4 * (int)((tune / FD_TUNE_DW_PITCH4) & 3)) * (4 / le);
+            L.lds = lds_patch_bytes((long)th_in * tw_in, L.pstr, le) + (size_t)d.ksize * d.ksize * cb * 4;
             L.grid = dim3(L.tiles_x * L.tiles_y, ceil_div(d.cin, cb), batch);
             L.nblk = L.tiles_x * L.tiles_y * batch;
             {   // FORWARD of the 3x3 units on plain inputs whose channel-group count C/4 is a power of two in 8 ... 64 (32 ... 256 channels: the
@@ -482,6 +507,12 @@ int fd_train_forward(fd_train_plan *plan, const fd_layer_params *params, int32_t
     if (n_layers != (int)plan->layers.size()) return fail(FD_ERR_INVALID, "expected %zu layer parameter sets", plan->layers.size());
     return plan->dtype == FD_BF16 ? train_forward_t<fd_bf16>(plan, params, n_layers, bn_eps, bn_momentum, x_nchw, y, stream)
                                   : train_forward_t<float>(plan, params, n_layers, bn_eps, bn_momentum, x_nchw, y, stream);
+}
+
+int fd_train_plan_lds_rounding(const fd_train_plan *plan, int32_t layer)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return -1;
+    return plan->layers[layer].lds_rounding;
 }
 
 int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n, int32_t *h,

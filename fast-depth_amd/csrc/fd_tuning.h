@@ -25,15 +25,23 @@
 #define FD_TUNE_DW_FORCE_ROWS 8192u       /* tests: the register-window kernels on every eligible 3x3 unit whatever the map size */
 #define FD_TUNE_DW_TH8 16384u             /* train: depthwise tiles of 8 rows with a ragged last tile instead of balanced row counts */
 #define FD_TUNE_DW_CB16 32768u            /* train: depthwise kernels work on 16-channel blocks instead of 32 */
-#define FD_TUNE_NO_DW_H8 65536u           /* 16-bit plans: the LDS-tiled depthwise kernels keep fp32 patches and 4 channels per work-item (round-1..3 form)
-                                             instead of storage-typed patches and 8 channels (16 bytes) per work-item */
-#define FD_TUNE_ALL 131071u
+#define FD_TUNE_NO_DW_H8 65536u           /* 16-bit plans: every LDS-tiled depthwise kernel keeps fp32 patches and 4 channels per work-item (round-1..3 form) */
+#define FD_TUNE_FORCE_DW_H8 131072u       /* 16-bit plans: storage-typed LDS patches and 8 channels (16 bytes) per work-item (fd_lane<T, 8>) on every eligible
+                                             LDS-tiled depthwise kernel, inference and train (default: only where it was measured to pay -- the 5x5
+                                             inference units on maps >= 56x56; tests and A/B runs) */
+#define FD_TUNE_ALL 262143u
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 /* the mask applies to the next plan this thread creates (then resets to 0); unknown bits are rejected by that creation */
 void fd_tuning_next(uint32_t mask);
+/* Test hook of the layer-local train parity (tests/harness.py: the fp64 single-unit reference rounds exactly where the kernels round): which
+ * kernels of depthwise unit `layer` kept their LDS patches in the 16-bit storage type during the LAST forward / backward of this plan --
+ * bit 0: the forward kernel rounded its (activated, upsampled, skip-added) conv input; bit 1: the backward kernels rounded dz and the
+ * re-created conv input.  0 for fp32 plans, the 4-channel form and the register-window kernels.  -1: bad arguments. */
+struct fd_train_plan;
+int fd_train_plan_lds_rounding(const struct fd_train_plan *plan, int32_t layer);
 #ifdef __cplusplus
 }
 #endif

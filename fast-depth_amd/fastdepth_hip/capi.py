@@ -46,6 +46,7 @@ FD_TUNE_DW_FORCE_ROWS = 8192 << _TUNE_SHIFT
 FD_TUNE_DW_TH8 = 16384 << _TUNE_SHIFT
 FD_TUNE_DW_CB16 = 32768 << _TUNE_SHIFT
 FD_TUNE_NO_DW_H8 = 65536 << _TUNE_SHIFT
+FD_TUNE_FORCE_DW_H8 = 131072 << _TUNE_SHIFT
 
 
 def create_plan(lib, train, descs, n, batch, height, width, fd_dtype, flags, handle_ref):
@@ -86,6 +87,10 @@ class LayerParams(ctypes.Structure):
 
 class LayerGrads(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("conv_weight", "bn_weight", "bn_bias")]
+
+
+class GradBucket(ctypes.Structure):
+    _fields_ = [("from_layer", ctypes.c_int32), ("to_layer", ctypes.c_int32), ("grad", ctypes.c_void_p), ("numel", ctypes.c_int64), ("grad16", ctypes.c_void_p)]
 
 
 class TraceRecord(ctypes.Structure):
@@ -168,6 +173,16 @@ def load(path=None):
         lib.fd_sgd_step.restype = ctypes.c_int
         lib.fd_cast_gradients.argtypes = [vp, vp, ctypes.c_int64, i32, vp]
         lib.fd_cast_gradients.restype = ctypes.c_int
+        lib.fd_comm_unique_id.argtypes = [vp]
+        lib.fd_comm_unique_id.restype = ctypes.c_int
+        lib.fd_comm_create.argtypes = [vp, i32, i32, ctypes.POINTER(vp)]
+        lib.fd_comm_create.restype = ctypes.c_int
+        lib.fd_comm_destroy.argtypes = [vp]
+        lib.fd_comm_destroy.restype = None
+        lib.fd_train_backward_allreduce.argtypes = [vp, ctypes.POINTER(LayerParams), ctypes.POINTER(LayerGrads), i32, vp, vp, ctypes.POINTER(GradBucket), i32, vp]
+        lib.fd_train_backward_allreduce.restype = ctypes.c_int
+        lib.fd_comm_last_exchange_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        lib.fd_comm_last_exchange_ms.restype = ctypes.c_int
     lib.fd_val_transform.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.fd_val_transform.restype = ctypes.c_int
     lib.fd_depth_metrics_scratch_bytes.argtypes = []
@@ -202,7 +217,8 @@ EXPORTS = ("fd_plan_create", "fd_plan_destroy", "fd_plan_workspace_bytes", "fd_p
            "fd_plan_algorithmic_bytes", "fd_plan_algorithmic_flops", "fd_plan_layer_stats", "fd_plan_layer_traffic",
            "fd_train_plan_create", "fd_train_plan_destroy", "fd_train_plan_workspace_bytes", "fd_train_plan_bind_workspace",
            "fd_train_forward", "fd_train_backward", "fd_train_backward_range", "fd_train_layer_tensor", "fd_l1_loss_scratch_bytes",
-           "fd_l1_loss", "fd_l1_loss_masked", "fd_sgd_step", "fd_cast_gradients", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
+           "fd_l1_loss", "fd_l1_loss_masked", "fd_sgd_step", "fd_cast_gradients", "fd_comm_unique_id", "fd_comm_create", "fd_comm_destroy",
+           "fd_train_backward_allreduce", "fd_comm_last_exchange_ms", "fd_val_transform", "fd_depth_metrics_scratch_bytes", "fd_depth_metrics",
            "fd_depth_metrics_frames_scratch_bytes", "fd_depth_metrics_frames", "fd_plan_export_bytes", "fd_plan_export",
            "fd_plan_import", "fd_plan_import_weights", "fd_plan_shape", "fd_trace_begin", "fd_trace_end", "fd_last_error", "fd_version")
 

@@ -270,11 +270,14 @@ class TrainEngine(TrainCore):
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=None, force_buckets=False,
-                 dtype=torch.float32, masked_loss=False, grad_exchange_dtype=torch.float32, _library=None):
+                 dtype=torch.float32, masked_loss=False, grad_exchange_dtype=torch.float32, exchange="auto", _library=None):
         """n_buckets: None (default) = two buckets cut by finish time (make_buckets_by_finish); an integer = that many buckets of roughly
         equal bytes (make_buckets).  grad_exchange_dtype: torch.float32 (default: the 15.84 MB fp32 vector is all-reduced in place) or
         torch.bfloat16 (every bucket is converted to bfloat16, all-reduced as 7.92 MB, converted back: half the bytes over xGMI for one
-        rounding of every summand and of the sum)."""
+        rounding of every summand and of the sum).  exchange: "library" = the all-reduces are issued by libfastdepth_hip.so itself
+        (fd_train_backward_allreduce: RCCL on the library's own communicator and stream, torch.distributed only broadcasts the 128-byte
+        rendezvous id once); "torch" = every bucket goes through torch.distributed.all_reduce on a side stream (rounds 1-3; the only route for
+        a gloo group, i.e. the CPU test tier); "auto" = "library" for an nccl group on a GPU, "torch" otherwise."""
         super().__init__(model, dtype, _library)
         if grad_exchange_dtype not in (torch.float32, torch.bfloat16):
             raise capi.FastDepthError("grad_exchange_dtype must be float32 or bfloat16")
@@ -306,10 +309,44 @@ class TrainEngine(TrainCore):
         self.exchange_dtype = grad_exchange_dtype
         self.flat_grad16 = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) if (self.use_comm and grad_exchange_dtype == torch.bfloat16) else None
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.use_comm and self.device.type == "cuda") else None
+        # ---- the library's own communicator (RCCL bound at run time inside libfastdepth_hip.so) ----
+        self.comm = None
+        if exchange not in ("auto", "library", "torch"):
+            raise capi.FastDepthError("exchange must be 'auto', 'library' or 'torch'")
+        want_lib = exchange == "library" or (exchange == "auto" and self.use_comm and self.device.type == "cuda" and self.dist.get_backend(process_group) == "nccl")
+        if want_lib and self.use_comm:
+            if self.device.type != "cuda":
+                raise capi.FastDepthError("exchange='library' needs a GPU (RCCL)")
+            L = self.L
+            rank = self.dist.get_rank(process_group)
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                capi.check(L, L.fd_comm_unique_id(uid.data_ptr()), "fd_comm_unique_id")
+            uid_dev = uid.to(self.device)
+            self.dist.broadcast(uid_dev, src=self.dist.get_global_rank(process_group, 0) if hasattr(self.dist, "get_global_rank") else 0, group=process_group)
+            uid = uid_dev.cpu()
+            handle = ctypes.c_void_p()
+            with _device_guard(self.device):
+                capi.check(L, L.fd_comm_create(uid.data_ptr(), rank, self.world, ctypes.byref(handle)), "fd_comm_create")
+            self.comm = handle
+            nb = len(self.buckets)
+            self.c_buckets = (capi.GradBucket * nb)()
+            for k, (fl, tl) in enumerate(self.buckets):
+                g32 = self.bucket_slice(fl, tl)
+                g16 = self.bucket_slice(fl, tl, self.flat_grad16) if self.flat_grad16 is not None else None
+                self.c_buckets[k] = capi.GradBucket(fl, tl, g32.data_ptr(), g32.numel(), g16.data_ptr() if g16 is not None else None)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._dpred = None
         self._scratch = torch.empty(self.L.fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
         self.last_comm_us = None                  # set by step(time_comm=True): device time of the all-reduces / of the whole step
+
+    def __del__(self):
+        if getattr(self, "comm", None):
+            try:
+                self.L.fd_comm_destroy(self.comm)
+            except Exception:
+                pass
+            self.comm = None
 
     def bucket_slice(self, from_layer, to_layer, buf=None):
         return (self.flat_grad if buf is None else buf)[self.layer_span[from_layer][0]:self.layer_span[to_layer][1]]
@@ -350,7 +387,12 @@ class TrainEngine(TrainCore):
             if ev:
                 ev["bwd0"].record(cur)
             works = []
-            for bi, (from_layer, to_layer) in enumerate(self.buckets):
+            if self.comm is not None:
+                # ONE library call: every bucket's backward range, its event hand-over to the communicator's stream and its RCCL all-reduce;
+                # on return `cur` already waits for the last collective
+                capi.check(L, L.fd_train_backward_allreduce(self._plan.handle, self._params, self.c_grads, self.n, self._dpred.data_ptr(), self.comm,
+                                                            self.c_buckets, len(self.buckets), sp), "fd_train_backward_allreduce")
+            for bi, (from_layer, to_layer) in enumerate(self.buckets if self.comm is None else ()):
                 self.backward_range(self._dpred, from_layer, to_layer)
                 if self.use_comm:
                     if on_gpu:
@@ -365,7 +407,7 @@ class TrainEngine(TrainCore):
                         works.append(self._exchange(from_layer, to_layer, None))
             if ev:
                 ev["bwd1"].record(cur)
-            if self.use_comm:
+            if self.use_comm and self.comm is None:
                 for w in works:
                     w.wait()                       # makes the current stream wait for the collective (no host sync on the GPU)
                 if on_gpu:
@@ -378,7 +420,12 @@ class TrainEngine(TrainCore):
             if ev:
                 ev["end"].record(cur)
                 torch.cuda.synchronize(self.device)
-                comm = ev["c0"].elapsed_time(ev["c1"]) * 1e3 if self.use_comm else 0.0
-                self.last_comm_us = (comm, ev["bwd0"].elapsed_time(ev["end"]) * 1e3, ev["bwd1"].elapsed_time(ev["end"]) * 1e3)
+                if self.comm is not None:
+                    a, b = ctypes.c_float(), ctypes.c_float()
+                    capi.check(L, L.fd_comm_last_exchange_ms(self.comm, ctypes.byref(a), ctypes.byref(b)), "fd_comm_last_exchange_ms")
+                    self.last_comm_us = (a.value * 1e3, ev["bwd0"].elapsed_time(ev["end"]) * 1e3, b.value * 1e3)
+                else:
+                    comm = ev["c0"].elapsed_time(ev["c1"]) * 1e3 if self.use_comm else 0.0
+                    self.last_comm_us = (comm, ev["bwd0"].elapsed_time(ev["end"]) * 1e3, ev["bwd1"].elapsed_time(ev["end"]) * 1e3)
         self.steps += 1
         return self.loss

@@ -231,6 +231,32 @@ int fd_sgd_step(const fd_sgd_tensor *table_device, int32_t n_tensors, int64_t to
  * fp32 after it.  The collective itself stays the host's (torch.distributed / RCCL), as for the fp32 exchange. */
 int fd_cast_gradients(const void *src, void *dst, int64_t numel, int32_t to_bf16, void *stream);
 
+/* ---- Data-parallel gradient exchange issued by the LIBRARY (the reference's only multi-GPU idiom is torch.nn.DataParallel,
+ * imagenet/mobilenet.py:68): one process per GPU, RCCL all-reduce of the flat gradient vector over xGMI, bucket by bucket on the communicator's own
+ * HIP stream, each bucket released by an event the moment its last backward kernel has been enqueued -- no host round trip per bucket (the
+ * torch.distributed route of rounds 1-3 cost a Python call, an event, a stream switch and a ProcessGroup work object per bucket).  RCCL is bound
+ * at run time (dlopen librccl.so.1), the library does not link it.
+ *   fd_comm_unique_id      rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the host broadcasts it by whatever means it has
+ *                          (torch.distributed.broadcast in train.py, MPI / a file in a C host)
+ *   fd_comm_create         every rank: ncclCommInitRank on its current device + the communication stream and events
+ *   fd_train_backward_allreduce
+ *                          = fd_train_backward_range over `buckets` (which must tile layers n-1 .. 0 in backward order), each followed by the summing
+ *                          all-reduce of its contiguous fp32 gradient slice grad[numel] in place -- or, when grad16 != NULL, of a bfloat16 copy
+ *                          (fd_cast_gradients -> all-reduce -> cast back: half the bytes over xGMI); on return `stream` waits for the last collective,
+ *                          so fd_sgd_step(grad_scale = 1 / world) can be enqueued right behind
+ *   fd_comm_last_exchange_ms
+ *                          measurement aid (synchronises): device time from the first collective's issue to the last one's end in the most recent
+ *                          call, and how much of it was left after the last backward kernel had finished (the part backward does not hide) */
+#define FD_COMM_ID_BYTES 128
+typedef struct fd_comm fd_comm;
+typedef struct fd_grad_bucket { int32_t from_layer, to_layer; float *grad; int64_t numel; void *grad16; } fd_grad_bucket;
+int fd_comm_unique_id(void *id_out);
+int fd_comm_create(const void *id, int32_t rank, int32_t world, fd_comm **out);
+void fd_comm_destroy(fd_comm *comm);
+int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers, const void *dy,
+                                fd_comm *comm, const fd_grad_bucket *buckets, int32_t n_buckets, void *stream);
+int fd_comm_last_exchange_ms(fd_comm *comm, float *ms_first_issue_to_last_done, float *ms_exposed_after_backward);
+
 /* Depth metrics (reference metrics.py:31-55 Result.evaluate): one fused reduction over output/target
  * (fp32, any shape, `numel` elements) producing the 10 sums from which every metric follows:
  *   sums[0] #valid, [1] sum ad^2, [2] sum ad, [3] sum |log10 o - log10 t|, [4] sum ad/t, [5..7] #(max(o/t,t/o) < 1.25^k),

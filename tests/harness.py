@@ -111,6 +111,7 @@ def saturate_encoder(model, gain=4.0):
     return model
 
 
+LAST_LOCAL_INFO = None     # {"dw_units_with_16bit_lds_patches": n} of the last local_train_parity call
 LAST_SAT6_FRAC = None      # fraction of ReLU6-unit pre-activations >= 6 seen by the last train_parity_report / local_train_parity call
 
 
@@ -294,6 +295,11 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
     Z = [tp.tensor(i, 0).double() for i in range(n)]
     ST = [tp.tensor(i, 2).double()[0, :, :, 0].t() for i in range(n)]
     G = [tp.tensor(i, 1).double() for i in range(n)]
+    # which depthwise kernels kept their LDS patches in the 16-bit storage type (private test hook, csrc/fd_tuning.h): bit 0 forward, bit 1 backward
+    tp.lib.fd_train_plan_lds_rounding.restype = ctypes.c_int
+    tp.lib.fd_train_plan_lds_rounding.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lds_round = [max(tp.lib.fd_train_plan_lds_rounding(tp.h, i), 0) for i in range(n)]
+    rep_info = {"dw_units_with_16bit_lds_patches": sum(1 for v in lds_round if v)}
     consumers = {}
     for i in range(n):
         if L[i].desc.src >= 0:
@@ -345,8 +351,14 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
                 ask = act(d.skip, pre(d.skip)).requires_grad_(True)
                 inp = torch.cat((inp, ask), 1) if d.concat else inp + ask
         w = (rnd(w) if pw16 else w).requires_grad_(True)
-        zr = F.conv2d(inp, w, None, d.stride, d.ksize // 2, 1, d.cout if d.op == FD_OP_DW else 1)
+        groups = d.cout if d.op == FD_OP_DW else 1
+        # 16-bit LDS patches (fd_lane<T, 8> depthwise kernels): the conv input is rounded to the storage type on its way into LDS -- straight-through
+        # for autograd, so that the gradient below flows to `a` / `ask` as the kernels compute it
+        st_round = lambda t: t + (rnd(t.detach()) - t.detach())
+        zr = F.conv2d(st_round(inp) if (lds_round[i] & 1) else inp, w, None, d.stride, d.ksize // 2, 1, groups)
         note("z", relmax(Z[i], zr.detach()), i)
+        if (lds_round[i] & 1) != ((lds_round[i] >> 1) & 1):           # the backward kernels stage the input their own way
+            zr = F.conv2d(st_round(inp) if (lds_round[i] & 2) else inp, w, None, d.stride, d.ksize // 2, 1, groups)
         # batch statistics of the STORED z, tables, running statistics
         C = d.cout
         cnt = Z[i].numel() // C
@@ -376,8 +388,10 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
             note("pred", relmax(y.double(), up(act(i, yh))), i)
             gsum = F.avg_pool2d(dpred.double(), 2) * 4 if d.upsample else dpred.double()
             note("g_head", relmax(G[i], gsum * passmask(i, yh), (~near_kink(i, yh)).double()), i)
-        zr.backward(dz)
-        note("conv_wgrad", relmax(grads[i]["conv_weight"].cpu().double(), w.grad), i)
+        zr.backward(rnd(dz) if (lds_round[i] & 2) else dz)
+        # (16-bit LDS patches: the kernel rounds fp32 values, this reference fp64 ones -- an operand within 1e-7 of a rounding boundary lands on the other
+        # side, i.e. moves by 2^-8 of its value, ~3e-5 of all operands: those few show up in a sum over a few thousand pixels, hence a category of its own)
+        note("conv_wgrad_lds16" if (lds_round[i] & 2) else "conv_wgrad", relmax(grads[i]["conv_weight"].cpu().double(), w.grad), i)
         if a is not None:
             din = a.grad
             if d.src in skip_sources and d.skip < 0:
@@ -388,4 +402,6 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
         if ask is not None:
             note("skip_grad", relmax(tp.tensor(d.skip, 3).double(), ask.grad), i)
     tp.close()
+    global LAST_LOCAL_INFO
+    LAST_LOCAL_INFO = rep_info
     return rep

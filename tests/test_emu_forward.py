@@ -249,13 +249,14 @@ WIDE = ((16, 32, 64, 64, 128, 128, 40, 40, 40, 40, 40, 40, 48, 16), (200, 128, 6
 @pytest.mark.parametrize("b,hw", [(2, (64, 64)), (1, (64, 96))])
 def test_emulated_16bit_depthwise_8_channels_per_work_item(b, hw, dtype, ulp):
     """16-bit plans run the LDS-tiled depthwise layers (the decoder's 5x5 units: plain, on up2, on up2 + skip) with storage-typed LDS patches and
-    8 channels (16 bytes) per work-item (fd_dwconv<T, ..., 8>); FD_TUNE_NO_DW_H8 keeps the fp32-patch / 4-channel form.  Plain and upsampled inputs
+    8 channels (16 bytes) per work-item (fd_dwconv<T, ..., 8>) where that was measured to pay (the large maps) or, as here, under FD_TUNE_FORCE_DW_H8 wherever
+    eligible; FD_TUNE_NO_DW_H8 keeps the fp32-patch / 4-channel form everywhere.  Plain and upsampled inputs
     are copied into LDS bit for bit and the taps accumulate in fp32 in the same order, so those layers agree exactly; the up2(low) + skip sum is
     rounded to the storage type on its way into LDS (the 4-channel form keeps it in fp32): one extra rounding of the conv input."""
     m = small_model(WIDE[0], WIDE[1], seed=44).eval()
     x = torch.rand(b, 3, hw[0], hw[1], generator=torch.Generator().manual_seed(13))
     cap = harness.capi
-    new = harness.CPlan("emu", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_EPILOGUE_FUSION)
+    new = harness.CPlan("emu", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_EPILOGUE_FUSION | cap.FD_TUNE_FORCE_DW_H8)
     old = harness.CPlan("emu", m, x, dtype=dtype, flags=cap.FD_PLAN_NO_EPILOGUE_FUSION | cap.FD_TUNE_NO_DW_H8)
     info = new.info()
     h8 = [i for i, s in enumerate(info) if s.startswith("dwconv<") and "8 channels per work-item" in s]

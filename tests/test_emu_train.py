@@ -135,7 +135,9 @@ LOCAL_TOL = {
     torch.float32: {"default": 2e-5},
     # bf16 plan: tensors STORED in bf16 carry one rounding (2^-8 relative to the tensor's max is the bound, 2^-9 typical);
     # everything kept in fp32 (tables, running statistics, parameter gradients, prediction) stays at fp32 accuracy
-    torch.bfloat16: {"default": 2e-5, "z": 4e-3, "g_src": 4e-3, "dz": 4e-3, "skip_grad": 4e-3},
+    # (conv_wgrad_lds16: depthwise units whose backward kernels keep bf16 LDS patches -- fp32 result of operands that were rounded from fp32
+    # values, against a reference that rounds fp64 values: see harness.local_train_parity)
+    torch.bfloat16: {"default": 2e-5, "z": 4e-3, "g_src": 4e-3, "dz": 4e-3, "skip_grad": 4e-3, "conv_wgrad_lds16": 2e-3},
 }
 
 
@@ -153,7 +155,10 @@ def assert_local_parity(rep, dtype):
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_DW_BWD_PAIR),
                                                    ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_BWD1),
                                                    ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_PITCH4 | capi.FD_TUNE_DW_PITCH8 | capi.FD_TUNE_DW_WGRAD_TH4),
-                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.bfloat16, capi.FD_TUNE_DW_FORCE_ROWS)])
+                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.bfloat16, capi.FD_TUNE_DW_FORCE_ROWS),
+                                                   # fd_lane<T, 8>: bf16 LDS patches, 8 channels per work-item -- paired launch / single-staging kernel, ragged channel counts
+                                                   ("ragged", RAGGED, torch.bfloat16, capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_BWD_PAIR),
+                                                   ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_BWD1)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     """Every unit's forward and backward kernels on their own stored inputs against an fp64 single-unit autograd reference
     (harness.local_train_parity): the rigorous check of the bf16 train plan, whose end-to-end
@@ -171,6 +176,7 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     target = 2.0 + torch.rand(2, 1, h, w, generator=g)
     rep = harness.local_train_parity("emu", m, x, target, torch.device("cpu"), dtype=dtype, flags=flags)
     assert_local_parity(rep, dtype)
+    assert (harness.LAST_LOCAL_INFO["dw_units_with_16bit_lds_patches"] > 0) == bool(flags & capi.FD_TUNE_FORCE_DW_H8)
     if dtype == torch.bfloat16:
         assert "dz" in rep
     if name.endswith("sat6"):

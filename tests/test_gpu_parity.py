@@ -146,7 +146,7 @@ def test_16bit_default_plan_batch32_vs_oracle(dtype, tol, mtol_d1, mtol_rmse):
     assert sum(s.startswith("pw_gemm16") and "fused dw" in s for s in info) >= 6, info
     assert any("head on its output tile" in s for s in info), info
     assert any(s.startswith("dw3_rows8") for s in info), info
-    assert sum(s.startswith("dwconv<k5") and "8 channels per work-item" in s for s in info) >= 3, info
+    assert sum(s.startswith("dwconv<k5") and "8 channels per work-item" in s for s in info) >= 2, info     # decode_conv4 / 5: the maps of >= 56 x 56
     assert harness.rel_err(y.numpy(), y_ref.numpy()) < tol
     depth = inputs.load_sample()[1].numpy()
     for i in (0, 5, 17, 31):

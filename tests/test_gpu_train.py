@@ -104,9 +104,10 @@ def test_eval_after_training_uses_updated_running_stats():
     assert harness.rel_err(y.cpu().numpy(), yo) < 1e-3
 
 
-@pytest.mark.parametrize("pruned,dtype,sat6", [(False, torch.float32, False), (False, torch.bfloat16, False), (True, torch.bfloat16, False),
-                                               (False, torch.float32, True), (False, torch.bfloat16, True)])
-def test_train_step_layer_local_parity_full_size(pruned, dtype, sat6):
+@pytest.mark.parametrize("pruned,dtype,sat6,h8", [(False, torch.float32, False, False), (False, torch.bfloat16, False, False), (True, torch.bfloat16, False, False),
+                                                  (False, torch.float32, True, False), (False, torch.bfloat16, True, False),
+                                                  (False, torch.bfloat16, False, True), (True, torch.bfloat16, True, True)])
+def test_train_step_layer_local_parity_full_size(pruned, dtype, sat6, h8):
     """Every unit's forward and backward kernels on their own stored inputs vs an fp64 single-unit autograd reference, at
     224x224 (harness.local_train_parity).  For the bf16 plan this is the rigorous parity statement:
     stored tensors within one bf16 rounding (2^-8 of the tensor's max), everything kept in fp32 at fp32 accuracy."""
@@ -115,8 +116,11 @@ def test_train_step_layer_local_parity_full_size(pruned, dtype, sat6):
     x, tgt = _batch(2)
     from fastdepth_hip import capi
     # (pruned case: weight-gradient tile rows; saturating cases: every depthwise unit through the single-staging backward kernel, 5x5 + upsample + skip included)
-    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype, flags=capi.FD_TUNE_WGRAD_TILE_ROWS if pruned else (capi.FD_TUNE_DW_BWD1 if sat6 else 0))
+    # (h8: the depthwise kernels with bf16 LDS patches and 8 channels per work-item, fd_lane<T, 8> -- off in default train plans, where they measured slower)
+    flags = (capi.FD_TUNE_WGRAD_TILE_ROWS if pruned else (capi.FD_TUNE_DW_BWD1 if sat6 else 0)) | (capi.FD_TUNE_FORCE_DW_H8 if h8 else 0)
+    rep = harness.local_train_parity("hip", m, x, tgt, torch.device("cuda"), dtype=dtype, flags=flags)
     assert_local_parity(rep, dtype)
+    assert (harness.LAST_LOCAL_INFO["dw_units_with_16bit_lds_patches"] > 0) == h8
     if sat6:
         assert harness.LAST_SAT6_FRAC > 0.005, harness.LAST_SAT6_FRAC
 
