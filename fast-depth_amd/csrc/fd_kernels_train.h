@@ -575,16 +575,21 @@ fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const fl
 __device__ __forceinline__ void fd_sum_partial_rows(const float *__restrict__ part, int r0, int r1, int wave, int C, int c, bool ok, double &s, double &q)
 {
     s = 0.0; q = 0.0;
-    if (!ok) return;
-    int b = r0 + wave;
-    for (; b + 16 * 7 < r1; b += 16 * 8) {
+    if (!ok || r1 <= r0) return;
+    // EVERY batch -- the last, partial one included -- is issued as eight row loads in flight (row index clamped, the add masked): round 3 walked the
+    // remainder (all of a <= 112-row reduction: the 14 x 14 and 7 x 7 units, i.e. most of the 76 finalisations of a step) one dependent load pair at a
+    // time, 6 - 7 serial round trips of ~0.5 us inside a launch that sits between every producer and its consumer.  Same ascending row order as before.
+    for (int b = r0 + wave; b < r1; b += 16 * 8) {
         float vs[8], vq[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { vs[u] = part[(long)(b + 16 * u) * 2 * C + c]; vq[u] = part[(long)(b + 16 * u) * 2 * C + C + c]; }
+        for (int u = 0; u < 8; ++u) {
+            const int row = b + 16 * u < r1 ? b + 16 * u : r1 - 1;
+            vs[u] = part[(long)row * 2 * C + c]; vq[u] = part[(long)row * 2 * C + C + c];
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s += (double)vs[u]; q += (double)vq[u]; }
+        for (int u = 0; u < 8; ++u)
+            if (b + 16 * u < r1) { s += (double)vs[u]; q += (double)vq[u]; }
     }
-    for (; b < r1; b += 16) { s += (double)part[(long)b * 2 * C + c]; q += (double)part[(long)b * 2 * C + C + c]; }
 }
 
 // ------------------------------------------------------------------------------------------------
