@@ -548,6 +548,7 @@ def main():
             roof, whole, kernels = train_profile(teng, x_ring, tgt_ring, stats, 3, peak, 4.0 * teng.total, "train_f32" if dtype == torch.float32 else "train_bf16")
             res["roofline"], res["whole_step"], res["kernels"] = roof, whole, kernels[:12]
             res["whole_step"]["frac_of_roofline"] = round(whole["roofline_bound_ms"] / res["ms_per_step"], 4)
+        teng.close()                                            # the library's RCCL communicator, before the process group goes away
         return res
 
     # ---- one configuration only (profiling runs) ------------------------------------------------------------------------------------

@@ -132,6 +132,9 @@ int plan_layers(fd_plan *p, const fd_layer_desc *layers, size_t *woff_out)
         default: FD_BAD("layer %d: unknown op %d", i, d.op);
         }
         if (L.lds > 160 * 1024) FD_BAD("layer %d: LDS request %zu exceeds 160 KiB", i, L.lds);
+        // fd_nhwc (fd_device.h): within-image element offsets are 32-bit, formed with 24 x 24 bit multiplications
+        if ((long)L.in_h * L.in_w >= (1L << 24) || d.cin >= (1 << 24) || d.cout >= (1 << 24) || (double)L.in_h * L.in_w * std::max(d.cin, d.cout) >= 4294967296.0)
+            FD_BAD("layer %d: a %dx%d map with %d channels exceeds the kernels' 32-bit within-image addressing", i, L.in_h, L.in_w, std::max(d.cin, d.cout));
         L.w_off = woff; woff += align_up(L.w_bytes, 256);
         L.b_off = woff; woff += align_up((size_t)d.cout * 4, 256);
         L.out_bytes = align_up((size_t)batch * L.out_h * L.out_w * d.cout * esz, 256);

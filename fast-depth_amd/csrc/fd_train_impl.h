@@ -429,6 +429,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         }
         // (the 16-bit pointwise forward kernel raises its dynamic-LDS limit itself; the other train kernels stay within the default 64 KiB)
         if (L.lds > (((h16 && d.op == FD_OP_PW && !L.head) || d.op == FD_OP_DW) ? 160 : 64) * 1024) FD_BAD("layer %d: LDS request %zu exceeds the limit", i, L.lds);
+        // fd_nhwc (fd_device.h): within-image element offsets are 32-bit, formed with 24 x 24 bit multiplications
+        if ((long)L.in_h * L.in_w >= (1L << 24) || d.cin >= (1 << 24) || d.cout >= (1 << 24) || (double)L.in_h * L.in_w * std::max(d.cin, d.cout) >= 4294967296.0)
+            FD_BAD("layer %d: a %dx%d map with %d channels exceeds the kernels' 32-bit within-image addressing", i, L.in_h, L.in_w, std::max(d.cin, d.cout));
         L.M = (long)batch * L.out_h * L.out_w;
         L.z_elems = (size_t)L.M * d.cout;
         L.n_stat = (double)L.M;

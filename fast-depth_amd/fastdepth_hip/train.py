@@ -340,13 +340,19 @@ class TrainEngine(TrainCore):
         self._scratch = torch.empty(self.L.fd_l1_loss_scratch_bytes(1), dtype=torch.uint8, device=self.device)
         self.last_comm_us = None                  # set by step(time_comm=True): device time of the all-reduces / of the whole step
 
-    def __del__(self):
+    def close(self):
+        """Releases the library's RCCL communicator (a collective call: every rank of the group closes).  Call it before the process group is
+        destroyed / the interpreter exits; __del__ only does it as a best effort."""
         if getattr(self, "comm", None):
-            try:
-                self.L.fd_comm_destroy(self.comm)
-            except Exception:
-                pass
+            torch.cuda.synchronize(self.device)
+            self.L.fd_comm_destroy(self.comm)
             self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def bucket_slice(self, from_layer, to_layer, buf=None):
         return (self.flat_grad if buf is None else buf)[self.layer_span[from_layer][0]:self.layer_span[to_layer][1]]

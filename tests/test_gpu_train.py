@@ -310,3 +310,47 @@ def test_masked_l1_loss_on_device_and_in_the_engine():
     assert l0 == pytest.approx(float(want), rel=1e-4)
     l1 = float(eng.step(x.cuda(), t2.cuda()))
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_library_issued_rccl_exchange_one_rank():
+    """fd_train_backward_allreduce (the all-reduces issued by libfastdepth_hip.so itself on its own RCCL communicator and stream, one C call per step)
+    on a 1-rank nccl group -- the only world size a 1-GPU box offers; world 2 of the HOST logic (bucket spans, grad_scale, the bf16 exchange) is
+    tests/test_dp_gloo.py through torch.distributed.  A sum over one rank is the identity, so: (a) the fp32 exchange leaves exactly the single-GPU
+    engine's parameters after two steps; (b) the library route and the torch.distributed route agree bit for bit for the bf16 exchange (both round
+    every gradient to bfloat16 and back); (c) the buckets really went through the communicator (its timing events exist)."""
+    import socket
+    import torch.distributed as dist
+    from fastdepth_hip.train import TrainEngine
+    from fastdepth_hip import capi
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x, tgt = _batch(4, seed=3)
+        xg, tg = x.cuda(), tgt.cuda()
+        base = _model(seed=7)
+
+        def run(**kw):
+            eng = TrainEngine(copy.deepcopy(base).cuda().train(), lr=0.01, momentum=0.9, weight_decay=1e-4, **kw)
+            return eng, [float(eng.step(xg, tg)) for _ in range(2)]
+        e0, l0 = run()
+        e1, l1 = run(process_group=dist.group.WORLD, force_buckets=True)
+        assert e1.comm is not None and len(e1.buckets) == 2, "the library route was not taken"
+        assert l0 == l1
+        for (_, _, p0), (_, _, p1) in zip(e0.param_list, e1.param_list):
+            assert torch.equal(p0, p1)
+        e1.step(xg, tg, time_comm=True)
+        assert e1.last_comm_us[0] > 0.0
+        e2, l2 = run(process_group=dist.group.WORLD, force_buckets=True, grad_exchange_dtype=torch.bfloat16)
+        e3, l3 = run(process_group=dist.group.WORLD, force_buckets=True, grad_exchange_dtype=torch.bfloat16, exchange="torch")
+        assert e2.comm is not None and e3.comm is None and l2 == l3
+        for (_, _, p2), (_, _, p3) in zip(e2.param_list, e3.param_list):
+            assert torch.equal(p2, p3)
+        assert any(not torch.equal(p0, p2) for (_, _, p0), (_, _, p2) in zip(e0.param_list, e2.param_list))      # the 16-bit exchange does round
+        # a bucket list that does not tile the layers is refused by the C entry point
+        bad = (capi.GradBucket * 1)(capi.GradBucket(e1.n - 1, 5, e1.flat_grad.data_ptr(), 16, None))
+        rc = e1.L.fd_train_backward_allreduce(e1._plan.handle, e1._params, e1.c_grads, e1.n, e1._dpred.data_ptr(), e1.comm, bad, 1, None)
+        assert rc == -1 and b"cover every layer" in e1.L.fd_last_error()
+        for e in (e1, e2, e3):
+            e.close()
+    finally:
+        dist.destroy_process_group()

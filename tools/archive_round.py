@@ -11,6 +11,13 @@ for name, out in (("profile_summary.txt", "profile_summary.txt"), ("profile_summ
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, out))
+if os.path.exists(os.path.join(src, "dist_overhead.txt")):
+    shutil.copy(os.path.join(src, "dist_overhead.txt"), os.path.join(dst, "dist_overhead_one_rank.txt"))
+for d in glob.glob(os.path.join(src, "pmc_valu_*")):
+    if os.path.exists(os.path.join(d, "summary.txt")):
+        cfg = os.path.basename(d)[len("pmc_valu_"):]
+        os.makedirs(os.path.join(dst, cfg), exist_ok=True)
+        shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, cfg, "pmc_valu_lds_wait_per_kernel.txt"))
 for cfg in ("infer", "train_f32", "train_bf16", "f16", "bf16", "pruned_f16"):
     m = glob.glob(os.path.join(src, "prof_" + cfg, "**", "*kernel_stats.csv"), recursive=True)
     if m:
@@ -19,7 +26,7 @@ for cfg in ("infer", "train_f32", "train_bf16", "f16", "bf16", "pruned_f16"):
         if os.path.exists(os.path.join(src, "prof_%s.json" % cfg)):
             shutil.copy(os.path.join(src, "prof_%s.json" % cfg), os.path.join(dst, cfg, "bench_only.json"))
 for d in glob.glob(os.path.join(src, "pmc_*")):
-    if not os.path.isdir(d):
+    if not os.path.isdir(d) or os.path.basename(d).startswith("pmc_valu_"):        # (the SQ accounting passes are archived as their summaries, above)
         continue
     m = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not m:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: smoke, gpu tests, bench, then ONE rocprofv3 invocation per configuration (kernel trace + stats) and the PMC passes.
 # Usage: gpurun --timeout 2400 -- bash tools/gpu_round.sh [tag] [skip-tests]
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -23,5 +23,14 @@ for cfg in infer train_bf16 train_f32 f16 pruned_f16; do
   done
 done
 timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_infer_SQ -o p -- python $ROOT/bench.py --only infer --steps 3 --warmup 2 > /dev/null 2> $OUT/pmc_infer_SQ.err; echo "infer SQ rc=$?"
+echo "== VALU / LDS / wait accounting (SQ counters, own passes)"
+for cfg in infer f16 train_bf16 train_f32; do PMC_OUT=$OUT bash $ROOT/tools/pmc_valu.sh $cfg > /dev/null 2>&1; echo "$cfg valu rc=$?"; done
+echo "== data-parallel machinery on one rank (single vs forced RCCL path, bf16 and fp32 steps, alternating)"
+cd $ROOT
+for rep in 1 2; do for mode in single forced; do for cfg in train_bf16 train_f32; do
+  if [ $mode = forced ]; then export FD_BENCH_FORCE_DIST=1; else unset FD_BENCH_FORCE_DIST; fi
+  echo "$rep $mode $cfg $(timeout 200 python bench.py --only $cfg --steps 50 --warmup 5 2> /dev/null | tail -1)" >> $OUT/dist_overhead.txt
+done; done; done
+unset FD_BENCH_FORCE_DIST; cat $OUT/dist_overhead.txt
 cd $ROOT; python tools/summarize_profiles.py $OUT > $OUT/profile_summary.txt 2>&1; head -60 $OUT/profile_summary.txt
 du -sh $OUT
