@@ -447,12 +447,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    force_dist = os.environ.get("FD_BENCH_FORCE_DIST") == "1"           # exercises the RCCL code path on one rank
+    force_dist = os.environ.get("FD_BENCH_FORCE_DIST") in ("1", "2")    # exercises the RCCL code path on one rank ("2": with the ncclAllReduce calls themselves elided)
     if world > 1 or force_dist:
         import torch.distributed as dist
         if not dist.is_initialized():
             if "MASTER_ADDR" not in os.environ:
                 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            # the compute stream's hardware queue exists BEFORE RCCL creates its own (measured on one rank, scratch probe / DESIGN.md section 12: with the
+            # process group initialised before the first device allocation the bucket hand-over of the train step costs +150 us per step, after it +50)
+            torch.zeros(1, device=dev)
+            torch.cuda.synchronize(dev)
             dist.init_process_group("nccl", device_id=dev)
 
     import models
@@ -504,7 +508,8 @@ def main():
         tm.decode_conv6[1].bias.data.fill_(2.8)
         tm = tm.to(dev).train()
         return TrainEngine(tm, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None),
-                           force_buckets=force_dist, dtype=dtype, grad_exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32)
+                           force_buckets=force_dist, dtype=dtype, grad_exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32,
+                           _elide_collectives=os.environ.get("FD_BENCH_FORCE_DIST") == "2")      # (measurement hook, one rank: the machinery without the ncclAllReduce calls)
 
     gt = torch.Generator().manual_seed(1)
     # synthetic depth, U[0.7, 10) m: one target per input batch of the ring (the train loops rotate (input, target) pairs like the inference loop)

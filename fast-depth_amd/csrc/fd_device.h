@@ -272,6 +272,11 @@ __device__ __forceinline__ fd_u16x8 fd_pack8v(fd_bf16, fd_f32x8 v)
     const fd_u32x4_ r = {fd_f32x2_to_bf16x2(v[0], v[1]), fd_f32x2_to_bf16x2(v[2], v[3]), fd_f32x2_to_bf16x2(v[4], v[5]), fd_f32x2_to_bf16x2(v[6], v[7])};
     return __builtin_bit_cast(fd_u16x8, r);
 }
+__device__ __forceinline__ fd_u16x8 fd_sum8(fd_half, fd_u16x8 a, fd_u16x8 b)
+{
+    return __builtin_bit_cast(fd_u16x8, __builtin_bit_cast(fd_f16x8, a) + __builtin_bit_cast(fd_f16x8, b));
+}
+__device__ __forceinline__ fd_u16x8 fd_sum8(fd_bf16, fd_u16x8 a, fd_u16x8 b) { return fd_pack8v(fd_bf16{}, fd_cvt8(fd_bf16{}, a) + fd_cvt8(fd_bf16{}, b)); }
 template <int ACT>
 __device__ __forceinline__ fd_f32x8 fd_act4(fd_f32x8 v)      // (same name as the 4-channel form: the kernels are generic in the lane width)
 {
@@ -308,6 +313,7 @@ template <typename T> struct fd_lane<T, 4> {
     static __device__ __forceinline__ vec lds_ld(const lds_t *p) { return fd_ld4(p); }
     static __device__ __forceinline__ void lds_st(lds_t *p, vec v) { fd_st4(p, v); }
     static __device__ __forceinline__ void lds_st_raw(lds_t *p, raw r) { fd_st4(p, fd_cvt4(T{}, r)); }
+    static __device__ __forceinline__ void lds_st_sum(lds_t *p, raw a, raw b) { fd_st4(p, fd_cvt4(T{}, a) + fd_cvt4(T{}, b)); }   // up2(low) + skip
     static __device__ __forceinline__ vec round(vec v) { return fd_round4(T{}, v); }          // value a T store will hold
     static __device__ __forceinline__ vec lds_round(vec v) { return v; }                      // value an LDS patch store will hold
 };
@@ -335,6 +341,9 @@ template <typename T> struct fd_lane<T, 8> {
     static __device__ __forceinline__ vec lds_ld(const lds_t *p) { return cvt(*reinterpret_cast<const fd_u16x8 *>(p)); }
     static __device__ __forceinline__ void lds_st(lds_t *p, vec v) { *reinterpret_cast<fd_u16x8 *>(p) = fd_pack8v(T{}, v); }
     static __device__ __forceinline__ void lds_st_raw(lds_t *p, raw r) { *reinterpret_cast<fd_u16x8 *>(p) = r; }
+    // up2(low) + skip, rounded to the storage type.  fp16: four v_pk_add_f16 -- the sum of two fp16 values is exact in fp32, so one fp16 addition
+    // rounds exactly as "convert both, add in fp32, round" does, for 4 instructions instead of 16 conversions + 4 packed adds + 4 packed conversions
+    static __device__ __forceinline__ void lds_st_sum(lds_t *p, raw a, raw b) { *reinterpret_cast<fd_u16x8 *>(p) = fd_sum8(T{}, a, b); }
     static __device__ __forceinline__ vec round(vec v) { return cvt(fd_pack8v(T{}, v)); }
     static __device__ __forceinline__ vec lds_round(vec v) { return cvt(fd_pack8v(T{}, v)); }
 };

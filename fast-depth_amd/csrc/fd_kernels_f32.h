@@ -253,7 +253,7 @@ fd_dwconv(const T *__restrict__ in, const T *__restrict__ skip, const float *__r
             if (px < npx_in) {
                 lds_t *dst = s_in + px * PSTR + c4 * N;
                 // (N = 8: the up2(low) + skip sum is rounded to the storage type on its way into LDS; plain inputs are copied bit for bit)
-                if (MODE == 2) LN::lds_st(dst, ok[u] ? LN::cvt(v[u]) + LN::cvt(sk[u]) : LN::zero());
+                if (MODE == 2) { if (ok[u]) LN::lds_st_sum(dst, v[u], sk[u]); else LN::lds_st(dst, LN::zero()); }
                 else if (ok[u]) LN::lds_st_raw(dst, v[u]);
                 else LN::lds_st(dst, LN::zero());
             }

@@ -527,6 +527,7 @@ struct fd_comm {
     hipEvent_t all_done = nullptr, t0 = nullptr, t1 = nullptr, tb = nullptr;   // t0 / t1: first collective issued / last one finished; tb: backward finished on the compute stream (timing enabled)
     int rank = 0, world = 1;
     bool timed = false;                   // t0 / t1 hold a pair of the last fd_train_backward_allreduce
+    bool elide = false;                   // measurement hook (fd_tuning.h: fd_comm_elide_collectives): everything but the ncclAllReduce calls themselves
 };
 
 extern "C++" {
@@ -598,8 +599,14 @@ int fd_comm_create(const void *id, int32_t rank, int32_t world, fd_comm **out)
     memcpy(uid.internal, id, FD_COMM_ID_BYTES);
     int rc = rccl().CommInitRank(&c->comm, world, uid, rank);          // (on the calling thread's current device, like every entry point here)
     if (rc) { delete c; return rccl_fail("ncclCommInitRank", rc); }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->all_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess || hipEventCreate(&c->tb) != hipSuccess) {
+    // Every event here is consumed by another stream of the SAME device (or only read for its timestamp): a device-scope release.  A default HIP event
+    // performs a SYSTEM-scope fence when it is recorded -- an L2 write-back + invalidate in the middle of backward; measured on one rank: the exchange
+    // machinery cost +155 us per step with default events (6 records per step), with or without the ncclAllReduce calls themselves.
+    // (a default-priority stream: with the highest priority the one-rank step measured 8.6 ms instead of 2.56 -- the hand-over barriers pre-empt the
+    // compute queue)
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->all_done, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&c->t0, hipEventReleaseToDevice) != hipSuccess || hipEventCreateWithFlags(&c->t1, hipEventReleaseToDevice) != hipSuccess ||
+        hipEventCreateWithFlags(&c->tb, hipEventReleaseToDevice) != hipSuccess) {
         fd_comm_destroy(c);
         return fail(FD_ERR_HIP, "fd_comm_create: stream / event creation failed");
     }
@@ -640,7 +647,7 @@ int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *para
     hipStream_t s = static_cast<hipStream_t>(stream);
     while ((int)comm->bucket_done.size() < n_buckets) {
         hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
         comm->bucket_done.push_back(e);
     }
     for (int b = 0; b < n_buckets; ++b) {
@@ -654,11 +661,11 @@ int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *para
         int nrc;
         if (k.grad16) {                                          // 16-bit exchange: convert, all-reduce the bf16 copy, convert back -- all in stream order
             if ((rc = fd_cast_gradients(k.grad, k.grad16, k.numel, 1, comm->stream))) return rc;
-            nrc = rccl().AllReduce(k.grad16, k.grad16, (size_t)k.numel, kNcclBfloat16, kNcclSum, comm->comm, comm->stream);
+            nrc = comm->elide ? 0 : rccl().AllReduce(k.grad16, k.grad16, (size_t)k.numel, kNcclBfloat16, kNcclSum, comm->comm, comm->stream);
             if (nrc) return rccl_fail("ncclAllReduce", nrc);
             if ((rc = fd_cast_gradients(k.grad16, k.grad, k.numel, 0, comm->stream))) return rc;
         } else {
-            nrc = rccl().AllReduce(k.grad, k.grad, (size_t)k.numel, kNcclFloat32, kNcclSum, comm->comm, comm->stream);
+            nrc = comm->elide ? 0 : rccl().AllReduce(k.grad, k.grad, (size_t)k.numel, kNcclFloat32, kNcclSum, comm->comm, comm->stream);
             if (nrc) return rccl_fail("ncclAllReduce", nrc);
         }
     }
@@ -671,6 +678,8 @@ int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *para
     return FD_OK;
 #endif
 }
+
+void fd_comm_elide_collectives(fd_comm *comm, int32_t on) { if (comm) comm->elide = on != 0; }
 
 int fd_comm_last_exchange_ms(fd_comm *comm, float *ms_exchange, float *ms_exposed)
 {

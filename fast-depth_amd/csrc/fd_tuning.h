@@ -42,6 +42,11 @@ void fd_tuning_next(uint32_t mask);
  * re-created conv input.  0 for fp32 plans, the 4-channel form and the register-window kernels.  -1: bad arguments. */
 struct fd_train_plan;
 int fd_train_plan_lds_rounding(const struct fd_train_plan *plan, int32_t layer);
+/* Measurement hook (tools/gpu_round.sh, bench.py with FD_BENCH_FORCE_DIST=2): fd_train_backward_allreduce runs everything -- bucket ranges, event
+ * hand-over to the communicator's stream, casts, the wait of the compute stream -- EXCEPT the ncclAllReduce calls.  On one rank this separates the
+ * cost of the library's own machinery from RCCL's degenerate one-rank collective (a run of small copy / fill kernels).  Only valid on one rank. */
+struct fd_comm;
+void fd_comm_elide_collectives(struct fd_comm *comm, int32_t on);
 #ifdef __cplusplus
 }
 #endif

@@ -270,7 +270,7 @@ class TrainEngine(TrainCore):
     on a side stream as soon as backward has finished a bucket; fd_sgd_step applies grad_scale = 1/n (gradient mean)."""
 
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=None, n_buckets=None, force_buckets=False,
-                 dtype=torch.float32, masked_loss=False, grad_exchange_dtype=torch.float32, exchange="auto", _library=None):
+                 dtype=torch.float32, masked_loss=False, grad_exchange_dtype=torch.float32, exchange="auto", _library=None, _elide_collectives=False):
         """n_buckets: None (default) = two buckets cut by finish time (make_buckets_by_finish); an integer = that many buckets of roughly
         equal bytes (make_buckets).  grad_exchange_dtype: torch.float32 (default: the 15.84 MB fp32 vector is all-reduced in place) or
         torch.bfloat16 (every bucket is converted to bfloat16, all-reduced as 7.92 MB, converted back: half the bytes over xGMI for one
@@ -329,6 +329,10 @@ class TrainEngine(TrainCore):
             with _device_guard(self.device):
                 capi.check(L, L.fd_comm_create(uid.data_ptr(), rank, self.world, ctypes.byref(handle)), "fd_comm_create")
             self.comm = handle
+            if _elide_collectives and self.world == 1:
+                L.fd_comm_elide_collectives.argtypes = [ctypes.c_void_p, ctypes.c_int32]      # measurement hook (csrc/fd_tuning.h), one rank only
+                L.fd_comm_elide_collectives.restype = None
+                L.fd_comm_elide_collectives(handle, 1)
             nb = len(self.buckets)
             self.c_buckets = (capi.GradBucket * nb)()
             for k, (fl, tl) in enumerate(self.buckets):

@@ -27,8 +27,8 @@ echo "== VALU / LDS / wait accounting (SQ counters, own passes)"
 for cfg in infer f16 train_bf16 train_f32; do PMC_OUT=$OUT bash $ROOT/tools/pmc_valu.sh $cfg > /dev/null 2>&1; echo "$cfg valu rc=$?"; done
 echo "== data-parallel machinery on one rank (single vs forced RCCL path, bf16 and fp32 steps, alternating)"
 cd $ROOT
-for rep in 1 2; do for mode in single forced; do for cfg in train_bf16 train_f32; do
-  if [ $mode = forced ]; then export FD_BENCH_FORCE_DIST=1; else unset FD_BENCH_FORCE_DIST; fi
+for rep in 1 2; do for mode in single forced forced_without_the_nccl_calls; do for cfg in train_bf16 train_f32; do
+  if [ $mode = forced ]; then export FD_BENCH_FORCE_DIST=1; elif [ $mode = single ]; then unset FD_BENCH_FORCE_DIST; else export FD_BENCH_FORCE_DIST=2; fi
   echo "$rep $mode $cfg $(timeout 200 python bench.py --only $cfg --steps 50 --warmup 5 2> /dev/null | tail -1)" >> $OUT/dist_overhead.txt
 done; done; done
 unset FD_BENCH_FORCE_DIST; cat $OUT/dist_overhead.txt
