@@ -29,7 +29,7 @@
 #include "fd_host_common.h"
 #include "fd_plan_select.h"
 #include "fd_infer_launch.h"
-#include "fd_plan_build.h"
+#include "fd_plan_build.h"   // (uses FD_G16_STAGES of fd_infer_launch.h)
 
 
 // ==================================================================================================

@@ -1,6 +1,10 @@
 // fd_infer_launch.h -- kernel launches of the inference plan: one function per kernel family, template instance picked from the plan's per-layer record
 // (one translation unit: included by fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
 #pragma once
+#ifndef FD_G16_STAGES
+#define FD_G16_STAGES 4      // depth of fd_pw_gemm16_f32's LDS-DMA ring, issued STAGES - 1 K tiles ahead (build switch for tools/build_variant.py).  Round 4: 4 instead of
+                             // 3 stages (139 KB at TM = 13: still one workgroup per CU, as designed) -- conv7.3 38.0 -> 36.9 us, conv13.3 43.4 -> 41.4, the B = 32 step -1.7 %
+#endif
 namespace {
 
 // ---- launches ------------------------------------------------------------------------------------
@@ -80,8 +84,8 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
             fdw = D.d.ksize;
         }
 #define FD_PW16_LAUNCH(TMV, FD_) \
-        do { (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, 3, ACT, 0, FD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-             FD_LAUNCH((fd_pw_gemm16_f32<TMV, 3, ACT, 0, FD_>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz); } while (0)
+        do { (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, FD_G16_STAGES, ACT, 0, FD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+             FD_LAUNCH((fd_pw_gemm16_f32<TMV, FD_G16_STAGES, ACT, 0, FD_>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz); } while (0)
 #define FD_PW16_CASE(TMV) \
     case TMV: if (fdw == 3) FD_PW16_LAUNCH(TMV, 3); else if (fdw == 5) FD_PW16_LAUNCH(TMV, 5); else FD_PW16_LAUNCH(TMV, 0); break;
         switch (L.pw16_tm) {
