@@ -43,10 +43,10 @@ const char *fd_version(void) { return "fastdepth_hip 0.3 (gfx950; inference f32/
 int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
                    int32_t dtype, uint32_t flags, fd_plan **out_plan)
 {
+    const uint32_t tune = fd_take_tuning();                  // (consumed first: also when the creation fails)
     if (!layers || !out_plan || n_layers <= 0) return fail(FD_ERR_INVALID, "null/empty layer list");
     if (batch <= 0 || height <= 0 || width <= 0 || height % 32 || width % 32)
         return fail(FD_ERR_INVALID, "batch must be > 0 and height/width positive multiples of 32 (got %d, %dx%d)", batch, height, width);
-    const uint32_t tune = fd_take_tuning();                  // (consumed even when the creation fails)
     if (dtype != FD_F32 && dtype != FD_F16 && dtype != FD_BF16) return fail(FD_ERR_INVALID, "unknown dtype %d", dtype);
     if (flags & ~FD_PLAN_ALL_FLAGS) return fail(FD_ERR_INVALID, "unknown plan flag bits 0x%x", flags & ~FD_PLAN_ALL_FLAGS);
     if (tune & ~FD_TUNE_ALL) return fail(FD_ERR_INVALID, "unknown tuning bits 0x%x", tune & ~FD_TUNE_ALL);
