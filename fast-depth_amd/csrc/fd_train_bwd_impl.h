@@ -572,8 +572,9 @@ constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclBfloat16 = 9;    // rccl.h: n
 int fd_comm_unique_id(void *id_out)
 {
 #ifdef FD_EMU
-    (void)id_out;
-    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
+    if (!id_out) return fail(FD_ERR_INVALID, "null argument");
+    memset(id_out, 0, FD_COMM_ID_BYTES);                      // (the CPU emulator's communicator has exactly one rank: no rendezvous)
+    return FD_OK;
 #else
     if (!id_out) return fail(FD_ERR_INVALID, "null argument");
     if (!rccl().ok) return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy)");
@@ -588,8 +589,12 @@ int fd_comm_unique_id(void *id_out)
 int fd_comm_create(const void *id, int32_t rank, int32_t world, fd_comm **out)
 {
 #ifdef FD_EMU
-    (void)id; (void)rank; (void)world; (void)out;
-    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
+    // the CPU emulator build (tests/hipemu) runs the exchange's control flow -- bucket tiling, ranges, the 16-bit casts -- with a one-rank communicator whose
+    // all-reduce is the identity; more ranks need RCCL, i.e. the HIP build
+    if (!id || !out || rank != 0 || world != 1) return fail(FD_ERR_STATE, "the CPU emulator offers a one-rank communicator only (RCCL needs the HIP build)");
+    fd_comm *c = new fd_comm();
+    *out = c;
+    return FD_OK;
 #else
     if (!id || !out || world <= 0 || rank < 0 || rank >= world) return fail(FD_ERR_INVALID, "fd_comm_create: bad argument (rank %d of %d)", rank, world);
     if (!rccl().ok) return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded");
@@ -631,10 +636,6 @@ void fd_comm_destroy(fd_comm *c)
 int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers, const void *dy,
                                 fd_comm *comm, const fd_grad_bucket *buckets, int32_t n_buckets, void *stream)
 {
-#ifdef FD_EMU
-    (void)plan; (void)params; (void)grads; (void)n_layers; (void)dy; (void)comm; (void)buckets; (void)n_buckets; (void)stream;
-    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
-#else
     if (!comm || !buckets || n_buckets <= 0) return fail(FD_ERR_INVALID, "fd_train_backward_allreduce: null communicator / empty bucket list");
     // the buckets must tile the layers n-1 .. 0 in backward order
     int expect = n_layers - 1;
@@ -644,39 +645,50 @@ int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *para
         expect = buckets[b].to_layer - 1;
     }
     if (expect != -1) return fail(FD_ERR_INVALID, "the buckets stop at layer %d: they must cover every layer", expect + 1);
+#ifndef FD_EMU
     hipStream_t s = static_cast<hipStream_t>(stream);
     while ((int)comm->bucket_done.size() < n_buckets) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
         comm->bucket_done.push_back(e);
     }
+#endif
+    // the summing all-reduce of `count` values in place on the communicator's stream (emulator: one rank, the identity)
+    auto all_reduce = [&](void *buf, size_t count, bool bf16) -> int {
+#ifdef FD_EMU
+        (void)buf; (void)count; (void)bf16;
+        return FD_OK;
+#else
+        if (comm->elide) return FD_OK;
+        const int nrc = rccl().AllReduce(buf, buf, count, bf16 ? kNcclBfloat16 : kNcclFloat32, kNcclSum, comm->comm, comm->stream);
+        return nrc ? rccl_fail("ncclAllReduce", nrc) : FD_OK;
+#endif
+    };
     for (int b = 0; b < n_buckets; ++b) {
         const fd_grad_bucket &k = buckets[b];
         int rc = fd_train_backward_range(plan, params, grads, n_layers, dy, k.from_layer, k.to_layer, stream);
         if (rc) return rc;
+#ifndef FD_EMU
         // the bucket's gradients are complete on the compute stream: the collective's stream waits for exactly that point
         if (hipEventRecord(comm->bucket_done[b], s) != hipSuccess || hipStreamWaitEvent(comm->stream, comm->bucket_done[b], 0) != hipSuccess)
             return fail(FD_ERR_HIP, "event hand-over to the communication stream failed");
         if (b == 0) (void)hipEventRecord(comm->t0, comm->stream);
-        int nrc;
+#endif
         if (k.grad16) {                                          // 16-bit exchange: convert, all-reduce the bf16 copy, convert back -- all in stream order
             if ((rc = fd_cast_gradients(k.grad, k.grad16, k.numel, 1, comm->stream))) return rc;
-            nrc = comm->elide ? 0 : rccl().AllReduce(k.grad16, k.grad16, (size_t)k.numel, kNcclBfloat16, kNcclSum, comm->comm, comm->stream);
-            if (nrc) return rccl_fail("ncclAllReduce", nrc);
+            if ((rc = all_reduce(k.grad16, (size_t)k.numel, true))) return rc;
             if ((rc = fd_cast_gradients(k.grad16, k.grad, k.numel, 0, comm->stream))) return rc;
-        } else {
-            nrc = comm->elide ? 0 : rccl().AllReduce(k.grad, k.grad, (size_t)k.numel, kNcclFloat32, kNcclSum, comm->comm, comm->stream);
-            if (nrc) return rccl_fail("ncclAllReduce", nrc);
-        }
+        } else if ((rc = all_reduce(k.grad, (size_t)k.numel, false))) return rc;
     }
+#ifndef FD_EMU
     (void)hipEventRecord(comm->tb, s);
     (void)hipEventRecord(comm->t1, comm->stream);
     comm->timed = true;
     // whatever the caller enqueues next on its stream (fd_sgd_step) runs after the last collective
     if (hipEventRecord(comm->all_done, comm->stream) != hipSuccess || hipStreamWaitEvent(s, comm->all_done, 0) != hipSuccess)
         return fail(FD_ERR_HIP, "event hand-over from the communication stream failed");
-    return FD_OK;
 #endif
+    return FD_OK;
 }
 
 void fd_comm_elide_collectives(fd_comm *comm, int32_t on) { if (comm) comm->elide = on != 0; }

@@ -315,8 +315,8 @@ class TrainEngine(TrainCore):
             raise capi.FastDepthError("exchange must be 'auto', 'library' or 'torch'")
         want_lib = exchange == "library" or (exchange == "auto" and self.use_comm and self.device.type == "cuda" and self.dist.get_backend(process_group) == "nccl")
         if want_lib and self.use_comm:
-            if self.device.type != "cuda":
-                raise capi.FastDepthError("exchange='library' needs a GPU (RCCL)")
+            if self.device.type != "cuda" and _library is None:
+                raise capi.FastDepthError("exchange='library' needs a GPU (RCCL)")          # (a test-only library -- the CPU emulator -- brings its own one-rank communicator)
             L = self.L
             rank = self.dist.get_rank(process_group)
             uid = torch.zeros(128, dtype=torch.uint8)
@@ -327,7 +327,7 @@ class TrainEngine(TrainCore):
             uid = uid_dev.cpu()
             handle = ctypes.c_void_p()
             with _device_guard(self.device):
-                capi.check(L, L.fd_comm_create(uid.data_ptr(), rank, self.world, ctypes.byref(handle)), "fd_comm_create")
+                capi.check(L, L.fd_comm_create(uid.contiguous().data_ptr(), rank, self.world, ctypes.byref(handle)), "fd_comm_create")
             self.comm = handle
             if _elide_collectives and self.world == 1:
                 L.fd_comm_elide_collectives.argtypes = [ctypes.c_void_p, ctypes.c_int32]      # measurement hook (csrc/fd_tuning.h), one rank only
@@ -348,7 +348,8 @@ class TrainEngine(TrainCore):
         """Releases the library's RCCL communicator (a collective call: every rank of the group closes).  Call it before the process group is
         destroyed / the interpreter exits; __del__ only does it as a best effort."""
         if getattr(self, "comm", None):
-            torch.cuda.synchronize(self.device)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
             self.L.fd_comm_destroy(self.comm)
             self.comm = None
 

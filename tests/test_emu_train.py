@@ -283,3 +283,45 @@ def test_autograd_function_returns_gradients():
     autograd_forward(core, x2)
     with pytest.raises(capi.FastDepthError):
         (y_old - tgt).abs().mean().backward()
+
+
+def test_library_exchange_control_flow_on_the_emulator():
+    """fd_train_backward_allreduce's control flow -- bucket tiling check, backward ranges, the bf16 cast -> all-reduce -> cast back -- on the CPU
+    emulator, whose communicator has exactly one rank (its all-reduce is the identity; RCCL itself needs the HIP build: the GPU tier's
+    test_library_issued_rccl_exchange_one_rank).  fp32 exchange: bit-identical to the engine without a group; bf16 exchange: bit-identical to the
+    torch.distributed route (both round every gradient to bfloat16 and back)."""
+    import copy
+    import socket
+    import torch.distributed as dist
+    from fastdepth_hip.train import TrainEngine
+    L = harness.get_lib("emu")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        base = small_model(TINY[0], TINY[1], seed=4).train()
+        g = torch.Generator().manual_seed(3)
+        x, tgt = torch.rand(2, 3, 64, 64, generator=g), 2.0 + torch.rand(2, 1, 64, 64, generator=g)
+
+        def run(**kw):
+            eng = TrainEngine(copy.deepcopy(base), lr=0.01, momentum=0.9, weight_decay=1e-4, _library=L, **kw)
+            return eng, [float(eng.step(x, tgt)) for _ in range(2)]
+        e0, l0 = run()
+        e1, l1 = run(process_group=dist.group.WORLD, force_buckets=True, exchange="library")
+        assert e1.comm is not None and len(e1.buckets) == 2 and l0 == l1
+        assert all(torch.equal(p0, p1) for (_, _, p0), (_, _, p1) in zip(e0.param_list, e1.param_list))
+        e2, l2 = run(process_group=dist.group.WORLD, force_buckets=True, exchange="library", grad_exchange_dtype=torch.bfloat16, dtype=torch.bfloat16)
+        e3, l3 = run(process_group=dist.group.WORLD, force_buckets=True, exchange="torch", grad_exchange_dtype=torch.bfloat16, dtype=torch.bfloat16)
+        assert e2.comm is not None and e3.comm is None and l2 == l3
+        assert all(torch.equal(p2, p3) for (_, _, p2), (_, _, p3) in zip(e2.param_list, e3.param_list))
+        # buckets that do not tile the layers n-1 .. 0 are refused
+        bad = (capi.GradBucket * 2)(capi.GradBucket(e1.n - 1, 9, e1.flat_grad.data_ptr(), 16, None), capi.GradBucket(7, 0, e1.flat_grad.data_ptr(), 16, None))
+        rc = L.fd_train_backward_allreduce(e1._plan.handle, e1._params, e1.c_grads, e1.n, e1._dpred.data_ptr(), e1.comm, bad, 2, None)
+        assert rc == -1 and b"do not continue the backward order" in L.fd_last_error()
+        # more than one rank is RCCL's business
+        h = ctypes.c_void_p()
+        uid = (ctypes.c_ubyte * 128)()
+        assert L.fd_comm_create(uid, 0, 2, ctypes.byref(h)) == -2
+        for e in (e1, e2, e3):
+            e.close()
+    finally:
+        dist.destroy_process_group()
