@@ -19,10 +19,10 @@ static void run(int B, int H, int C, int th, int tw, int abl = 0, size_t extra_l
   std::vector<float> hs(4 * C, 1.0f), hw(9 * C, 0.1f); CK(hipMemcpy(st, hs.data(), hs.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
   const int th_in = th - 1 + K, tw_in = tw - 1 + K;
   const size_t lds = (std::max((size_t)th_in * tw_in * (cb + 4), (size_t)2048) + (size_t)K * K * cb) * 4 + extra_lds;
-  CK(hipFuncSetAttribute((const void *)fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute((const void *)fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   dim3 grid(tiles_x * tiles_y, (C + cb - 1) / cb, B);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto launch = [&]() { hipLaunchKernelGGL((fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2>), grid, dim3(256), lds, 0, zin, st, (const fd_bf16 *)nullptr, (const float *)nullptr, w, zout, part, H, H, H, H, C, 3, th, tw, tiles_x, 0, 36); };
+  auto launch = [&]() { hipLaunchKernelGGL((fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2, 4>), grid, dim3(256), lds, 0, zin, st, (const fd_bf16 *)nullptr, (const float *)nullptr, w, zout, part, H, H, H, H, C, 3, th, tw, tiles_x, 0, 36); };
   for (int i = 0; i < 3; ++i) launch();
   CK(hipEventRecord(e0, 0)); for (int i = 0; i < 20; ++i) launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -44,7 +44,8 @@ int main(int argc, char **argv) {
   }
   for (int abl : {0, 1, 2, 3}) run(32, 112, 32, 8, 16, abl);          // conv1.0: full / no stores / no loads / neither
   for (size_t extra : {(size_t)0, (size_t)6000, (size_t)14000, (size_t)27000, (size_t)54000}) run(32, 112, 32, 8, 16, 0, extra);   // residency 5, 4, 3, 2, 1 (by LDS)
-  for (int abl : {0, 1, 2, 3}) run(32, 14, 512, 7, 16, abl);           // conv7.0
+  for (int abl : {0, 1, 2, 3}) run(32, 14, 512, 14, 16, abl);          // conv7.0 (whole-frame tiles, as the plan selects)
+  for (size_t extra : {(size_t)0, (size_t)8000, (size_t)20000, (size_t)45000, (size_t)100000}) run(32, 14, 512, 14, 16, 0, extra);   // residency by LDS
   run(32, 56, 128, 7, 16);    // conv3.0
   return 0;
 }
