@@ -731,7 +731,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
     vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
     if (c_ok) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
-    constexpr int U = 8;
+    constexpr int U = K == 3 ? FD_DW_U3 : 8;
     fd_px_walk wk(pt, npt, PW);
     for (int base = pt; base < npx; base += npt * U) {
         vec g[U], z[U];
@@ -986,7 +986,7 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     else { s1 = LN::ldf(st1 + FD_ST_SCALE * C1 + tab_l); t1 = LN::ldf(st1 + FD_ST_SHIFT * C1 + tab_l); }
     if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + tab_c); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
-    constexpr int U = 4;
+    constexpr int U = sizeof(T) == 2 ? (K == 3 ? FD_DW_WU3 : FD_DW_WU5) : 4;
     fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
         vec v[U], sk[U];

@@ -27,6 +27,17 @@ __device__ int fd_dw_abl;                                 // ablation bits (micr
 #define FD_DW_ABL(b) false
 #endif
 
+// staging depth of the LDS-tiled depthwise train kernels: patch pixels whose loads a work-item has in flight before it consumes the first (build switches for
+// tools/build_variant.py sweeps).  A patch of more pixels than (pixel-threads x depth) costs a second, dependent round of loads.
+// Measured (round 4, B = 32, paired backward family / step): bf16 plan 575.7 us / 2.513 ms at (8; 4, 4) -> 555.0 / 2.485 at (10; 6, 8); fp32 plan 679.8 / 4.269 ->
+// 678.0 / 4.268 with the deeper forward / backward-data staging alone, 714 / 4.306 with the deeper weight-gradient staging (its fp32 vectors cost registers).
+#ifndef FD_DW_U3
+#define FD_DW_U3 10      // forward / backward-data, 3x3 units (whole-frame 14 x 14 tiles: 9 patch pixels per work-item)
+#endif
+#ifndef FD_DW_WU3
+#define FD_DW_WU3 6      // backward-weights of the 16-bit plans, 3x3 / 5x5 units (fp32 plans: 4)
+#define FD_DW_WU5 8
+#endif
 // per-channel table written by fd_bn_finalize_f32:  [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) invstd
 #define FD_ST_SCALE 0
 #define FD_ST_SHIFT 1
@@ -336,7 +347,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
         if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + cg); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + cg); }
     }
     const int npx_in = TH_in * TW_in;
-    constexpr int U = 8;
+    constexpr int U = K == 3 ? FD_DW_U3 : 8;            // patch pixels in flight per work-item (3x3 whole-frame tiles: 16 x 18 pixels over 32 pixel-threads = 9 each)
     fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in; base += npt * U) {
         vec v[U], sk[U];
