@@ -98,6 +98,60 @@ fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C,
     fd_bn_bwd_finalize_dev(part, nblk, rps, C, n, st, dgamma, dbeta, coef, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
+// BatchNorm-backward finalisation of a unit INSIDE the unit's own first backward kernel (the backward mirror of fd_bn_finalize_block, fd_kernels_train.h):
+// the partial rows (sum G, sum G*xhat) its consumer's backward kernel left are few (<= FD_FIN_MAX_ROWS: the 14 x 14 / 7 x 7 units), so every workgroup
+// sums them for the CB channels of its block -- same fixed order everywhere: identical bits -- and keeps the four coefficients in LDS; the designated
+// workgroup also writes the parameter gradients (dgamma, dbeta) and the table.  Replaces a fd_bn_bwd_finalize_f32 launch at the per-launch floor.
+// sh: >= 4 KiB of LDS that is dead until the next barrier; s_cf: [4][CB] floats (A, C1, MU, C2) that nothing else touches.
+struct fd_bn_bwd_fin {
+    const float *part;               // null: the table `coef` was finalised by its own launch
+    int nblk;
+    int cf_off;                      // byte offset of s_cf in the kernel's dynamic LDS (the plan appends it to the kernel's own request)
+    double n;
+    const float *st;                 // the unit's forward table
+    float *dgamma, *dbeta, *coef;
+};
+
+#ifndef FD_BWD_FIN_U
+#define FD_BWD_FIN_U 4
+#endif
+__device__ __forceinline__ void fd_bn_bwd_finalize_block(const fd_bn_bwd_fin &f, double *sh, float *s_cf, int c0, int CB, int C, int tid, bool writer)
+{
+    const int ch = tid & (CB - 1), rg = tid / CB, RG = 256 / CB;
+    const int c = c0 + ch;
+    const bool ok = c < C;
+    float sc_c = 0.0f, mean_c = 0.0f, invstd_c = 0.0f;
+    if (rg == 0 && ok) { sc_c = f.st[FD_ST_SCALE * C + c]; mean_c = f.st[FD_ST_MEAN * C + c]; invstd_c = f.st[FD_ST_INVSTD * C + c]; }
+    double s = 0.0, q = 0.0;
+    if (ok) {
+        for (int b = rg; b < f.nblk; b += RG * FD_BWD_FIN_U) {      // (FD_BWD_FIN_U rows in flight: the block is inlined into register-heavy kernels)
+            float vs[FD_BWD_FIN_U], vq[FD_BWD_FIN_U];
+#pragma unroll
+            for (int u = 0; u < FD_BWD_FIN_U; ++u) {
+                const int row = b + RG * u < f.nblk ? b + RG * u : f.nblk - 1;
+                vs[u] = f.part[(long)row * 2 * C + c]; vq[u] = f.part[(long)row * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < FD_BWD_FIN_U; ++u)
+                if (b + RG * u < f.nblk) { s += (double)vs[u]; q += (double)vq[u]; }
+        }
+    }
+    sh[2 * tid] = s; sh[2 * tid + 1] = q;
+    __syncthreads();
+    if (rg == 0) {
+        s = 0.0; q = 0.0;
+        for (int r = 0; r < RG; ++r) { s += sh[2 * (r * CB + ch)]; q += sh[2 * (r * CB + ch) + 1]; }
+        const float a = ok ? sc_c : 0.0f, c1 = ok ? (float)(s / f.n) : 0.0f, mu = ok ? mean_c : 0.0f, c2 = ok ? (float)((double)invstd_c * q / f.n) : 0.0f;
+        s_cf[FD_CF_A * CB + ch] = a; s_cf[FD_CF_C1 * CB + ch] = c1; s_cf[FD_CF_MU * CB + ch] = mu; s_cf[FD_CF_C2 * CB + ch] = c2;
+        if (writer && ok) {
+            f.dbeta[c] = (float)s;
+            f.dgamma[c] = (float)q;
+            f.coef[FD_CF_A * C + c] = a; f.coef[FD_CF_C1 * C + c] = c1; f.coef[FD_CF_MU * C + c] = mu; f.coef[FD_CF_C2 * C + c] = c2;
+        }
+    }
+    __syncthreads();
+}
+
 // ---- weight-gradient partials of a whole range of units, reduced by ONE launch at the end of the range (round 1: one launch per unit paired
 // with its BatchNorm-backward finalisation, 36 x ~10 us per step).  Every unit's weight-gradient kernel leaves its partial rows in its
 // own region; entry e describes one unit:  out[j] = sum_b part[b*n + j]  (KK == 0), or the depthwise form
@@ -691,12 +745,13 @@ fd_pw_bwd_f32(const float *__restrict__ G, const float *__restrict__ Z, const fl
 // ------------------------------------------------------------------------------------------------
 // (body: bm = logical (tile, channel block, image) of this workgroup, grid_x = tiles per image -- the plain kernel passes fd_xcd_image_map() /
 // gridDim.x, the paired launch fd_dw_bwd its own numbering)
-template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N, bool FIN = false>     // FIN: instance with the in-kernel BatchNorm-backward finalisation (fd_bn_bwd_fin)
 __device__ __forceinline__ void
 fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x,
+                const fd_bn_bwd_fin &fin)
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
@@ -729,12 +784,13 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
         wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
     vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
-    if (c_ok) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
+    const bool fin_here = FIN && fin.part != nullptr;               // this unit's BatchNorm backward is finalised here, after the first batch of patch loads has been issued
+    if (c_ok && !fin_here) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = K == 3 ? FD_DW_U3 : 8;
     fd_px_walk wk(pt, npt, PW);
-    for (int base = pt; base < npx; base += npt * U) {
-        vec g[U], z[U];
+    for (int base = pt; base < npx || (fin_here && base == pt); base += npt * U) {
+        typename LN::raw g[U], z[U];                        // (storage-typed until they are used: half the registers of a 16-bit plan's batch in flight)
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -746,13 +802,18 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
             {   // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
                 const int qy = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), qx = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
                 const long o = fd_nhwc(n, Ho, qy, Wo, qx, C, (c_ok ? cg : 0));
-                g[u] = LN::ld(G + o); z[u] = LN::ld(Z + o);
+                g[u] = LN::ldraw(G + o); z[u] = LN::ldraw(Z + o);
             }
+        }
+        if (fin_here && base == pt) {
+            float *s_cf = reinterpret_cast<float *>(smem_raw + fin.cf_off);
+            fd_bn_bwd_finalize_block(fin, reinterpret_cast<double *>(smem_raw), s_cf, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
+            if (c_ok) { cA = LN::ldf(s_cf + FD_CF_A * CB + c4 * N); c1 = LN::ldf(s_cf + FD_CF_C1 * CB + c4 * N); cM = LN::ldf(s_cf + FD_CF_MU * CB + c4 * N); c2 = LN::ldf(s_cf + FD_CF_C2 * CB + c4 * N); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            if (px < npx) LN::lds_st(s_dz + px * PSTR + c4 * N, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : LN::zero());
+            if (px < npx) LN::lds_st(s_dz + px * PSTR + c4 * N, ok[u] ? fd_dz4(LN::cvt(g[u]), LN::cvt(z[u]), cA, c1, cM, c2) : LN::zero());
         }
     }
 #pragma unroll
@@ -904,8 +965,9 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr)
 {
+    const fd_bn_bwd_fin no_fin{};
     fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG, N>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit, pstr,
-                                                    fd_xcd_image_map(), (int)gridDim.x);
+                                                    fd_xcd_image_map(), (int)gridDim.x, no_fin);
 }
 
 
@@ -915,12 +977,12 @@ fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__res
 // outputs is staged next to it.  A work-item then owns ONE tap row of 4 channels and walks a share of the output strips; the
 // shares are summed through LDS once per workgroup, which writes wpart[blk][K*K][C].
 // ------------------------------------------------------------------------------------------------
-template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N, bool FIN = false>
 __device__ __forceinline__ void
 fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                 const float *__restrict__ st2, const T *__restrict__ G, const T *__restrict__ Z,
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
-                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, int pstr, const fd_blk3 bm, const int grid_x)
+                int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, int pstr, const fd_blk3 bm, const int grid_x, const fd_bn_bwd_fin &fin)
 {
     constexpr int P = K / 2;
     constexpr int NIN = 3 * S + K;
@@ -987,8 +1049,9 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + tab_c); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
     constexpr int U = sizeof(T) == 2 ? (K == 3 ? FD_DW_WU3 : FD_DW_WU5) : 4;
+    const bool fin_now = FIN && fin.part != nullptr && ti == 0;   // the unit's BatchNorm backward finalised here (every role of a paired launch computes the same bits; role 0 writes them)
     fd_px_walk wk(pt, npt, TW_in);
-    for (int base = pt; base < npx_in; base += npt * U) {
+    for (int base = pt; base < npx_in || (fin_now && base == pt); base += npt * U) {
         vec v[U], sk[U];
         bool ok[U];
 #pragma unroll
@@ -1011,6 +1074,8 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
                 if (MODE == 2) sk[u] = LN::ld(zskip + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             }
         }
+        if (fin_now && base == pt)
+            fd_bn_bwd_finalize_block(fin, reinterpret_cast<double *>(smem_raw), reinterpret_cast<float *>(smem_raw + fin.cf_off), c0, CB, C, tid, false);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
@@ -1027,7 +1092,10 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     // dz of this work-item's output strip (pixel-thread pt stages strip pt: TH*TW/4 <= npt) -> s_dz
     FD_OPAQUE(tab_c);
     {
-        const vec cA = LN::ldf(coef + FD_CF_A * C + tab_c), c1 = LN::ldf(coef + FD_CF_C1 * C + tab_c), cM = LN::ldf(coef + FD_CF_MU * C + tab_c), c2 = LN::ldf(coef + FD_CF_C2 * C + tab_c);
+        const bool cf_lds = FIN && fin.part != nullptr;
+        const float *cf = cf_lds ? reinterpret_cast<const float *>(smem_raw + fin.cf_off) + c4 * N : coef + tab_c;     // [4][CB] in LDS / [4][C] in memory
+        const int cfp = cf_lds ? CB : C;
+        const vec cA = LN::ldf(cf + FD_CF_A * cfp), c1 = LN::ldf(cf + FD_CF_C1 * cfp), cM = LN::ldf(cf + FD_CF_MU * cfp), c2 = LN::ldf(cf + FD_CF_C2 * cfp);
         if (pt < nstrips) {
             const int oy = pt / TWS, ox = (pt - oy * TWS) * 4;
 #pragma unroll
@@ -1081,8 +1149,9 @@ fd_dw_wgrad(const T *__restrict__ zin, const float *__restrict__ st1, const T *_
                 const float *__restrict__ coef, float *__restrict__ wpart, int Hin, int Win, int Ho, int Wo, int C,
                 int cbq, int TH, int TW, int tiles_x, int tpw, int csplit, int pstr)
 {
+    const fd_bn_bwd_fin no_fin{};
     fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2, N>(zin, st1, zskip, st2, G, Z, coef, wpart, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, tpw, csplit, pstr,
-                                                fd_xcd_image_map(), (int)gridDim.x);
+                                                fd_xcd_image_map(), (int)gridDim.x, no_fin);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1115,8 +1184,9 @@ template <typename T> struct fd_dw_bwd_args {
     int d_th, d_tw, d_tiles_x, d_gx, d_gy;             // backward-data: INPUT-space tiles; grid (d_gx tiles, d_gy channel blocks) per image
     int w_th, w_tw, w_tiles_x, w_tpw, w_gx, w_gy;      // backward-weights: OUTPUT-space tiles, tpw of them per workgroup
     int B;
+    fd_bn_bwd_fin fin;                                 // part != null: this unit's BatchNorm backward is finalised by these workgroups (fd_bn_bwd_finalize_block)
 };
-template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG, int N>
+template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG, int N, bool FIN = false>
 __global__ void __launch_bounds__(256)
 fd_dw_bwd(const fd_dw_bwd_args<T> a)
 {
@@ -1124,22 +1194,23 @@ fd_dw_bwd(const fd_dw_bwd_args<T> a)
     fd_blk3 bm = pb.b;
     if (pb.role == 0) {
         bm.y = bm.x / a.d_gx; bm.x -= bm.y * a.d_gx;
-        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG, N>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
-                                                      a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, bm, a.d_gx);
+        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG, N, FIN>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+                                                      a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, bm, a.d_gx, a.fin);
     } else {
         bm.y = bm.x / a.w_gx; bm.x -= bm.y * a.w_gx;
-        fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2, N>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
-                                                    a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, a.pstr, bm, a.w_gx);
+        fd_dw_wgrad_body<T, K, S, MODE, ACT1, ACT2, N, FIN>(a.Zin, a.st_in, a.Zskip, a.st_skip, a.G, a.Z, a.coef, a.wpart, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+                                                    a.w_th, a.w_tw, a.w_tiles_x, a.w_tpw, a.csplit, a.pstr, bm, a.w_gx, a.fin);
     }
 }
 
-template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, int N>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, int N, bool FIN = false>
 __device__ __forceinline__ void
 fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ Zskip, const float *__restrict__ st_skip,
                 const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part, float *__restrict__ wpart,
-                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x)
+                int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x,
+                const fd_bn_bwd_fin &fin)
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;
@@ -1177,12 +1248,13 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
         wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
     vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
-    if (c_ok) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
+    const bool fin_here = FIN && fin.part != nullptr;               // (see fd_dw_dgrad_body)
+    if (c_ok && !fin_here) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = 8;
     fd_px_walk wk(pt, npt, PW);
-    for (int base = pt; base < npx; base += npt * U) {
-        vec g[U], z[U];
+    for (int base = pt; base < npx || (fin_here && base == pt); base += npt * U) {
+        typename LN::raw g[U], z[U];                        // (storage-typed until they are used: half the registers of a 16-bit plan's batch in flight)
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1194,13 +1266,18 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
             {   // branch-free staging (clamped addresses, unconditional loads): see fd_dwconv_train
                 const int qy = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), qx = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
                 const long o = fd_nhwc(n, Ho, qy, Wo, qx, C, (c_ok ? cg : 0));
-                g[u] = LN::ld(G + o); z[u] = LN::ld(Z + o);
+                g[u] = LN::ldraw(G + o); z[u] = LN::ldraw(Z + o);
             }
+        }
+        if (fin_here && base == pt) {
+            float *s_cf = reinterpret_cast<float *>(smem_raw + fin.cf_off);
+            fd_bn_bwd_finalize_block(fin, reinterpret_cast<double *>(smem_raw), s_cf, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
+            if (c_ok) { cA = LN::ldf(s_cf + FD_CF_A * CB + c4 * N); c1 = LN::ldf(s_cf + FD_CF_C1 * CB + c4 * N); cM = LN::ldf(s_cf + FD_CF_MU * CB + c4 * N); c2 = LN::ldf(s_cf + FD_CF_C2 * CB + c4 * N); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
-            if (px < npx) LN::lds_st(s_dz + px * PSTR + c4 * N, ok[u] ? fd_dz4(g[u], z[u], cA, c1, cM, c2) : LN::zero());
+            if (px < npx) LN::lds_st(s_dz + px * PSTR + c4 * N, ok[u] ? fd_dz4(LN::cvt(g[u]), LN::cvt(z[u]), cA, c1, cM, c2) : LN::zero());
         }
     }
     {   // ---- the forward input patch, re-created on load as in fd_dwconv_train: act(z_in * s + t), nearest x2, + / cat skip ----
@@ -1443,12 +1520,12 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
 // both patches once (all loads of a work-item in flight together), runs the backward-data taps and the weight-gradient taps from LDS, and
 // leaves the producer's gradient, its BatchNorm partial sums and one weight-gradient partial row.  Tiles are INPUT-space (TH x TW, multiples of
 // the stride); an output belongs to the tile its receptive field starts in.
-template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, int N>
+template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, int N, bool FIN = false>
 __global__ void __launch_bounds__(256)
 fd_dw_bwd1(const fd_dw_bwd_args<T> a)
 {
-    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG, N>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
-                                                         a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, fd_xcd_image_map(), (int)gridDim.x);
+    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG, N, FIN>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
+                                                         a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, fd_xcd_image_map(), (int)gridDim.x, a.fin);
 }
 
 

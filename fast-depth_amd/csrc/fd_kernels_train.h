@@ -293,6 +293,72 @@ fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// BatchNorm finalisation of the PRODUCER inside its depthwise consumer (<= FD_FIN_MAX_ROWS partial rows: the 14 x 14 / 7 x 7 pointwise units).
+// Every workgroup of the consumer sums the producer's partial rows for the CB channels of its block (256 / CB row groups, all rows
+// of a group in flight, double, fixed order: every workgroup computes the same bits) and derives (scale, shift) into LDS; the
+// workgroup the caller designates (tile 0 of image 0, one per channel block) also writes the table the backward pass reads,
+// the running statistics and num_batches_tracked.  Replaces a fd_bn_finalize_f32 launch (~5 us at the per-launch floor)
+// that sat between the two kernels; the extra work is one more global round trip in front of the patch loads.
+// sh: >= 4 KiB of LDS that is dead until the next barrier; s_st: [2][CB] floats that nothing else touches.
+// ------------------------------------------------------------------------------------------------
+#define FD_FIN_MAX_ROWS 128
+struct fd_bn_fin {
+    const float *part;               // null: the table st1 was finalised by its own launch
+    int nblk;
+    double n, n_unbiased;
+    float eps, momentum;
+    const float *gamma, *beta;
+    float *run_mean, *run_var, *st;
+    long long *nbt;
+};
+
+__device__ __forceinline__ void fd_bn_finalize_block(const fd_bn_fin &f, double *sh, float *s_st, int c0, int CB, int C, int tid, bool writer)
+{
+    const int ch = tid & (CB - 1), rg = tid / CB, RG = 256 / CB;
+    const int c = c0 + ch;
+    const bool ok = c < C;
+    float g_c = 0.0f, b_c = 0.0f, rm_c = 0.0f, rv_c = 0.0f;
+    if (rg == 0 && ok) { g_c = f.gamma[c]; b_c = f.beta[c]; if (writer) { rm_c = f.run_mean[c]; rv_c = f.run_var[c]; } }
+    double s = 0.0, q = 0.0;
+    if (ok) {
+        for (int b = rg; b < f.nblk; b += RG * 8) {
+            float vs[8], vq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = b + RG * u < f.nblk ? b + RG * u : f.nblk - 1;
+                vs[u] = f.part[(long)row * 2 * C + c]; vq[u] = f.part[(long)row * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b + RG * u < f.nblk) { s += (double)vs[u]; q += (double)vq[u]; }
+        }
+    }
+    sh[2 * tid] = s; sh[2 * tid + 1] = q;
+    __syncthreads();
+    if (rg == 0) {
+        s = 0.0; q = 0.0;
+        for (int r = 0; r < RG; ++r) { s += sh[2 * (r * CB + ch)]; q += sh[2 * (r * CB + ch) + 1]; }
+        const double mean = s / f.n;
+        double var = q / f.n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)f.eps);
+        const double sc = (double)g_c * invstd;
+        const float scf = ok ? (float)sc : 0.0f, shf = ok ? (float)((double)b_c - mean * sc) : 0.0f;
+        s_st[ch] = scf; s_st[CB + ch] = shf;
+        if (writer && ok) {
+            f.st[FD_ST_SCALE * C + c] = scf;
+            f.st[FD_ST_SHIFT * C + c] = shf;
+            f.st[FD_ST_MEAN * C + c] = (float)mean;
+            f.st[FD_ST_INVSTD * C + c] = (float)invstd;
+            f.run_mean[c] = (float)((1.0 - f.momentum) * rm_c + f.momentum * mean);
+            f.run_var[c] = (float)((1.0 - f.momentum) * rv_c + f.momentum * var * (f.n_unbiased / (f.n_unbiased - 1.0)));
+            if (c == 0 && f.nbt) f.nbt[0] += 1;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Depthwise K x K, stride S, train mode (LDS-tiled, same geometry as fd_dwconv).
 //   input  = act1(z_in * s1 + t1)                                   (MODE 0)
 //          = up2(act1(z_in * s1 + t1))                              (MODE 1)
@@ -304,7 +370,8 @@ template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N>
 __global__ void __launch_bounds__(256)
 fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                     const float *__restrict__ st2, const float *__restrict__ w, T *__restrict__ zout,
-                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr)
+                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr,
+                    fd_bn_fin fin)
 {
     constexpr int P = K / 2;
     constexpr int UNR_TAPROWS = K == 3 ? 3 : 1;           // 3x3: all tap rows of a strip unrolled (their LDS reads in flight together); 5x5: one row at a time (registers)
@@ -341,15 +408,18 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     const bool from_skip = MODE == 3 && cg >= csplit;
     const int C1 = MODE == 3 ? csplit : C, C2 = MODE == 3 ? C - csplit : C, cl = from_skip ? cg - csplit : cg;
     vec s1 = LN::zero(), t1 = LN::zero(), s2 = LN::zero(), t2 = LN::zero();
+    const int npx_in = TH_in * TW_in;
+    // producer finalised here (MODE 0..2: its table is per channel of this tensor): the (scale, shift) of this block's channels land at the END of the dynamic LDS
+    // (requested AFTER the first batch of patch loads, below: the partial rows' round trip runs under the patch's)
+    const bool fin_here = MODE != 3 && fin.part != nullptr;
     if (c_ok) {
         if (from_skip) { s1 = LN::ldf(st2 + FD_ST_SCALE * C2 + cl); t1 = LN::ldf(st2 + FD_ST_SHIFT * C2 + cl); }
-        else { s1 = LN::ldf(st1 + FD_ST_SCALE * C1 + cl); t1 = LN::ldf(st1 + FD_ST_SHIFT * C1 + cl); }
+        else if (!fin_here) { s1 = LN::ldf(st1 + FD_ST_SCALE * C1 + cl); t1 = LN::ldf(st1 + FD_ST_SHIFT * C1 + cl); }
         if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + cg); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + cg); }
     }
-    const int npx_in = TH_in * TW_in;
     constexpr int U = K == 3 ? FD_DW_U3 : 8;            // patch pixels in flight per work-item (3x3 whole-frame tiles: 16 x 18 pixels over 32 pixel-threads = 9 each)
     fd_px_walk wk(pt, npt, TW_in);
-    for (int base = pt; base < npx_in; base += npt * U) {
+    for (int base = pt; base < npx_in || (fin_here && base == pt); base += npt * U) {      // (every work-item runs the first batch when it carries the finalisation's barriers)
         vec v[U], sk[U];
         bool ok[U];
 #pragma unroll
@@ -372,6 +442,11 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
                 else v[u] = LN::ld(zin + fd_nhwc(n, Hs, (qy >> 1), Ws, (qx >> 1), C1, ql));
                 if (MODE == 2) sk[u] = LN::ld(zskip + fd_nhwc(n, Hin, qy, Win, qx, C, qg));
             }
+        }
+        if (fin_here && base == pt) {
+            float *s_st = s_w + K * K * CB;
+            fd_bn_finalize_block(fin, reinterpret_cast<double *>(smem_raw), s_st, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
+            if (c_ok) { s1 = LN::ldf(s_st + c4 * N); t1 = LN::ldf(s_st + CB + c4 * N); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

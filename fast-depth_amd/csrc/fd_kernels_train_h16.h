@@ -208,6 +208,41 @@ fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__r
     }
 }
 
+// The same map for the units whose BatchNorm-backward partial rows are few (<= FD_FIN_MAX_ROWS: the 14 x 14 / 7 x 7 maps at batch 32), with the
+// finalisation inside (fd_bn_bwd_finalize_block): workgroup (x, y) owns channels [64x, 64x + 64) of the rows 32y + r, 32(y + gridDim.y) + r, ...
+// (a row's 64 channels = 128 bytes = one line: 8 work-items), sums the partial rows of its channels while its first row's loads are in flight, and
+// row y == 0 also writes dgamma / dbeta and the coefficient table.  One launch per unit instead of fd_bn_bwd_finalize_f32 + fd_bn_bwd_apply_h16.
+template <typename T>
+__global__ void __launch_bounds__(256)
+fd_bn_bwd_apply_fin_h16(const T *G, T *DZ, const T *__restrict__ Z, int M, int N, const fd_bn_bwd_fin fin)
+{
+    __shared__ double sh[512];
+    __shared__ float s_cf[4 * 64];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, cl = (tid & 7) * 8;
+    const bool c_ok = c0 + cl < N;                         // N % 8 == 0 (16-bit plans): a work-item's 8 channels are all inside or all outside
+    const long step = (long)gridDim.y * 32;
+    long r = (long)blockIdx.y * 32 + (tid >> 3);
+    const long rq = r < M ? r : M - 1;
+    const long cq = c_ok ? c0 + cl : 0;
+    fd_u16x8 gq = fd_ld8(G + rq * N + cq), zq = fd_ld8(Z + rq * N + cq);
+    fd_bn_bwd_finalize_block(fin, sh, s_cf, c0, 64, N, tid, blockIdx.y == 0);
+    float cA[8], c1[8], cM[8], c2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cA[j] = s_cf[FD_CF_A * 64 + cl + j]; c1[j] = s_cf[FD_CF_C1 * 64 + cl + j]; cM[j] = s_cf[FD_CF_MU * 64 + cl + j]; c2[j] = s_cf[FD_CF_C2 * 64 + cl + j]; }
+    if (!c_ok) return;
+    for (; r < M; r += step) {
+        const long rn = r + step < M ? r + step : r;       // the next row of this work-item, requested before this one is formed
+        const fd_u16x8 gn = fd_ld8(G + rn * N + cq), zn = fd_ld8(Z + rn * N + cq);
+        float g[8], z[8];
+        fd_unpack8(T{}, gq, g);
+        fd_unpack8(T{}, zq, z);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = fd_dz(g[j], z[j], cA[j], c1[j], cM[j], c2[j]);
+        fd_st8(DZ + r * N + cq, fd_pack8(T{}, g));
+        gq = gn; zq = zn;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward-data:  G_in[M][K] = mask_in(y_in) * (dz[M][N] x W[N][K] (+ skipgrad)),  + the producer's BN partials.
 // Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed

@@ -50,13 +50,67 @@ inline int dw_dgrad_cols(const TLayer &L) { return L.d.ksize == 5 ? FD_T_DW5_DTW
 inline int dw_dz_patch(int t, int k, int s) { return (t + k - 2) / s + (s == 2 ? 2 : 1); }
 inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr, int le) { return lds_patch_bytes((long)ph * pw, pstr, le) + (size_t)k * k * cb * 4; }
 
+// Where the BatchNorm-backward partial rows (sum G, sum G*xhat) of unit u are written by its consumer's backward kernels.  A unit that finalises them
+// inside its own first backward kernel (TLayer::bwd_fin, fd_bn_bwd_finalize_block) reads them while that kernel writes its PRODUCER's rows, so such
+// units alternate between two extra buffers; everything else shares the one buffer, as before.
+inline float *bwd_part(fd_train_plan *p, int u) { return tws(p, (u >= 0 && p->layers[u].bwd_fin) ? p->partb_off[u & 1] : p->part_off); }
+
+// the paired depthwise launch has an instance for this unit's kernel size / stride / input composition / activations (dispatch_dw_bwd_pair)
+inline bool dw_bwd_has_pair(const fd_train_plan *p, int i)
+{
+    const TLayer &L = p->layers[i];
+    const TLayer &P = p->layers[L.d.src];
+    const int a1 = P.d.act, a2 = L.d.skip >= 0 ? p->layers[L.d.skip].d.act : FD_ACT_RELU6;
+    const bool add = P.skip_consumer >= 0 && L.mode == 0;
+    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
+    if (a1 == FD_ACT_RELU6 && !add && (key == 310 || key == 320 || key == 510)) return true;
+    if (a1 == FD_ACT_RELU6 && add && key == 320) return true;
+    if (a1 == FD_ACT_RELU && key == 511) return true;
+    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6 && (key == 512 || key == 513)) return true;
+    return false;
+}
+// the stride-2 3x3 units of the large maps run their backward on the two register-window kernels (launch_dw_bwd_pair)
+inline bool dw_bwd_on_rows(const fd_train_plan *p, const TLayer &L)
+{
+    const int cgn = L.d.cin / 4;
+    const bool rows_ok = L.d.ksize == 3 && L.d.stride == 2 && L.mode == 0 && L.d.cin % 4 == 0 && cgn >= 8 && cgn <= 64 && (cgn & (cgn - 1)) == 0 &&
+                         (((long)L.out_h * L.out_w >= 28 * 28 && p->esz == 2) || (p->tune & FD_TUNE_DW_FORCE_ROWS));
+    return rows_ok && !(p->tune & (FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_BWD_PAIR | FD_TUNE_DW_BWD1));
+}
+// plan-time half of TLayer::bwd_fin: the unit's first backward kernel CAN finalise its BatchNorm backward (the LDS-tiled depthwise launches, the
+// apply pass of the 16-bit pointwise units); whether it does is decided per step by the number of partial rows its consumer left (finalize_or_defer)
+inline bool bwd_fin_candidate(const fd_train_plan *p, int i)
+{
+    const TLayer &L = p->layers[i];
+    if ((p->tune & FD_TUNE_NO_CONSUMER_FINALIZE) || L.head || L.d.src < 0) return false;
+    if (L.d.op == FD_OP_PW) return p->esz == 2;
+    // (depthwise units: built and measured, off by default -- bf16 step: the 10 launches it removes are 43 us, the paired kernels get 40 us slower (both roles
+    // sum the rows; 163 VGPRs + 36 bytes of scratch in the 3x3 instance); fp32 step +26 us.  FD_TUNE_DW_BWD_FINALIZE turns it on: tests, A/B)
+    if (L.d.op == FD_OP_DW) return (p->tune & FD_TUNE_DW_BWD_FINALIZE) && !(p->flags & FD_PLAN_NO_BWD_PAIRING) && dw_bwd_has_pair(p, i) && !dw_bwd_on_rows(p, L);
+    return false;
+}
+
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {
     TLayer &L = c.p->layers[i];
     const RedGeom rg = red_geom(nblk, L.d.cout);
-    FD_LAUNCH(fd_bn_bwd_finalize_f32, rg.grid, dim3(1024), 0, c.s, tws(c.p, c.p->part_off), nblk, rg.rps, L.d.cout, L.n_stat,
+    FD_LAUNCH(fd_bn_bwd_finalize_f32, rg.grid, dim3(1024), 0, c.s, bwd_part(c.p, i), nblk, rg.rps, L.d.cout, L.n_stat,
               tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off), red_slices(c.p), red_counters(c.p));
     return check_launch("fd_bn_bwd_finalize_f32");
+}
+// unit u's partial rows are complete (its consumer's backward kernels have been launched): few rows and a capable first kernel -> that kernel finalises them
+// (TLayer::bwd_fin_rows, consumed when unit u is processed -- possibly by a later range call); otherwise the separate launch
+int finalize_or_defer(BwdCtx &c, int u, int nblk)
+{
+    TLayer &U = c.p->layers[u];
+    if (U.bwd_fin && nblk <= FD_FIN_MAX_ROWS) { U.bwd_fin_rows = nblk; return FD_OK; }
+    U.bwd_fin_rows = 0;
+    return bn_bwd_finalize(c, u, nblk);
+}
+inline fd_bn_bwd_fin bwd_fin_args(BwdCtx &c, int i, size_t cf_off)
+{
+    TLayer &L = c.p->layers[i];
+    return fd_bn_bwd_fin{bwd_part(c.p, i), L.bwd_fin_rows, (int)cf_off, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off)};
 }
 
 template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
@@ -77,7 +131,7 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG, NL>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
                   c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
-                  twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, tws(c.p, c.p->part_off),
+                  twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, bwd_part(c.p, L.d.src),
                   L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit, L.bpstr);
     });
     *nblk_out = tiles_x * tiles_y * c.p->B;
@@ -169,7 +223,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.Zskip = Kp ? twt<T>(c.p, Kp->z_off) : nullptr; a.SG = ADD_SG ? twt<T>(c.p, P.sg_off) : nullptr;
     a.Gin = twt<T>(c.p, P.g_off); a.SGout = Kp ? twt<T>(c.p, Kp->sg_off) : nullptr;
     a.coef = tws(c.p, L.coef_off); a.w = c.params[i].conv_weight; a.st_in = tws(c.p, P.st_off); a.st_skip = Kp ? tws(c.p, Kp->st_off) : nullptr;
-    a.part = tws(c.p, c.p->part_off); a.wpart = tws(c.p, L.wp_off);
+    a.part = bwd_part(c.p, L.d.src); a.wpart = tws(c.p, L.wp_off);
     a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.pstr = L.bpstr; a.B = c.p->B;
     // backward-data geometry (launch_dw_dgrad)
     a.d_th = dw_dgrad_rows(c.p, L); a.d_tw = dw_dgrad_cols(L);
@@ -186,18 +240,17 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.w_th = L.bth; a.w_tw = L.btw; a.w_tiles_x = btx; a.w_tpw = tpw; a.w_gx = groups_x * bty; a.w_gy = ceil_div(L.d.cin, cb);
     const int th_in = (L.bth - 1) * S + K, tw_in = (L.btw - 1) * S + K;
     const size_t lds_w = std::max(lds_patch_bytes((long)th_in * tw_in + L.bth * L.btw, L.bpstr, le), (size_t)((256 >> L.cbq) / K) * K * K * cb * 4);
-    const size_t lds = std::max(lds_d, lds_w);
+    size_t lds = align_up(std::max(lds_d, lds_w), 16);
+    if (L.bwd_fin_rows) lds += (size_t)4 * cb * 4;          // + the coefficient block of the in-kernel finalisation (fd_bn_bwd_fin::cf_off)
     if (lds > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 160 KiB", lds);
     const int kk = K * K;
     // The stride-2 3x3 units of the large maps (channel-group count a power of two in 8 ... 64): two register-window kernels without LDS staging
     // (fd_dw3s2_dgrad_rows over input columns, fd_dw3_wgrad_rows over output columns), row strips as high as still leave >= ~1024 workgroups
     {
         const int cgn = L.d.cin / 4;
-        const bool rows_ok = K == 3 && S == 2 && MODE == 0 && L.d.cin % 4 == 0 && cgn >= 8 && cgn <= 64 && (cgn & (cgn - 1)) == 0 &&
-                             (((long)L.out_h * L.out_w >= 28 * 28 && sizeof(T) == 2) || (c.p->tune & FD_TUNE_DW_FORCE_ROWS));
         // measured (us, rows pair vs single-staging kernel): bf16 conv2.0 48.9 + 16.8 vs 79.3, conv4.0 33.4 + 11.0 vs 48.2, conv6.0 (14x14 outputs) 23.4 + 7.8 vs 29.6;
         // fp32 conv2.0 69.0 + 26.7 vs 96.2, conv4.0 40.7 + 15.3 vs 55.2 (equal: both forms move the fp32 bytes at the same rate) -> 16-bit plans, maps >= 28x28
-        if (rows_ok && !(c.p->tune & (FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_BWD_PAIR | FD_TUNE_DW_BWD1))) {
+        if (dw_bwd_on_rows(c.p, L)) {
             L.lds_rounding &= ~2;
             const int gxd = ceil_div((long)L.in_w * cgn, 256), h2 = L.in_h / 2;
             int th2 = h2;
@@ -230,14 +283,20 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
         const int oth = a.d_th / S, otw = a.d_tw / S;
         const int th_in1 = (oth - 1) * S + K, tw_in1 = (otw - 1) * S + K;
         const int ph1 = (a.d_th + K - 2) / S + 2, pw1 = (a.d_tw + K - 2) / S + 2;          // upper bound of the dz patch
-        const size_t lds1 = std::max(lds_patch_bytes((long)ph1 * pw1 + th_in1 * tw_in1, L.bpstr, le) + (size_t)kk * cb * 4, (size_t)((256 >> L.cbq) / K) * kk * cb * 4 + 8192);
+        size_t lds1 = align_up(std::max(lds_patch_bytes((long)ph1 * pw1 + th_in1 * tw_in1, L.bpstr, le) + (size_t)kk * cb * 4, (size_t)((256 >> L.cbq) / K) * kk * cb * 4 + 8192), 16);
+        if (L.bwd_fin_rows) { a.fin = bwd_fin_args(c, i, lds1); lds1 += (size_t)4 * cb * 4; }
         if (lds1 > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward: LDS request %zu exceeds 160 KiB", lds1);
         const int wblk1 = a.d_gx * c.p->B;
         if ((size_t)wblk1 * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
         fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
             constexpr int NL = decltype(nt)::value;
-            (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-            FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
+            if (a.fin.part) {                                 // (the instance with the in-kernel finalisation costs registers: only where it replaces a launch)
+                (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
+            } else {
+                (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, false>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
+            }
         });
         int rc1 = check_launch("fd_dw_bwd1");
         if (rc1) return rc1;
@@ -246,11 +305,17 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     }
     const int wblk = a.w_gx * c.p->B;
     if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+    if (L.bwd_fin_rows) a.fin = bwd_fin_args(c, i, lds - (size_t)4 * cb * 4);
     const long total = (long)c.p->B * ((long)a.d_gx * a.d_gy + (long)a.w_gx * a.w_gy);
     fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
         constexpr int NL = decltype(nt)::value;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL>), dim3((unsigned)total), dim3(256), lds, c.s, a);
+        if (a.fin.part) {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>), dim3((unsigned)total), dim3(256), lds, c.s, a);
+        } else {
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, false>), dim3((unsigned)total), dim3(256), lds, c.s, a);
+        }
     });
     int rc = check_launch("fd_dw_bwd");
     if (rc) return rc;
@@ -292,8 +357,15 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     // dz = BatchNorm-backward(G, z), in place over G: the operand of both GEMMs below
     {
         const long chunks = (long)M * N / 8;
-        FD_LAUNCH((fd_bn_bwd_apply_h16<T>), dim3((unsigned)std::min<long>(4096, ceil_div(chunks, 256))), dim3(256), 0, c.s, Gsrc, G, twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), chunks, N);
-        if ((rc = check_launch("fd_bn_bwd_apply_h16"))) return rc;
+        if (L.bwd_fin_rows) {                                 // few partial rows: the apply pass finalises the unit's BatchNorm backward itself
+            const int gx = ceil_div(N, 64), gy = std::max(1, std::min(ceil_div(M, 32), 1024 / gx));
+            const fd_bn_bwd_fin fa = bwd_fin_args(c, i, 0);
+            FD_LAUNCH((fd_bn_bwd_apply_fin_h16<T>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c.s, Gsrc, G, twt<T>(c.p, L.z_off), M, N, fa);
+            if ((rc = check_launch("fd_bn_bwd_apply_fin_h16"))) return rc;
+        } else {
+            FD_LAUNCH((fd_bn_bwd_apply_h16<T>), dim3((unsigned)std::min<long>(4096, ceil_div(chunks, 256))), dim3(256), 0, c.s, Gsrc, G, twt<T>(c.p, L.z_off), tws(c.p, L.coef_off), chunks, N);
+            if ((rc = check_launch("fd_bn_bwd_apply_h16"))) return rc;
+        }
     }
     // weight gradient: output tiles x pixel splits
     const int n_tiles = ceil_div(N, 64), k_tiles_w = ceil_div(K, 64);
@@ -317,7 +389,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     do {                                                                                                                                           \
         (void)hipFuncSetAttribute((const void *)fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         FD_LAUNCH((fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>), dim3(n_dgrad + (unsigned)(tiles_w * splits)), dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), \
-                  tws(c.p, P.st_off), ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), tws(c.p, L.wp_off), M, N, K, L.n64, \
+                  tws(c.p, P.st_off), ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_part(c.p, L.d.src), tws(c.p, L.wp_off), M, N, K, L.n64, \
                   m_tiles, k_tiles, (int)n_dgrad, k_tiles_w, tiles_w, rows);                                                                       \
     } while (0)
         if (add) { if (tn == 2) FD_PWBWD_H16(1, 2); else FD_PWBWD_H16(1, 1); }
@@ -340,7 +412,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     do {                                                                                                                                           \
         (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);    \
         FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>), grid, dim3(256), lds_d, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off), \
-                  ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, L.n64, m_tiles, k_tiles);          \
+                  ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_part(c.p, L.d.src), M, N, K, L.n64, m_tiles, k_tiles);          \
     } while (0)
         if (add) { if (tn == 2) FD_DGRAD_H16(1, 2); else FD_DGRAD_H16(1, 1); }
         else { if (tn == 2) FD_DGRAD_H16(0, 2); else FD_DGRAD_H16(0, 1); }
@@ -376,11 +448,11 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         if (add) {
             (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 1>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      tws(c.p, P.sg_off), tws(c.p, P.g_off), tws(c.p, c.p->part_off), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_part(c.p, L.d.src), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
         } else {
             (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 0>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      (const float *)nullptr, tws(c.p, P.g_off), tws(c.p, c.p->part_off), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+                      (const float *)nullptr, tws(c.p, P.g_off), bwd_part(c.p, L.d.src), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
         }
         if ((rc = check_launch("fd_pw_bwd_f32"))) return rc;
         return defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
@@ -397,11 +469,11 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         if (add) {
             (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
             FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 1>), grid, dim3(256), lds_d, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      tws(c.p, P.sg_off), tws(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, m_tiles, k_tiles);
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_part(c.p, L.d.src), M, N, K, m_tiles, k_tiles);
         } else {
             (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
             FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 0>), grid, dim3(256), lds_d, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      (const float *)nullptr, tws(c.p, P.g_off), tws(c.p, c.p->part_off), M, N, K, m_tiles, k_tiles);
+                      (const float *)nullptr, tws(c.p, P.g_off), bwd_part(c.p, L.d.src), M, N, K, m_tiles, k_tiles);
         }
         return check_launch("fd_pw_dgrad_f32");
     }
@@ -414,7 +486,6 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
     constexpr bool F32 = std::is_same<T, float>::value;
     BwdCtx c{plan, params, grads, static_cast<hipStream_t>(stream)};
     hipStream_t s = c.s;
-    float *part = tws(plan, plan->part_off);
     int rc;
     // ---- head
     const int hi = n_layers - 1;
@@ -423,8 +494,8 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
     if (from_layer == hi) {
         g_trace_layer = hi;
         const int nb = ceil_div(Hd.M, 256);
-        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
-        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), part, Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_part(plan, hi), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_part(plan, hi), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
         if ((rc = check_launch("fd_head_bwd_reduce_f32"))) return rc;
         if ((rc = bn_bwd_finalize(c, hi, nb))) return rc;
         constexpr int PPB = 16;
@@ -432,12 +503,12 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         const size_t lds = (size_t)32 * Hd.d.cin * 3 * 4;
         float *wpart = tws(plan, Hd.wp_off);
         if ((size_t)nb2 * Hd.d.cin > Hd.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small for the head");
-        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
-        else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), part, wpart, Hd.M, Hd.d.cin);
+        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), bwd_part(plan, Hd.d.src), wpart, Hd.M, Hd.d.cin);
+        else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), bwd_part(plan, Hd.d.src), wpart, Hd.M, Hd.d.cin);
         if ((rc = check_launch("fd_head_bwd"))) return rc;
         if ((rc = defer_weights(c, wpart, nb2, Hd.d.cin, 0, 0, grads[hi].conv_weight))) return rc;
         // the BN partials of the head's producer are now in `part` (nb2 workgroups)
-        if ((rc = bn_bwd_finalize(c, Hd.d.src, nb2))) return rc;
+        if ((rc = finalize_or_defer(c, Hd.d.src, nb2))) return rc;
     }
     // ---- remaining units in reverse order; invariant: coef_i and the BN grads of unit i are final when unit i is processed
     for (int i = std::min(hi - 1, (int)from_layer); i >= to_layer; --i) {
@@ -461,7 +532,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
                 bool paired = false;
                 if ((rc = dispatch_dw_bwd_pair<T>(c, i, &nblk, &paired))) return rc;
                 if (paired) {
-                    if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+                    if ((rc = finalize_or_defer(c, d.src, nblk))) return rc;
                     break;
                 }
             }
@@ -471,7 +542,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             if (P.d.act == FD_ACT_RELU6) rc = add ? dispatch_dw_dgrad<T, FD_ACT_RELU6_, 1>(c, i, &nblk) : dispatch_dw_dgrad<T, FD_ACT_RELU6_, 0>(c, i, &nblk);
             else rc = add ? dispatch_dw_dgrad<T, FD_ACT_RELU_, 1>(c, i, &nblk) : dispatch_dw_dgrad<T, FD_ACT_RELU_, 0>(c, i, &nblk);
             if (rc) return rc;
-            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+            if ((rc = finalize_or_defer(c, d.src, nblk))) return rc;
             break;
         }
         case FD_OP_PW: {
@@ -479,7 +550,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             if constexpr (F32) rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd<FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd<FD_ACT_RELU_>(c, i, &nblk);
             else rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd_h16<T, FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd_h16<T, FD_ACT_RELU_>(c, i, &nblk);
             if (rc) return rc;
-            if ((rc = bn_bwd_finalize(c, d.src, nblk))) return rc;
+            if ((rc = finalize_or_defer(c, d.src, nblk))) return rc;
             break;
         }
         }

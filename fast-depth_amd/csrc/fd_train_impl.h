@@ -63,6 +63,9 @@ struct TLayer {
     size_t lds = 0;
     dim3 grid;
     int nblk = 0;                    // reduction partials this unit's forward kernel writes
+    bool bwd_fin = false;            // the unit's first backward kernel can finalise its BatchNorm backward (bwd_fin_candidate); its partial rows live in partb_off[i & 1]
+    mutable int bwd_fin_rows = 0;    // > 0: it does so in this step -- that many partial rows are waiting (set when the consumer's backward kernels were launched)
+    bool fin_by_consumer = false;    // pointwise unit with <= FD_FIN_MAX_ROWS partial rows whose LDS-tiled depthwise consumer finalises its BatchNorm (no fd_bn_finalize_f32 launch)
     size_t z_off = 0, z_elems = 0;   // raw output
     size_t st_off = 0;               // [4][C] table
     size_t coef_off = 0;             // backward coefficient table [4][C]
@@ -86,6 +89,7 @@ struct fd_train_plan {
     int B = 0, H = 0, W = 0, dtype = FD_F32;
     uint32_t flags = 0, tune = 0;    // public plan flags (include/fastdepth_hip.h) / private tuning mask (fd_tuning.h)
     size_t esz = 4;                  // bytes per stored activation / activation-gradient element
+    size_t partb_off[2] = {0, 0};    // partial rows of the units finalised inside a kernel that writes the next rows meanwhile: forward [0]; backward [unit & 1]
     size_t ws_bytes = 0, part_off = 0, part_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
     unsigned char *ws = nullptr;
     bool forward_done = false;
@@ -95,6 +99,7 @@ struct fd_train_plan {
 
 namespace {
 
+inline bool bwd_fin_candidate(const fd_train_plan *p, int i);    // (fd_train_bwd_impl.h)
 inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
 template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reinterpret_cast<T *>(p->ws + off); }
 
@@ -122,7 +127,7 @@ inline size_t lds_patch_bytes(long npx, int pstr, int le) { return std::max(alig
 
 template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
-                    T *zout, float *part, hipStream_t s, int batch)
+                    T *zout, float *part, hipStream_t s, int batch, const fd_bn_fin &fin)
 {
     L.lds_rounding = (L.lds_rounding & ~1) | ((!L.rows_th && L.dw_n == 8) ? 1 : 0);
     if (L.rows_th) {                                          // register-window kernel (3x3, plain input, large maps)
@@ -137,7 +142,7 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
             constexpr int NL = decltype(nt)::value;                                                                         \
             if (L.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
             FD_LAUNCH((fd_dwconv_train<T, K_, S_, M_, ACT1, ACT2, NL>), L.grid, dim3(256), L.lds, s, zin, st1, zskip, st2, w, zout, part, \
-                      L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr);            \
+                      L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, L.th, L.tw, L.tiles_x, L.csplit, L.pstr, fin);       \
         });                                                                                                                  \
         break;
     switch (key) {
@@ -152,12 +157,12 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
 // the skip tensor's activation, always an encoder unit)
 template <typename T>
 int dispatch_dw_train(const TLayer &L, int act1, int act2, const T *zin, const float *st1, const T *zskip, const float *st2,
-                      const float *w, T *zout, float *part, hipStream_t s, int batch)
+                      const float *w, T *zout, float *part, hipStream_t s, int batch, const fd_bn_fin &fin)
 {
-    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
-    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
-    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
-    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s, batch);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch, fin);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch, fin);
+    if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s, batch, fin);
+    if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU_>(L, zin, st1, zskip, st2, w, zout, part, s, batch, fin);
     return fail(FD_ERR_INVALID, "train: unsupported producer activations %d/%d", act1, act2);
 }
 
@@ -203,6 +208,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         const T *zin = P ? twt<T>(plan, P->z_off) : nullptr;
         const float *st1 = P ? tws(plan, P->st_off) : nullptr;
         int rc = FD_OK;
+        float *part_i = L.fin_by_consumer ? tws(plan, plan->partb_off[0]) : part;
         switch (d.op) {
         case FD_OP_STEM:
             FD_LAUNCH((fd_stem_train<T>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, L.in_h, L.in_w, d.cout, (int)(L.lds / 4) - 4 * 2 * 32);
@@ -210,8 +216,14 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
             break;
         case FD_OP_DW: {
             const TLayer *K = d.skip >= 0 ? &plan->layers[d.skip] : nullptr;
+            fd_bn_fin fin{};
+            if (P->fin_by_consumer) {                         // the producer's finalisation runs in this kernel (fd_bn_finalize_block)
+                const fd_layer_params &pq = params[d.src];
+                fin = fd_bn_fin{tws(plan, plan->partb_off[0]), P->nblk, P->n_stat, P->n_unbiased, bn_eps, bn_momentum, pq.bn_weight, pq.bn_bias,
+                                const_cast<float *>(pq.bn_mean), const_cast<float *>(pq.bn_var), tws(plan, P->st_off), reinterpret_cast<long long *>(pq.bn_num_batches_tracked)};
+            }
             rc = dispatch_dw_train<T>(L, P->d.act, K ? K->d.act : FD_ACT_RELU6, zin, st1, K ? twt<T>(plan, K->z_off) : (const T *)nullptr,
-                                      K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s, plan->B);
+                                      K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s, plan->B, fin);
             break;
         }
         case FD_OP_PW:
@@ -223,15 +235,15 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
                 rc = check_launch("fd_head_train");
             } else {
                 if constexpr (F32) {
-                    if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
-                    else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                    if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part_i, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                    else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part_i, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
                     rc = check_launch("fd_pw_gemm_train_f32");
                 } else {
                     T *wt = twt<T>(plan, L.wt_off);      // 16-bit operand copies of the master weights: made for all units at the start of the step
 #define FD_PWT_H16(ACTV, TNV)                                                                                                                     \
     do {                                                                                                                                          \
         (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, ACTV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);     \
-        FD_LAUNCH((fd_pw_gemm_train_h16<T, ACTV, TNV>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles); \
+        FD_LAUNCH((fd_pw_gemm_train_h16<T, ACTV, TNV>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part_i, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles); \
     } while (0)
                     if (P->d.act == FD_ACT_RELU6) { if (L.pw_tn == 2) FD_PWT_H16(FD_ACT_RELU6_, 2); else FD_PWT_H16(FD_ACT_RELU6_, 1); }
                     else { if (L.pw_tn == 2) FD_PWT_H16(FD_ACT_RELU_, 2); else FD_PWT_H16(FD_ACT_RELU_, 1); }
@@ -242,6 +254,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
             break;
         }
         if (rc) return rc;
+        if (L.fin_by_consumer) continue;
         const RedGeom rg = red_geom(L.nblk, d.cout);
         FD_LAUNCH(fd_bn_finalize_f32, rg.grid, dim3(1024), 0, s, part, L.nblk, rg.rps, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
                   q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off), red_slices(plan), red_counters(plan),
@@ -381,6 +394,15 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                     L.lds = 0;
                 }
             }
+            if (d.src == i - 1 && !L.rows_th && L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE)) {
+                // the pointwise producer's BatchNorm is finalised by this kernel's workgroups (fd_bn_finalize_block) when its partial rows are few:
+                // the 14 x 14 / 7 x 7 units at B = 32 (98 / 25 rows) -- one launch at the per-launch floor less per unit
+                TLayer &P = p->layers[d.src];
+                if (P.d.op == FD_OP_PW && !P.head && P.nblk <= FD_FIN_MAX_ROWS) {
+                    P.fin_by_consumer = true;
+                    L.lds += (size_t)2 * cb * 4;
+                }
+            }
             const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
                 // up to 8 rows) -- sized for the larger count
@@ -477,9 +499,12 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     }
     // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
     p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
+    p->partb_off[0] = off; off += p->part_bytes;
+    p->partb_off[1] = off; off += p->part_bytes;
     // slice sums (double) of the fused two-level reductions: ceil(rows / 64) x 2 x width, bounded through rows x width <= the partial buffers
     p->part2_off = off; p->part2_bytes = align_up((2 * max_part / 16 + max_wpart / 16 + 8 * std::max(max_width, (size_t)1) + 128) * 8, 256); off += p->part2_bytes;   // two reductions can share a launch
     p->cnt_off = off; p->cnt_bytes = align_up((2 * ceil_div((long)std::max(max_width, (size_t)1), 64) + 2) * 4, 256); off += p->cnt_bytes;   // arrival counters, one per 64 columns
+    for (int i = 0; i < n_layers; ++i) p->layers[i].bwd_fin = bwd_fin_candidate(p, i);
     p->ws_bytes = off;
     *out_plan = p;
     return FD_OK;

@@ -29,7 +29,12 @@
 #define FD_TUNE_FORCE_DW_H8 131072u       /* 16-bit plans: storage-typed LDS patches and 8 channels (16 bytes) per work-item (fd_lane<T, 8>) on every eligible
                                              LDS-tiled depthwise kernel, inference and train (default: only where it was measured to pay -- the 5x5
                                              inference units on maps >= 56x56; tests and A/B runs) */
-#define FD_TUNE_ALL 262143u
+#define FD_TUNE_NO_CONSUMER_FINALIZE 262144u /* train plans: every BatchNorm is finalised by its own fd_bn_finalize_f32 launch (default: the depthwise consumer of a
+                                             pointwise unit with <= 128 partial rows finalises it, fd_bn_finalize_block; backward: the
+                                             apply pass of a 16-bit pointwise unit with <= 128 partial rows, fd_bn_bwd_apply_fin_h16) */
+#define FD_TUNE_DW_BWD_FINALIZE 524288u    /* train plans: the LDS-tiled depthwise backward launches finalise their unit's BatchNorm backward themselves when its partial
+                                             rows are <= 128 (fd_bn_bwd_finalize_block; default: only the apply pass of the 16-bit pointwise units does) */
+#define FD_TUNE_ALL 1048575u
 
 #ifdef __cplusplus
 extern "C" {

@@ -151,6 +151,7 @@ def test_train_engine_dp_world2_matches_shard_averaged_oracle(tmp_path):
         assert torch.equal(r[0]["after1"][k], r[1]["after1"][k]) and torch.equal(r[0]["after2"][k], r[1]["after2"][k]), k
     assert torch.equal(r[0]["mom"], r[1]["mom"])
     assert int(r[0]["after2"]["conv0.1.num_batches_tracked"]) == 2 and int(r[1]["after1"]["decode_conv6.1.num_batches_tracked"]) == 1   # incremented by the kernels' tails
+    assert int(r[0]["after2"]["conv7.4.num_batches_tracked"]) == 2 and int(r[1]["after1"]["conv13.4.num_batches_tracked"]) == 1       # (finalised inside the consuming depthwise kernel)
     assert not torch.equal(r[0]["after1"]["conv3.1.running_mean"], r[1]["after1"]["conv3.1.running_mean"])
     assert all(np.isfinite(v).all() for v in (r[0]["losses"], r[1]["losses"]))
     # (1) same kernels, single process, gradients averaged by hand

@@ -158,7 +158,13 @@ def assert_local_parity(rep, dtype):
                                                    ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_FORCE_ROWS), ("tiny_tall", TINY, torch.bfloat16, capi.FD_TUNE_DW_FORCE_ROWS),
                                                    # fd_lane<T, 8>: bf16 LDS patches, 8 channels per work-item -- paired launch / single-staging kernel, ragged channel counts
                                                    ("ragged", RAGGED, torch.bfloat16, capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_BWD_PAIR),
-                                                   ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_BWD1)])
+                                                   ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_BWD1),
+                                                   # every BatchNorm finalised by its own launch (default at this size: inside the consuming depthwise kernel /
+                                                   # the unit's own first backward kernel, fd_bn_finalize_block / fd_bn_bwd_finalize_block)
+                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_NO_CONSUMER_FINALIZE),
+                                                   # ... and the depthwise backward launches finalising their own unit too (off by default: measured no faster)
+                                                   ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_BWD_FINALIZE), ("ragged", RAGGED, torch.bfloat16, capi.FD_TUNE_DW_BWD_FINALIZE | capi.FD_TUNE_DW_BWD1),
+                                                   ("ragged", RAGGED, torch.bfloat16, capi.FD_TUNE_NO_CONSUMER_FINALIZE)])
 def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     """Every unit's forward and backward kernels on their own stored inputs against an fp64 single-unit autograd reference
     (harness.local_train_parity): the rigorous check of the bf16 train plan, whose end-to-end
