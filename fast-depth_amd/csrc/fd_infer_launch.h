@@ -85,7 +85,7 @@ int launch_pw(const fd_plan *plan, const Layer &L, const float *A, const float *
         }
 #define FD_PW16_LAUNCH(TMV, FD_) \
         do { (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, FD_G16_STAGES, ACT, 0, FD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
-             FD_LAUNCH((fd_pw_gemm16_f32<TMV, FD_G16_STAGES, ACT, 0, FD_>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz); } while (0)
+             FD_LAUNCH((fd_pw_gemm16_f32<TMV, FD_G16_STAGES, ACT, 0, FD_>), L.grid, dim3(512), L.lds, s, A, wp, bias, out, (int)M, N, K, L.w_pitch, L.pw16_stride, L.m_tiles, L.n_tiles, fz, fd_g16_train{}); } while (0)
 #define FD_PW16_CASE(TMV) \
     case TMV: if (fdw == 3) FD_PW16_LAUNCH(TMV, 3); else if (fdw == 5) FD_PW16_LAUNCH(TMV, 5); else FD_PW16_LAUNCH(TMV, 0); break;
         switch (L.pw16_tm) {

@@ -49,20 +49,35 @@ struct fd_dwfuse {
 __device__ long long fd_gemm16_probe[4 * 4096];          // measurement aid (tools/microbench/gemm16.hip): shader-clock and 100 MHz timestamps per workgroup
 #endif
 
+// Train-mode forward (TRAIN = the PRODUCER's activation, FD_ACT_RELU_ / FD_ACT_RELU6_; 0 = inference): the same kernel with
+//   * A = the producer's RAW output: every A fragment becomes act(a * s[k] + t[k]) right before its first MFMA (the producer's BatchNorm table,
+//     zero beyond K, sits in LDS behind the ring; a lane's four k of a K tile are the same for all TM fragments: two ds_read_b128 per K tile);
+//   * Wt = the LIVE weights [N][K] (K % 32 == 0: pitch K32 = K), no bias, no activation: the RAW conv output leaves the kernel;
+//   * the epilogue adds the per-column partial statistics of the tile's valid rows, part[mt*2*N + {0, N} + col] (fd_bn_finalize_f32 / _block).
+// Replaces fd_pw_gemm_train_f32 (the 32x32x2 structure) on the units one round of workgroups covers -- the 14x14 / 7x7 maps at batch 32.
+#ifndef FD_G16_TRAIN_AHEAD
+#define FD_G16_TRAIN_AHEAD 2       // (0 / 2 / 4 measured equal: 42.4 / 42.2 / 42.5 us on the 512 x 512 units -- the cost of the transform is its instruction count, not its latency)
+#endif
+struct fd_g16_train {
+    const float *st;           // the producer's table [4][K] (scale, shift, mean, invstd)
+    float *part;               // partial statistics rows of THIS unit
+};
+
 // ABL (measurement aid, 0 in the product): 1 = no LDS-DMA in the steady state (stages keep the first tiles), 2 = also no fragment reads,
 // 3 = also no per-tile barrier, 4 = full K loop but no global stores -- wrong results, used by tools/microbench/gemm16.hip to price each
 // ingredient of the kernel.
-template <int TM, int STAGES, int ACT, int ABL = 0, int FDW = 0>
+template <int TM, int STAGES, int ACT, int ABL = 0, int FDW = 0, int TRAIN = 0>
 __global__ void __launch_bounds__(512)
 fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, const float *__restrict__ bias,
-                 float *__restrict__ out, int M, int N, int K, int K32, int m_stride, int m_tiles, int n_tiles, const fd_dwfuse fz)
+                 float *__restrict__ out, int M, int N, int K, int K32, int m_stride, int m_tiles, int n_tiles, const fd_dwfuse fz, const fd_g16_train tr)
 {
+    static_assert(TRAIN == 0 || (FDW == 0 && ACT == 0), "train mode: raw output, no fused consumer");
     constexpr int BM = TM * 16, BN = 64, BK = 32, ROWS = BM + BN;
     constexpr int STAGE = ROWS * BK;                        // floats per stage
     constexpr int NG = ROWS / 8;                            // LDS-DMA row groups (8 rows = 1 KiB) per stage
     constexpr int RG = (NG + 3) / 4;                        // per leader wave (a leader without an own group in the last round repeats its first)
     constexpr int OP = BN + 4;                              // row pitch (floats) of the output tile image in LDS
-    static_assert(STAGES * STAGE >= BM * OP, "the output tile image must fit the ring");
+    static_assert(STAGES * STAGE >= BM * OP + (TRAIN != 0 ? 8 * 2 * 64 : 0), "the output tile image (+ the statistics scratch) must fit the ring");
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -109,7 +124,7 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
 
     // ---- accumulators: the leader starts at the folded-BN bias of its column, the follower at 0 ----
     const int col = n0 + wn * 16 + (lane & 15);
-    const float bv = (leader && col < N) ? bias[col] : 0.0f;
+    const float bv = (TRAIN == 0 && leader && col < N) ? bias[col] : 0.0f;
     fd_f32x4 acc[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) { acc[i].x = bv; acc[i].y = bv; acc[i].z = bv; acc[i].w = bv; }
@@ -123,6 +138,20 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
 
     const int T = K32 / BK;
     fd_f32x4 fa[2][TM], fb[2];
+    float *tab = smem + STAGES * STAGE;                      // TRAIN: [2][K32] scale / shift of the producer (0 beyond K)
+    fd_f32x4 sv[2], tv[2];                                   // ... of this lane's four k of the K tile in fragment buffer 0 / 1
+    // (requested now, stored to LDS after the prologue's LDS-DMA has been issued: the table's round trip runs under the first tiles' -- the loads are OLDER
+    // than every DMA piece, so the prologue's counted vmcnt wait covers them)
+    constexpr int TABQ = 2;                                  // K32 <= 1024 (checked by the plan)
+    float tsc[TABQ], tsh[TABQ];
+    if (TRAIN != 0) {
+#pragma unroll
+        for (int j = 0; j < TABQ; ++j) {
+            const int k = tid + 512 * j, kc = k < K ? k : 0;
+            const float a = tr.st[kc], b = tr.st[K + kc];     // FD_ST_SCALE = 0, FD_ST_SHIFT = 1 (fd_kernels_train.h)
+            tsc[j] = k < K ? a : 0.0f; tsh[j] = k < K ? b : 0.0f;
+        }
+    }
     // One K tile: 4*TM MFMAs on the fragments in buffer B with the loads spread through the MFMA stream: the leader's DMA pieces of
     // tile t+STAGES first, then (both roles) the fragment reads of tile t+1.  The uniform branches also pin the instruction order.
     auto step = [&](auto buf, auto role, int t) {
@@ -136,9 +165,16 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
             fd_block_barrier_lds();                          // ... for every leader, and every wave has finished reading tile t's fragments
         }
         const float *nxa = smem + ((t + 1) % STAGES) * STAGE + a_off0, *nxb = smem + ((t + 1) % STAGES) * STAGE + b_off;
+        if (TRAIN != 0 && do_frags) { sv[1 - B] = fd_ld4(tab + (t + 1) * BK + chunk * 4); tv[1 - B] = fd_ld4(tab + K32 + (t + 1) * BK + chunk * 4); }
 #pragma unroll
         for (int idx = 0; idx < 4 * TM; ++idx) {
             const int q = idx / TM, i = idx % TM;
+            // BatchNorm + activation of the producer on the A fragments, FD_G16_TRAIN_AHEAD MFMAs before a fragment's first use (its VALU latency never meets the matrix pipe)
+            if (TRAIN != 0 && idx == 0) {
+#pragma unroll
+                for (int j = 0; j < FD_G16_TRAIN_AHEAD && j < TM; ++j) fa[B][j] = fd_act4<TRAIN>(fa[B][j] * sv[B] + tv[B]);
+            }
+            if (TRAIN != 0 && q == 0 && i + FD_G16_TRAIN_AHEAD < TM) fa[B][i + FD_G16_TRAIN_AHEAD] = fd_act4<TRAIN>(fa[B][i + FD_G16_TRAIN_AHEAD] * sv[B] + tv[B]);
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[B][i][q], fb[B][q], acc[i], 0, 0, 0);
             if ((idx + 1) % SP == 0) {
                 const int l = (idx + 1) / SP - 1;            // load slot
@@ -162,11 +198,18 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
             }
         if (T >= STAGES) fd_wait_vmcnt<(STAGES - 1) * RG>(); else fd_wait_vmcnt<0>();
     }
-    fd_block_barrier();
+    if (TRAIN != 0) {
+#pragma unroll
+        for (int j = 0; j < TABQ; ++j) { const int k = tid + 512 * j; if (k < K32) { tab[k] = tsc[j]; tab[K32 + k] = tsh[j]; } }
+        fd_block_barrier_lds();
+    } else {
+        fd_block_barrier();
+    }
     {
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = fd_ld4(smem + a_off0 + i * 16 * BK);
         fb[0] = fd_ld4(smem + b_off);
+        if (TRAIN != 0) { sv[0] = fd_ld4(tab + chunk * 4); tv[0] = fd_ld4(tab + K32 + chunk * 4); }
     }
     if (leader) {
 #ifndef FD_EMU
@@ -246,6 +289,22 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
     if ((FDW == 0 || fz.store_pw) && n0 + c4 < N) {          // N % 4 == 0: a lane's 4 columns are all inside or all outside
         for (int r = wave * 4 + (lane >> 4); r < rows; r += 32)
             fd_st4(out + (m0 + r) * N + n0 + c4, fd_ld4(smem + (FDW != 0 ? rowmap[r] : r) * OP + c4));
+    }
+    if (TRAIN != 0) {
+        // partial statistics of the tile: column c = tid & 63, the rows dealt to 8 row lanes (fixed order), which meet behind the image in LDS
+        float *red = smem + BM * OP;                         // [8][2][64]
+        const int c = tid & 63, g = tid >> 6;
+        float ssum = 0.0f, ssq = 0.0f;
+        for (int r = g; r < rows; r += 8) { const float v = smem[r * OP + c]; ssum += v; ssq = fmaf(v, v, ssq); }
+        red[(g * 2 + 0) * 64 + c] = ssum; red[(g * 2 + 1) * 64 + c] = ssq;
+        __syncthreads();
+        if (tid < 64 && n0 + tid < N) {
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) { a += red[(gg * 2 + 0) * 64 + tid]; b += red[(gg * 2 + 1) * 64 + tid]; }
+            tr.part[(long)mt * 2 * N + n0 + tid] = a;
+            tr.part[(long)mt * 2 * N + N + n0 + tid] = b;
+        }
     }
     if (FDW != 0) {
         // ---- the consuming depthwise layer on the zero-bordered frames: work-item = 4 channels (cg) x every 32nd output pixel of a frame ----

@@ -404,7 +404,7 @@ void plan_describe(fd_plan *p)
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act, L.dw_n);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);
         else if (L.pw16_tm && dtype != FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm16_h16<%s, %d, 4, %d, %d, 1>", tn, L.pw16_tm, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
-        else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, %d, %d, 0, %d>", L.pw16_tm, FD_G16_STAGES, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
+        else if (L.pw16_tm) snprintf(buf, sizeof buf, "fd_pw_gemm16_f32<%d, %d, %d, 0, %d, 0>", L.pw16_tm, FD_G16_STAGES, d.act, L.fuse_next_dw >= 0 ? p->layers[L.fuse_next_dw].d.ksize : 0);
         else if (dtype == FD_F32) snprintf(buf, sizeof buf, "fd_pw_gemm_f32<%d, %d, %d, %d, %d>", L.pw.wgm, L.pw.wgn, L.pw.tm, L.pw.tn, d.act);
         else if (L.fuse_head >= 0) snprintf(buf, sizeof buf, "fd_pw_gemm_head_h16<%s, %d>", tn, d.act);
         else snprintf(buf, sizeof buf, "fd_pw_gemm_h16<%s, %d>", tn, d.act);

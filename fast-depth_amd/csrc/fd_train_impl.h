@@ -60,6 +60,7 @@ struct TLayer {
     int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels
     int chunk = 0;                                            // stem
     int m_tiles = 0, n_tiles = 0, pw_tn = 1;                  // pw (pw_tn: 32-column tiles per wave of the 16-bit forward GEMM)
+    int pw16_tm = 0, pw16_stride = 0;                         // fp32 plans: the forward runs on fd_pw_gemm16_f32<TM, ..., TRAIN> (one workgroup per CU, rows in strides of pw16_stride)
     size_t lds = 0;
     dim3 grid;
     int nblk = 0;                    // reduction partials this unit's forward kernel writes
@@ -235,6 +236,24 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
                 rc = check_launch("fd_head_train");
             } else {
                 if constexpr (F32) {
+                    if (L.pw16_tm) {
+                        const fd_g16_train tr{st1, part_i};
+#define FD_PW16T(TMV, ACTV)                                                                                                                          \
+    do {                                                                                                                                              \
+        (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, FD_G16_STAGES, 0, 0, 0, ACTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
+        FD_LAUNCH((fd_pw_gemm16_f32<TMV, FD_G16_STAGES, 0, 0, 0, ACTV>), L.grid, dim3(512), L.lds, s, zin, q.conv_weight, (const float *)nullptr, z, (int)L.M, d.cout, d.cin, \
+                  d.cin, L.pw16_stride, L.m_tiles, L.n_tiles, fd_dwfuse{}, tr);                                                                       \
+    } while (0)
+#define FD_PW16T_CASE(TMV) case TMV: if (P->d.act == FD_ACT_RELU6) FD_PW16T(TMV, FD_ACT_RELU6_); else FD_PW16T(TMV, FD_ACT_RELU_); break;
+                        switch (L.pw16_tm) {
+                            FD_PW16T_CASE(13) FD_PW16T_CASE(7) FD_PW16T_CASE(4)
+                        default: return fail(FD_ERR_INVALID, "no gemm16 instance for TM=%d", L.pw16_tm);
+                        }
+#undef FD_PW16T_CASE
+#undef FD_PW16T
+                        rc = check_launch("fd_pw_gemm16_f32");
+                        break;
+                    }
                     if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part_i, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
                     else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part_i, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
                     rc = check_launch("fd_pw_gemm_train_f32");
@@ -398,7 +417,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 // the pointwise producer's BatchNorm is finalised by this kernel's workgroups (fd_bn_finalize_block) when its partial rows are few:
                 // the 14 x 14 / 7 x 7 units at B = 32 (98 / 25 rows) -- one launch at the per-launch floor less per unit
                 TLayer &P = p->layers[d.src];
-                if (P.d.op == FD_OP_PW && !P.head && P.nblk <= FD_FIN_MAX_ROWS) {
+                // (every consumer workgroup re-reads the rows of its channel block: bounded, so that the re-reads stay far below the layer's own traffic --
+                // decode_conv4.0's 4096 workgroups behind a 128-row producer would read 130 MB of partial rows)
+                if (P.d.op == FD_OP_PW && !P.head && P.nblk <= FD_FIN_MAX_ROWS && (long)P.nblk * L.grid.x * L.grid.y * L.grid.z <= 131072) {
                     P.fin_by_consumer = true;
                     L.lds += (size_t)2 * cb * 4;
                 }
@@ -438,6 +459,23 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.lds = h16 ? (size_t)std::min(FD_H16_STAGES, L.k64 / 64) * (64 + bn) * 128 + ((size_t)2 * L.k64 + 4 * bn) * 4
                             : (size_t)(std::min(3, ceil_div(d.cin, 32)) * 128 * 32 + 2 * ((d.cin + 31) / 32 * 32) + 256) * 4;
                 L.nblk = L.m_tiles;
+                if (!h16 && !(flags & FD_PLAN_NO_GEMM16) && d.cin % 32 == 0) {
+                    // fp32 plans: the second-generation GEMM (fd_kernels_gemm16_f32.h, train mode) where ONE round of 256 workgroups covers the unit -- the same
+                    // rule as the inference plan (choose_pw16): the 14 x 14 / 7 x 7 units at batch 32; its tiles are whole strides of
+                    // up to 208 rows, so the unit leaves 32 ... 128 partial rows instead of 98 ... 392
+                    // measured (B = 32, us, gemm16 train vs the 32x32x2 kernel): conv7.3 ... conv11.3 42.5 / 50.0, conv6.3 27.2 / 28.5, conv13.3 44.0 / 48.4, decode_conv1.1 31.0 / 33.3,
+                    // conv12.3 26.6 / 26.5; with fewer than 512 output channels (<= 4 column tiles: decode_conv2.1 27.9 / 26.8, decode_conv3.1 29.4 / 28.9) it loses.  The BatchNorm +
+                    // activation of the A fragments costs 6 of the 42.5 us (every fragment is read -- and transformed -- by the 4 column waves of its k-half; ablation: 36.6 without)
+                    const bool force16 = (tune & FD_TUNE_FORCE_GEMM16) != 0;
+                    const Pw16Cfg c16 = (d.cout >= 512 || force16) ? choose_pw16(M, d.cout, d.cin, force16) : Pw16Cfg();
+                    if (c16.tm) {
+                        L.pw16_tm = c16.tm; L.pw16_stride = c16.stride;
+                        L.m_tiles = ceil_div(M, c16.stride); L.n_tiles = ceil_div(d.cout, 64);
+                        L.grid = dim3((unsigned)((L.m_tiles + 7) / 8 * 8 * L.n_tiles));
+                        L.lds = (size_t)FD_G16_STAGES * (c16.tm * 16 + 64) * 32 * 4 + (size_t)2 * d.cin * 4;      // ring + the producer's (scale, shift) table
+                        L.nblk = L.m_tiles;
+                    }
+                }
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
                     const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
                     int splits = std::max(1, std::min(ceil_div(h16 ? FD_WGRAD_TARGET_WGS_H16 : FD_WGRAD_TARGET_WGS_F32, (long)nt * kt), ceil_div(M, 256)));
@@ -450,7 +488,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         default: FD_BAD("layer %d: unknown op", i);
         }
         // (the 16-bit pointwise forward kernel raises its dynamic-LDS limit itself; the other train kernels stay within the default 64 KiB)
-        if (L.lds > (((h16 && d.op == FD_OP_PW && !L.head) || d.op == FD_OP_DW) ? 160 : 64) * 1024) FD_BAD("layer %d: LDS request %zu exceeds the limit", i, L.lds);
+        if (L.lds > (((h16 && d.op == FD_OP_PW && !L.head) || d.op == FD_OP_DW || L.pw16_tm) ? 160 : 64) * 1024) FD_BAD("layer %d: LDS request %zu exceeds the limit", i, L.lds);
         // fd_nhwc (fd_device.h): within-image element offsets are 32-bit, formed with 24 x 24 bit multiplications
         if ((long)L.in_h * L.in_w >= (1L << 24) || d.cin >= (1 << 24) || d.cout >= (1 << 24) || (double)L.in_h * L.in_w * std::max(d.cin, d.cout) >= 4294967296.0)
             FD_BAD("layer %d: a %dx%d map with %d channels exceeds the kernels' 32-bit within-image addressing", i, L.in_h, L.in_w, std::max(d.cin, d.cout));
@@ -541,6 +579,13 @@ int fd_train_plan_lds_rounding(const fd_train_plan *plan, int32_t layer)
 {
     if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return -1;
     return plan->layers[layer].lds_rounding;
+}
+
+int fd_train_plan_unit_kernels(const fd_train_plan *plan, int32_t layer)
+{
+    if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return -1;
+    const TLayer &L = plan->layers[layer];
+    return (L.pw16_tm ? 1 : 0) | (L.fin_by_consumer ? 2 : 0) | (L.bwd_fin_rows > 0 ? 4 : 0);
 }
 
 int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n, int32_t *h,

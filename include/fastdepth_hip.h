@@ -197,7 +197,9 @@ int fd_train_backward(fd_train_plan *plan, const fd_layer_params *params, const 
                       const void *dy, void *stream);
 
 /* Same, restricted to the units from_layer >= i >= to_layer (from_layer must continue where the previous call stopped;
- * the first call starts at n_layers-1).  Lets the host interleave gradient all-reduce buckets with the backward pass. */
+ * the first call starts at n_layers-1).  Lets the host interleave gradient all-reduce buckets with the backward pass: when a call returns,
+ * every gradient of ITS units (conv weight, BatchNorm weight / bias) has been enqueued -- nothing of a later unit is promised (the BatchNorm
+ * backward of unit to_layer - 1 may be finalised by that unit's own first kernel, i.e. by the next call). */
 int fd_train_backward_range(fd_train_plan *plan, const fd_layer_params *params, const fd_layer_grads *grads, int32_t n_layers,
                             const void *dy, int32_t from_layer, int32_t to_layer, void *stream);
 

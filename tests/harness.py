@@ -111,7 +111,7 @@ def saturate_encoder(model, gain=4.0):
     return model
 
 
-LAST_LOCAL_INFO = None     # {"dw_units_with_16bit_lds_patches": n} of the last local_train_parity call
+LAST_LOCAL_INFO = None     # kernel-selection counts of the last local_train_parity call (private test hooks of csrc/fd_tuning.h)
 LAST_SAT6_FRAC = None      # fraction of ReLU6-unit pre-activations >= 6 seen by the last train_parity_report / local_train_parity call
 
 
@@ -299,7 +299,11 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
     tp.lib.fd_train_plan_lds_rounding.restype = ctypes.c_int
     tp.lib.fd_train_plan_lds_rounding.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lds_round = [max(tp.lib.fd_train_plan_lds_rounding(tp.h, i), 0) for i in range(n)]
-    rep_info = {"dw_units_with_16bit_lds_patches": sum(1 for v in lds_round if v)}
+    tp.lib.fd_train_plan_unit_kernels.restype = ctypes.c_int
+    tp.lib.fd_train_plan_unit_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    forms = [max(tp.lib.fd_train_plan_unit_kernels(tp.h, i), 0) for i in range(n)]
+    rep_info = {"dw_units_with_16bit_lds_patches": sum(1 for v in lds_round if v), "pw_units_on_gemm16": sum(1 for v in forms if v & 1),
+                "units_finalised_by_consumer": sum(1 for v in forms if v & 2), "units_finalising_their_own_backward": sum(1 for v in forms if v & 4)}
     consumers = {}
     for i in range(n):
         if L[i].desc.src >= 0:

@@ -20,6 +20,7 @@ def small_model(enc, dec, seed):
 
 TINY = ((8, 16, 24, 24, 32, 32, 40, 40, 40, 40, 40, 40, 48, 48), (40, 32, 24, 16, 8, 1))
 RAGGED = ((16, 56, 88, 120, 144, 72, 104, 40, 72, 88, 96, 128, 80, 112), (200, 72, 120, 56, 16, 1))   # multiples of 8, like the pruned plan
+G16 = ((32, 32, 64, 64, 96, 96, 128, 128, 128, 128, 128, 128, 160, 160), (128, 96, 64, 32, 32, 1))    # every pointwise reduction a multiple of 32 (fd_pw_gemm16_f32 train mode); 96 / 160 outputs: a ragged last 64-column tile
 
 
 @pytest.mark.parametrize("name,plan,b,hw", [("tiny", TINY, 2, 64), ("ragged", RAGGED, 1, 64), ("tiny_rect", TINY, 1, (32, 96))])

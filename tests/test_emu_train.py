@@ -8,7 +8,7 @@ import torch
 
 import harness
 from fastdepth_hip import capi
-from test_emu_forward import RAGGED, TINY, small_model
+from test_emu_forward import G16, RAGGED, TINY, small_model
 
 
 @pytest.mark.parametrize("name,plan,b", [("tiny", TINY, 2), ("tiny_sat6", TINY, 2)])     # (the ragged widths run through the layer-local test below)
@@ -161,6 +161,8 @@ def assert_local_parity(rep, dtype):
                                                    ("tiny", TINY, torch.bfloat16, capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_BWD1),
                                                    # every BatchNorm finalised by its own launch (default at this size: inside the consuming depthwise kernel /
                                                    # the unit's own first backward kernel, fd_bn_finalize_block / fd_bn_bwd_finalize_block)
+                                                   # fp32 forward pointwise GEMMs on fd_pw_gemm16_f32<..., TRAIN> (TM = 13 / 7 / 4 as the maps shrink; statistics of whole-stride tiles)
+                                                   ("g16", G16, torch.float32, capi.FD_TUNE_FORCE_GEMM16), ("g16_sat6", G16, torch.float32, capi.FD_TUNE_FORCE_GEMM16 | capi.FD_TUNE_NO_CONSUMER_FINALIZE),
                                                    ("tiny", TINY, torch.float32, capi.FD_TUNE_NO_CONSUMER_FINALIZE),
                                                    # ... and the depthwise backward launches finalising their own unit too (off by default: measured no faster)
                                                    ("tiny", TINY, torch.float32, capi.FD_TUNE_DW_BWD_FINALIZE), ("ragged", RAGGED, torch.bfloat16, capi.FD_TUNE_DW_BWD_FINALIZE | capi.FD_TUNE_DW_BWD1),
@@ -182,7 +184,19 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     target = 2.0 + torch.rand(2, 1, h, w, generator=g)
     rep = harness.local_train_parity("emu", m, x, target, torch.device("cpu"), dtype=dtype, flags=flags)
     assert_local_parity(rep, dtype)
-    assert (harness.LAST_LOCAL_INFO["dw_units_with_16bit_lds_patches"] > 0) == bool(flags & capi.FD_TUNE_FORCE_DW_H8)
+    info = harness.LAST_LOCAL_INFO
+    assert (info["dw_units_with_16bit_lds_patches"] > 0) == bool(flags & capi.FD_TUNE_FORCE_DW_H8)
+    # the forms the flags ask for did run: gemm16 train GEMMs (every pointwise unit but the head), in-kernel finalisations forward / backward
+    assert info["pw_units_on_gemm16"] == (18 if name.startswith("g16") else 0)
+    assert (info["units_finalised_by_consumer"] > 0) == (not flags & capi.FD_TUNE_NO_CONSUMER_FINALIZE)
+    if flags & capi.FD_TUNE_NO_CONSUMER_FINALIZE:
+        assert info["units_finalising_their_own_backward"] == 0
+    elif flags & capi.FD_TUNE_DW_BWD_FINALIZE:
+        assert info["units_finalising_their_own_backward"] >= (12 if dtype == torch.float32 else 24)      # depthwise units (+ the 16-bit pointwise ones)
+    elif dtype == torch.bfloat16:
+        assert info["units_finalising_their_own_backward"] >= 10                                              # the apply pass of the 16-bit pointwise units
+    else:
+        assert info["units_finalising_their_own_backward"] == 0
     if dtype == torch.bfloat16:
         assert "dz" in rep
     if name.endswith("sat6"):

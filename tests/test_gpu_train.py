@@ -269,11 +269,13 @@ def test_in_kernel_batchnorm_finalisations_batch32(dtype):
     count = lambda ns, key: sum(1 for k in ns if key in k)
     fwd_sep, bwd_sep = count(names_sep, "fd_bn_finalize_f32"), count(names_sep, "fd_bn_bwd_finalize_f32")
     assert fwd_sep == 38 and bwd_sep == 38 and count(names_sep, "apply_fin") == 0
-    assert count(names, "fd_bn_finalize_f32") == 28
+    # (forward: conv6.3 ... conv13.3 and decode_conv1.1; decode_conv2.1's 98 rows would be re-read by 2048 consumer workgroups -- more than the plan allows)
+    assert count(names, "fd_bn_finalize_f32") == 29
     if dtype == torch.bfloat16:
-        assert count(names, "fd_bn_bwd_apply_fin_h16") == 10 and count(names, "fd_bn_bwd_finalize_f32") == 28 and len(names) == len(names_sep) - 20
+        assert count(names, "fd_bn_bwd_apply_fin_h16") == 10 and count(names, "fd_bn_bwd_finalize_f32") == 28 and len(names) == len(names_sep) - 19
     else:
-        assert count(names, "fd_bn_bwd_finalize_f32") == 38 and len(names) == len(names_sep) - 10
+        assert count(names, "fd_bn_bwd_finalize_f32") == 38 and len(names) == len(names_sep) - 9
+        assert count(names, "fd_pw_gemm16_f32") == 9 and count(names_sep, "fd_pw_gemm16_f32") == 9      # conv6.3 ... conv13.3, decode_conv1.1: the fp32 forward GEMMs in train mode
     # (a last-bit difference in ten tables, carried through a train-mode network that amplifies perturbations ~300x and whose ReLU masks can flip:
     # the rigorous statement about these kernels is the layer-local test above, which runs the same default plan)
     assert float((y - y_sep).abs().max() / y_sep.abs().max()) <= (1e-4 if dtype == torch.float32 else 2e-2)

@@ -30,9 +30,9 @@ float run_new(const float* A, const float* W, const float* bias, float* out, int
   int mt=(M+stride-1)/stride, nt=(N+63)/64; size_t lds = (size_t)S*(TM*16+64)*32*4;
   CK(hipFuncSetAttribute((const void*)fd_pw_gemm16_f32<TM,S,2,ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((mt+7)/8*8*nt);
-  for (int i=0;i<2;++i) hipLaunchKernelGGL((fd_pw_gemm16_f32<TM,S,2,ABL>), grid, dim3(512), lds, 0, A,W,bias,out,M,N,K,(K+31)/32*32,stride,mt,nt, fd_dwfuse{});
+  for (int i=0;i<2;++i) hipLaunchKernelGGL((fd_pw_gemm16_f32<TM,S,2,ABL>), grid, dim3(512), lds, 0, A,W,bias,out,M,N,K,(K+31)/32*32,stride,mt,nt, fd_dwfuse{}, fd_g16_train{});
   CK(hipEventRecord(e0,0));
-  for (int i=0;i<iters;++i) hipLaunchKernelGGL((fd_pw_gemm16_f32<TM,S,2,ABL>), grid, dim3(512), lds, 0, A,W,bias,out,M,N,K,(K+31)/32*32,stride,mt,nt, fd_dwfuse{});
+  for (int i=0;i<iters;++i) hipLaunchKernelGGL((fd_pw_gemm16_f32<TM,S,2,ABL>), grid, dim3(512), lds, 0, A,W,bias,out,M,N,K,(K+31)/32*32,stride,mt,nt, fd_dwfuse{}, fd_g16_train{});
   CK(hipEventRecord(e1,0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
   float ms; CK(hipEventElapsedTime(&ms,e0,e1)); return ms/iters*1e3f;
 }
