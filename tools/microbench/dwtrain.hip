@@ -22,7 +22,7 @@ static void run(int B, int H, int C, int th, int tw, int abl = 0, size_t extra_l
   CK(hipFuncSetAttribute((const void *)fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   dim3 grid(tiles_x * tiles_y, (C + cb - 1) / cb, B);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  auto launch = [&]() { hipLaunchKernelGGL((fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2, 4>), grid, dim3(256), lds, 0, zin, st, (const fd_bf16 *)nullptr, (const float *)nullptr, w, zout, part, H, H, H, H, C, 3, th, tw, tiles_x, 0, 36); };
+  auto launch = [&]() { hipLaunchKernelGGL((fd_dwconv_train<fd_bf16, 3, 1, 0, 2, 2, 4>), grid, dim3(256), lds, 0, zin, st, (const fd_bf16 *)nullptr, (const float *)nullptr, w, zout, part, H, H, H, H, C, 3, th, tw, tiles_x, 0, 36, fd_bn_fin{}); };
   for (int i = 0; i < 3; ++i) launch();
   CK(hipEventRecord(e0, 0)); for (int i = 0; i < 20; ++i) launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
