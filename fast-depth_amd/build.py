@@ -2,7 +2,8 @@
 
     python fast-depth_amd/build.py [--force]
 
-hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU box.
+The library is three translation units (inference; train plan + forward; train backward / loss / SGD / exchange) compiled IN PARALLEL into
+fast-depth_amd/csrc/_obj/ and linked.  hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU box.
 """
 import os
 import subprocess
@@ -10,27 +11,41 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(HERE, "fastdepth_hip", "libfastdepth_hip.so")
-SOURCES = [os.path.join(CSRC, "fd_api.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("fd_api.hip", "fd_train_fwd.hip", "fd_train_bwd.hip")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value",
-         "-Wno-unused-function", "-DNDEBUG"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-function", "-DNDEBUG"]
+FLAGS = CFLAGS + ["-shared"]          # (one-command form, kept for callers that build a single source)
 
 
 def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "fastdepth_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "_obj"] + [os.path.join(HERE, "..", "include", "fastdepth_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def compile_and_link(out, extra=(), tag=""):
+    """Every source -> its object (all at once), then one link.  `tag` keeps the objects of library variants (tools/build_variant.py) apart."""
+    os.makedirs(OBJ, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([HIPCC] + CFLAGS + list(extra) + ["-c", src, "-o", obj])))
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
 
 
 def build(force=False, extra=()):
     if not force and not _stale():
         return OUT
-    cmd = [HIPCC] + FLAGS + list(extra) + SOURCES + ["-o", OUT]
-    subprocess.check_call(cmd)
-    return OUT
+    return compile_and_link(OUT, extra)
 
 
 if __name__ == "__main__":

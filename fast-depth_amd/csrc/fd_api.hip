@@ -26,6 +26,7 @@
 #include <hip/hip_ext.h>
 #endif
 
+#define FD_DEFINE_HOST_STATE     // this unit defines the thread-local state the three units share (fd_host_common.h)
 #include "fd_host_common.h"
 #include "fd_plan_select.h"
 #include "fd_infer_launch.h"
@@ -210,5 +211,5 @@ int fd_plan_layer_traffic(const fd_plan *plan, int32_t layer, double *needed_byt
 
 }  // extern "C"
 
-#include "fd_train_impl.h"
+// (the train plan lives in its own translation units: fd_train_fwd.hip, fd_train_bwd.hip)
 

@@ -1,5 +1,5 @@
 // fd_bundle_impl.h -- deploy bundle export / import (included inside fd_api.hip's extern "C" block)
-// (one translation unit: included by fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
+// (translation unit fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
 #pragma once
 /* ---- deploy bundle: layer descriptions + packed (BatchNorm-folded) weights, self-describing, loadable with no Python.  The analogue of the
  * reference's TVM artefacts deploy_graph.json + deploy_param.params (deploy/tx2_run_tvm.py:13-20). ---- */

@@ -1,10 +1,6 @@
 // fd_infer_launch.h -- kernel launches of the inference plan: one function per kernel family, template instance picked from the plan's per-layer record
-// (one translation unit: included by fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
+// (translation unit fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
 #pragma once
-#ifndef FD_G16_STAGES
-#define FD_G16_STAGES 4      // depth of fd_pw_gemm16_f32's LDS-DMA ring, issued STAGES - 1 K tiles ahead (build switch for tools/build_variant.py).  Round 4: 4 instead of
-                             // 3 stages (139 KB at TM = 13: still one workgroup per CU, as designed) -- conv7.3 38.0 -> 36.9 us, conv13.3 43.4 -> 41.4, the B = 32 step -1.7 %
-#endif
 namespace {
 
 // ---- launches ------------------------------------------------------------------------------------

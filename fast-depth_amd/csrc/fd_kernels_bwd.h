@@ -88,7 +88,7 @@ __device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__
     }
 }
 
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
                        float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
                        double *__restrict__ slices, int *__restrict__ counters)
@@ -174,7 +174,7 @@ __device__ __forceinline__ void fd_wbatch_store(const fd_wred_args &W, int j, fd
         for (int q = 0; q < 4; ++q) { const int t = (j + q) / W.C, c = (j + q) - t * W.C; W.out[(long)c * W.KK + t] = s[q]; }
     }
 }
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 fd_reduce_weights_batch_f32(const fd_wbatch B)
 {
     __shared__ fd_f32x4 sh[16][64];
@@ -230,7 +230,7 @@ fd_reduce_weights_batch_f32(const fd_wbatch B)
 }
 
 // ---- mean-L1 loss forward + backward (torch.nn.L1Loss) --------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_l1_loss_f32(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ dpred,
                float *__restrict__ part, long numel, float inv_numel)
 {
@@ -246,7 +246,7 @@ fd_l1_loss_f32(const float *__restrict__ pred, const float *__restrict__ target,
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 fd_l1_loss_final_f32(const float *__restrict__ part, int nblk, float inv_numel, float *__restrict__ loss)
 {
     double s = 0.0;
@@ -261,7 +261,7 @@ fd_l1_loss_final_f32(const float *__restrict__ part, int nblk, float inv_numel, 
 // masks them too).  Pass 1 leaves per-workgroup (sum |d|, #valid) partials; pass 2: every workgroup adds the <= 1024 partial pairs in the
 // same fixed order (so all agree on the count), writes dpred = sign(d) / #valid on the valid pixels and 0 elsewhere; workgroup 0 writes the
 // loss (NaN when nothing is valid: the mean of an empty selection, as torch reports it; the gradient is all zeros then).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_l1_masked_partial_f32(const float *__restrict__ pred, const float *__restrict__ target, float *__restrict__ part, long numel)
 {
     __shared__ float red[4][2];
@@ -278,7 +278,7 @@ fd_l1_masked_partial_f32(const float *__restrict__ pred, const float *__restrict
         part[2 * blockIdx.x + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];      // <= 2^24 per workgroup slice: exact in fp32
     }
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_l1_masked_apply_f32(const float *__restrict__ pred, const float *__restrict__ target, const float *__restrict__ part, int nblk,
                        float *__restrict__ dpred, float *__restrict__ loss, long numel)
 {
@@ -305,7 +305,7 @@ fd_l1_masked_apply_f32(const float *__restrict__ pred, const float *__restrict__
 // ---- depth metrics (row f-2): every sum of reference metrics.py:31-55 in ONE pass, no per-scalar host synchronisation --------
 // sums[0] = #valid, [1] = sum ad^2, [2] = sum ad, [3] = sum |log10 o - log10 t|, [4] = sum ad/t, [5..7] = #(maxRatio < 1.25^k),
 // [8] = sum (1/o - 1/t)^2, [9] = sum |1/o - 1/t|;  valid = (target > 0) or (output > 0), o = 1e3*output, t = 1e3*target (mm).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_depth_metrics_f32(const float *__restrict__ output, const float *__restrict__ target, long numel, double *__restrict__ part)
 {
     // blockIdx.y = frame (numel elements each): the reference evaluates one image at a time (main.py:40-41 batch size 1, :80-82)
@@ -342,7 +342,7 @@ fd_depth_metrics_f32(const float *__restrict__ output, const float *__restrict__
     __syncthreads();
     if (threadIdx.x < 10) part[((long)blockIdx.y * gridDim.x + blockIdx.x) * 10 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 fd_depth_metrics_final_f32(const double *__restrict__ part, int nblk, double *__restrict__ sums)
 {
     if (threadIdx.x < 10) {                                  // blockIdx.x = frame
@@ -354,7 +354,7 @@ fd_depth_metrics_final_f32(const double *__restrict__ part, int nblk, double *__
 
 // ---- fused multi-tensor SGD ------------------------------------------------------------------------------------------
 struct fd_sgd_rec { float *param; const float *grad; float *buf; long numel; };
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_sgd_f32(const fd_sgd_rec *__restrict__ table, int n_tensors, float lr, float momentum, float wd, float grad_scale, int first_step)
 {
     // blockIdx.y = tensor, blockIdx.x strides over its elements: 16 bytes per lane where the tensor's three arrays are 16-byte aligned

@@ -6,7 +6,7 @@
 #pragma once
 #include "fd_device.h"
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_val_transform_u8(const unsigned char *__restrict__ rgb, const float *__restrict__ depth, const int *__restrict__ ymap,
                     const int *__restrict__ xmap, float *__restrict__ x, float *__restrict__ d, int n, int H, int W, int oh, int ow)
 {
@@ -28,13 +28,13 @@ fd_val_transform_u8(const unsigned char *__restrict__ rgb, const float *__restri
 
 // ---- gradient exchange in 16 bits (optional: SURVEY.md 8(e), the 7.92 MB form of the data-parallel all-reduce): a bucket of the flat fp32
 // gradient vector -> bfloat16 (round to nearest even) before the collective, and back after it.  4 elements per work-item.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_cast_f32_bf16(const float *__restrict__ src, fd_bf16 *__restrict__ dst, long n4, long n)
 {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) fd_st4(dst + 4 * i, fd_ld4(src + 4 * i));
     for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) fd_st1(dst + i, src[i]);
 }
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 fd_cast_bf16_f32(const fd_bf16 *__restrict__ src, float *__restrict__ dst, long n4, long n)
 {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) fd_st4(dst + 4 * i, fd_ld4(src + 4 * i));

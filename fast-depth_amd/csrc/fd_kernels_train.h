@@ -737,7 +737,7 @@ __device__ __forceinline__ bool fd_two_level_tail(double &s, double &q, bool has
 //   mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), running_var uses var_b * n_u/(n_u-1).
 // Grid (ceil(C/64), slices): lane = channel, wave w sums partial rows w, w+16, ... of its slice in double, fixed order.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, double n_unbiased, float eps, float momentum,
                    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ run_mean,
                    float *__restrict__ run_var, float *__restrict__ st, double *__restrict__ slices, int *__restrict__ counters,

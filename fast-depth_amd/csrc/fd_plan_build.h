@@ -1,5 +1,5 @@
 // fd_plan_build.h -- the passes of fd_plan_create: per-layer geometry and validation, the three fusion passes, the activation arena, bookkeeping / descriptions
-// (one translation unit: included by fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
+// (translation unit fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
 #pragma once
 namespace {
 

@@ -1,6 +1,10 @@
 // fd_plan_select.h -- the inference plan's records (Layer, fd_plan), the bank-conflict replay that picks LDS patch pitches, the lifetime arena and the pointwise tile selection (the shape thresholds in here were measured at batch 32 / 64: DESIGN.md sections 3, 10, 11)
-// (one translation unit: included by fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
+// (translation unit fd_api.hip; fd_train_fwd.hip includes it for choose_pw16 / FD_G16_STAGES; split out of fd_api.hip in round 4 -- the plan code was a 1 160-line monolith)
 #pragma once
+#ifndef FD_G16_STAGES
+#define FD_G16_STAGES 4      // depth of fd_pw_gemm16_f32's LDS-DMA ring, issued STAGES - 1 K tiles ahead (build switch for tools/build_variant.py).  Round 4: 4 instead of
+                             // 3 stages (139 KB at TM = 13: still one workgroup per CU, as designed) -- conv7.3 38.0 -> 36.9 us, conv13.3 43.4 -> 41.4, the B = 32 step -1.7 %
+#endif
 namespace {
 
 // Row pitch (floats) of the [pixels][pitch] LDS patch images that the depthwise kernels read with ds_read_b128 from (strip of `strip` pixels,

@@ -1,5 +1,5 @@
 // fd_trace_impl.h -- measurement aids: per-launch tracing and the per-layer timed forward (included inside fd_api.hip's extern "C" block)
-// (one translation unit: included by fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
+// (translation unit fd_api.hip; split out of it in round 4 -- the plan code was a 1 160-line monolith)
 #pragma once
 int fd_trace_begin(void)
 {

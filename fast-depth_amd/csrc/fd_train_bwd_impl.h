@@ -1,5 +1,6 @@
-// fd_train_bwd_impl.h -- host side of fd_train_backward, fd_l1_loss, fd_sgd_step (included by fd_train_impl.h).
+// fd_train_bwd_impl.h -- host side of fd_train_backward, fd_l1_loss, fd_sgd_step and the library-issued gradient exchange (translation unit fd_train_bwd.hip)
 #pragma once
+#include "fd_train_plan.h"
 
 namespace {
 
@@ -54,41 +55,6 @@ inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr, int le) { retu
 // inside its own first backward kernel (TLayer::bwd_fin, fd_bn_bwd_finalize_block) reads them while that kernel writes its PRODUCER's rows, so such
 // units alternate between two extra buffers; everything else shares the one buffer, as before.
 inline float *bwd_part(fd_train_plan *p, int u) { return tws(p, (u >= 0 && p->layers[u].bwd_fin) ? p->partb_off[u & 1] : p->part_off); }
-
-// the paired depthwise launch has an instance for this unit's kernel size / stride / input composition / activations (dispatch_dw_bwd_pair)
-inline bool dw_bwd_has_pair(const fd_train_plan *p, int i)
-{
-    const TLayer &L = p->layers[i];
-    const TLayer &P = p->layers[L.d.src];
-    const int a1 = P.d.act, a2 = L.d.skip >= 0 ? p->layers[L.d.skip].d.act : FD_ACT_RELU6;
-    const bool add = P.skip_consumer >= 0 && L.mode == 0;
-    const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
-    if (a1 == FD_ACT_RELU6 && !add && (key == 310 || key == 320 || key == 510)) return true;
-    if (a1 == FD_ACT_RELU6 && add && key == 320) return true;
-    if (a1 == FD_ACT_RELU && key == 511) return true;
-    if (a1 == FD_ACT_RELU && a2 == FD_ACT_RELU6 && (key == 512 || key == 513)) return true;
-    return false;
-}
-// the stride-2 3x3 units of the large maps run their backward on the two register-window kernels (launch_dw_bwd_pair)
-inline bool dw_bwd_on_rows(const fd_train_plan *p, const TLayer &L)
-{
-    const int cgn = L.d.cin / 4;
-    const bool rows_ok = L.d.ksize == 3 && L.d.stride == 2 && L.mode == 0 && L.d.cin % 4 == 0 && cgn >= 8 && cgn <= 64 && (cgn & (cgn - 1)) == 0 &&
-                         (((long)L.out_h * L.out_w >= 28 * 28 && p->esz == 2) || (p->tune & FD_TUNE_DW_FORCE_ROWS));
-    return rows_ok && !(p->tune & (FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_BWD_PAIR | FD_TUNE_DW_BWD1));
-}
-// plan-time half of TLayer::bwd_fin: the unit's first backward kernel CAN finalise its BatchNorm backward (the LDS-tiled depthwise launches, the
-// apply pass of the 16-bit pointwise units); whether it does is decided per step by the number of partial rows its consumer left (finalize_or_defer)
-inline bool bwd_fin_candidate(const fd_train_plan *p, int i)
-{
-    const TLayer &L = p->layers[i];
-    if ((p->tune & FD_TUNE_NO_CONSUMER_FINALIZE) || L.head || L.d.src < 0) return false;
-    if (L.d.op == FD_OP_PW) return p->esz == 2;
-    // (depthwise units: built and measured, off by default -- bf16 step: the 10 launches it removes are 43 us, the paired kernels get 40 us slower (both roles
-    // sum the rows; 163 VGPRs + 36 bytes of scratch in the 3x3 instance); fp32 step +26 us.  FD_TUNE_DW_BWD_FINALIZE turns it on: tests, A/B)
-    if (L.d.op == FD_OP_DW) return (p->tune & FD_TUNE_DW_BWD_FINALIZE) && !(p->flags & FD_PLAN_NO_BWD_PAIRING) && dw_bwd_has_pair(p, i) && !dw_bwd_on_rows(p, L);
-    return false;
-}
 
 int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
 {

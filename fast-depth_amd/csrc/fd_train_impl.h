@@ -1,130 +1,8 @@
-// fd_train_impl.h -- train-step plan (train-mode forward, backward, loss, SGD); included at the end of
-// fd_api.hip so that it shares that translation unit's helpers (fail(), FD_LAUNCH, ceil_div, ...).
-//
-// Workspace layout of a train plan:
-//   [z_i]   raw conv output of every unit, NHWC, fp32 or bf16 (plan dtype), all kept (they are the saved tensors of backward)
-//   [st_i]  per-unit BatchNorm table [4][C]: scale, shift, mean, invstd (fd_bn_finalize_f32)
-//   [part]  one shared buffer for per-workgroup reduction partials (consumed right after each producer)
-//   backward only: [g_a, g_b] ping-pong dLoss/d(BN output) buffers, [skipgrad_k] decoder->skip gradient buffers,
-//   [coef_i] per-unit BN-backward coefficient tables, [wpart_i] per-unit weight-gradient partials (reduced by ONE launch per backward
-//   range: fd_reduce_weights_batch_f32).
-//   bf16 plans: [wt_i, wtt_i] the 16-bit operand copies of every pointwise weight (re-made from the fp32 masters each step).
+// fd_train_impl.h -- train plan creation and the train-mode forward (translation unit fd_train_fwd.hip; records and helpers: fd_train_plan.h)
 #pragma once
-#include <type_traits>
-#include "fd_kernels_train.h"
-#include "fd_kernels_bwd.h"
-#include "fd_kernels_train_h16.h"
-#include "fd_kernels_io.h"
-
-// workgroups the pointwise weight-gradient GEMM aims for (output tiles x pixel splits); every split writes a private fp32 partial
-// tile that fd_reduce_partials_f32 sums afterwards, so more splits = more parallelism but more partial traffic
-// (measured at batch 32: 2048 is best for the fp32 kernel; the bf16 one, whose MFMA part is 16x shorter, wants fewer)
-// tile shapes of the 5x5 depthwise train kernels (build switches for tools/build_variant.py sweeps; the defaults are the measured best)
-#ifndef FD_T_DW5_FTH
-#define FD_T_DW5_FTH 8      // forward: rows (balanced over the map), columns
-#define FD_T_DW5_FTW 16
-#define FD_T_DW5_WTH 8      // backward-weights: output-space tile
-#define FD_T_DW5_WTW 16
-#define FD_T_DW5_DTH 8      // backward-data: input-space tile
-#define FD_T_DW5_DTW 16
-#endif
-#ifndef FD_T_S2_DTH
-#define FD_T_S2_DTH 8       // stride-2 units (single-staging backward kernel): input-space tile
-#define FD_T_S2_DTW 16
-#endif
-#ifndef FD_DW_WGRAD_TARGET_WGS
-#define FD_DW_WGRAD_TARGET_WGS 1536   // depthwise weight-gradient kernel: a workgroup walks up to a tile row's tiles as long as about this many workgroups remain
-#endif
-#ifndef FD_WGRAD_TUNE_H16
-#define FD_WGRAD_TUNE_H16 640      // (round 3, paired launch: 640 -> 2.840 ms per bf16 step, 1024 -> 2.877, 512 -> 2.860; fewer splits = fewer partial bytes)
-#endif
-#ifndef FD_WGRAD_TARGET_WGS_F32
-#define FD_WGRAD_TARGET_WGS_F32 1536   // (round 3, paired launch: 1024 -> 4.355 ms per fp32 step, 1536 -> 4.340, 2048 -> 4.361, 3072 -> 4.364)
-#endif
-#define FD_WGRAD_TARGET_WGS_H16 (FD_WGRAD_TUNE_H16)
+#include "fd_train_plan.h"
 
 namespace {
-
-struct TLayer {
-    fd_layer_desc d;
-    int in_h = 0, in_w = 0, out_h = 0, out_w = 0;   // in_* = logical (post-upsample) input size; head: out_* = LOW-res size when upsample
-    bool head = false;
-    int mode = 0;
-    int csplit = 0;                  // concatenating depthwise consumer (mode 3): channels [0, csplit) come from src, the rest from skip
-    int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
-    int dw_n = 4;                                             // channels per work-item of the LDS-tiled depthwise kernels (8: bf16 plans, storage-typed LDS patches; fd_lane)
-    mutable int lds_rounding = 0;                             // fd_train_plan_lds_rounding: set by the launches of the last forward / backward
-    int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
-    int rows_th = 0;                                          // > 0: the forward runs on fd_dw3_rows_train with row strips of this height
-    int stem_band = 0;                                        // floats of the stem kernels' input band in LDS
-    int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels
-    int chunk = 0;                                            // stem
-    int m_tiles = 0, n_tiles = 0, pw_tn = 1;                  // pw (pw_tn: 32-column tiles per wave of the 16-bit forward GEMM)
-    int pw16_tm = 0, pw16_stride = 0;                         // fp32 plans: the forward runs on fd_pw_gemm16_f32<TM, ..., TRAIN> (one workgroup per CU, rows in strides of pw16_stride)
-    size_t lds = 0;
-    dim3 grid;
-    int nblk = 0;                    // reduction partials this unit's forward kernel writes
-    bool bwd_fin = false;            // the unit's first backward kernel can finalise its BatchNorm backward (bwd_fin_candidate); its partial rows live in partb_off[i & 1]
-    mutable int bwd_fin_rows = 0;    // > 0: it does so in this step -- that many partial rows are waiting (set when the consumer's backward kernels were launched)
-    bool fin_by_consumer = false;    // pointwise unit with <= FD_FIN_MAX_ROWS partial rows whose LDS-tiled depthwise consumer finalises its BatchNorm (no fd_bn_finalize_f32 launch)
-    size_t z_off = 0, z_elems = 0;   // raw output
-    size_t st_off = 0;               // [4][C] table
-    size_t coef_off = 0;             // backward coefficient table [4][C]
-    double n_stat = 0, n_unbiased = 0;
-    long M = 0;                      // pixels of the stored output (B*out_h*out_w)
-    // backward bookkeeping
-    int consumer = -1;               // unit that reads this output as `src`
-    int skip_consumer = -1;          // decoder unit that reads this output as `skip` (-1: none)
-    size_t g_off = 0;                // dLoss/dy buffer of this unit
-    size_t sg_off = 0;               // decoder->skip gradient buffer (only for skip sources)
-    size_t wt_off = 0, wtt_off = 0;  // 16-bit plans: W as [N][K64] and W^T as [K][N64]
-    size_t dz_off = 0;               // 16-bit pointwise units under FD_PLAN_KEEP_ACTIVATIONS: dz kept apart from G (0 = in place)
-    size_t wp_off = 0, wp_elems = 0; // this unit's weight-gradient partial rows (reduced by one launch per backward range)
-    int k64 = 0, n64 = 0;
-};
-
-}  // namespace
-
-struct fd_train_plan {
-    std::vector<TLayer> layers;
-    int B = 0, H = 0, W = 0, dtype = FD_F32;
-    uint32_t flags = 0, tune = 0;    // public plan flags (include/fastdepth_hip.h) / private tuning mask (fd_tuning.h)
-    size_t esz = 4;                  // bytes per stored activation / activation-gradient element
-    size_t partb_off[2] = {0, 0};    // partial rows of the units finalised inside a kernel that writes the next rows meanwhile: forward [0]; backward [unit & 1]
-    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
-    unsigned char *ws = nullptr;
-    bool forward_done = false;
-    float eps = 1e-5f;
-    const void *x_saved = nullptr;   // the network input of the last forward (the stem's weight gradient re-reads it)
-};
-
-namespace {
-
-inline bool bwd_fin_candidate(const fd_train_plan *p, int i);    // (fd_train_bwd_impl.h)
-inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
-template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reinterpret_cast<T *>(p->ws + off); }
-
-// Launch geometry of the fused two-level reductions (fd_two_level_tail): up to 256 partial rows are finalised by a single
-// workgroup per 64 columns (16 rows per wave, all loads of 8 rows in flight: cheaper than slices + arrival counter + second level, which is
-// three more dependent round trips -- the 14x14 / 7x7 units have 25 ... 98 rows); more rows are cut into slices that the grid's y dimension sums first.
-struct RedGeom { int rps; dim3 grid; };
-inline RedGeom red_geom(int nrows, long width)
-{
-    if (nrows <= 256) return RedGeom{nrows, dim3((unsigned)ceil_div(width, 64), 1)};
-    const int rps = std::max(64, ceil_div(nrows, 128));       // at most 128 slices (fd_two_level_tail: 8 per wave)
-    return RedGeom{rps, dim3((unsigned)ceil_div(width, 64), (unsigned)ceil_div(nrows, rps))};
-}
-inline double *red_slices(fd_train_plan *p) { return reinterpret_cast<double *>(p->ws + p->part2_off); }
-inline int *red_counters(fd_train_plan *p) { return reinterpret_cast<int *>(p->ws + p->cnt_off); }
-
-// calls fn(fd_int<4>) or -- 16-bit storage types only -- fn(fd_int<8>): the lane width (fd_lane) of the LDS-tiled depthwise kernels
-template <typename T, typename F> inline void fd_by_lane_width(int n, F &&fn)
-{
-    if constexpr (!std::is_same<T, float>::value) { if (n == 8) { fn(fd_int<8>{}); return; } }
-    fn(fd_int<4>{});
-}
-// host mirror of fd_lds_patch_bytes (fd_kernels_train.h): bytes of an LDS patch image of npx pixels at pitch pstr in elements of `le` bytes
-inline size_t lds_patch_bytes(long npx, int pstr, int le) { return std::max(align_up((size_t)npx * pstr * le, 16), (size_t)8192); }
 
 template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
@@ -614,4 +492,3 @@ int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t whic
 
 }  // extern "C"
 
-#include "fd_train_bwd_impl.h"

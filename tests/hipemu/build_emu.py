@@ -13,13 +13,21 @@ CLANG = os.environ.get("FD_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "hipemu.h"),
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "_obj"] + [os.path.join(HERE, "hipemu.h"),
                                                                 os.path.join(REPO, "include", "fastdepth_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
-    cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-DFD_EMU", "-I", HERE, "-Wall",
-           "-Wno-unused-function", "-Wno-unused-variable", "-Wno-psabi", "-Wno-comment", "-mavx2", os.path.join(CSRC, "fd_api.hip"), "-o", OUT]
-    subprocess.check_call(cmd)
+    # the library's three translation units, compiled in parallel and linked (as fast-depth_amd/build.py does with hipcc)
+    flags = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DFD_EMU", "-I", HERE, "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-psabi",
+             "-Wno-comment", "-mavx2"]
+    objs, procs = [], []
+    for name in ("fd_api", "fd_train_fwd", "fd_train_bwd"):
+        obj = os.path.join(OUT_DIR, name + ".o")
+        objs.append(obj)
+        procs.append(subprocess.Popen([CLANG] + flags + ["-c", os.path.join(CSRC, name + ".hip"), "-o", obj]))
+    if any(p.wait() != 0 for p in procs):
+        raise subprocess.CalledProcessError(1, "clang++ -DFD_EMU -c")
+    subprocess.check_call([CLANG, "-shared", "-fPIC"] + objs + ["-o", OUT])
     return OUT
 
 

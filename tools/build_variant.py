@@ -1,11 +1,10 @@
 """Builds a variant of the HIP library with extra compiler switches into scratch/variants/<name>.so (tuning A/B aid; the product library is
 fast-depth_amd/build.py's).  usage: python tools/build_variant.py <name> -DFD_H16_STAGES=2 ...
 Measurement tools take it with --lib scratch/variants/<name>.so."""
-import os, subprocess, sys
+import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "fast-depth_amd"))
 import build as fd_build
 out = os.path.join(REPO, "scratch", "variants", sys.argv[1] + ".so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call([fd_build.HIPCC] + fd_build.FLAGS + sys.argv[2:] + fd_build.SOURCES + ["-o", out])
-print(out)
+print(fd_build.compile_and_link(out, sys.argv[2:], tag="_" + sys.argv[1]))
