@@ -3,9 +3,10 @@ import re
 import subprocess
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "fast-depth_amd/csrc/fd_api.hip"
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-value",
-                      "-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"], capture_output=True, text=True).stderr
+srcs = sys.argv[1:] if len(sys.argv) > 1 else ["fast-depth_amd/csrc/" + f for f in ("fd_api.hip", "fd_train_fwd.hip", "fd_train_bwd.hip")]   # (the library's translation units)
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Wno-unused-value",
+                           "-Rpass-analysis=kernel-resource-usage", src, "-o", "/dev/null"], stderr=subprocess.PIPE, text=True) for src in srcs]
+out = "".join(p.communicate()[1] for p in procs)
 rows, cur = [], None
 for line in out.splitlines():
     m = re.search(r"remark: (?:\S+ )?\s*(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\S+)", line)
