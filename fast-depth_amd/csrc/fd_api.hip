@@ -36,9 +36,9 @@
 // ==================================================================================================
 extern "C" {
 
-void fd_tuning_next(uint32_t mask) { g_tune_next = mask; }
+void fd_tuning_next(uint32_t mask) { fd_hs().tune_next = mask; }
 
-const char *fd_last_error(void) { return g_err.c_str(); }
+const char *fd_last_error(void) { return fd_hs().err.c_str(); }
 const char *fd_version(void) { return "fastdepth_hip 0.3 (gfx950; inference f32/f16/bf16, train step f32/bf16)"; }
 
 int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
@@ -120,11 +120,11 @@ int fd_forward(fd_plan *plan, const void *x_nchw, void *y, void *stream)
     for (size_t i = 0; i < plan->layers.size(); ++i) {
         const Layer &L = plan->layers[i];
         if (L.skipped || L.fused_into >= 0) continue;       // (a fused depthwise layer is produced by its producer's kernel)
-        g_trace_layer = (int)i;
+        fd_hs().trace_layer = (int)i;
         int rc = run_layer(plan, L, static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
         if (rc) return rc;
     }
-    g_trace_layer = -1;
+    fd_hs().trace_layer = -1;
     return FD_OK;
 }
 

@@ -26,29 +26,22 @@ __attribute__((visibility("hidden"))) fd_host_state &fd_hs();
 #ifdef FD_DEFINE_HOST_STATE
 fd_host_state &fd_hs() { static thread_local fd_host_state s; return s; }
 #endif
-#define g_err (fd_hs().err)
-#define g_tune_next (fd_hs().tune_next)
-#define g_ev_start (fd_hs().ev_start)
-#define g_ev_stop (fd_hs().ev_stop)
-#define g_trace_layer (fd_hs().trace_layer)
-#define g_trace_on (fd_hs().trace_on)
-#define g_trace (fd_hs().trace)
 
 namespace {
 
-inline uint32_t fd_take_tuning() { const uint32_t t = g_tune_next; g_tune_next = 0; return t; }
+inline uint32_t fd_take_tuning() { const uint32_t t = fd_hs().tune_next; fd_hs().tune_next = 0; return t; }
 
 #ifdef FD_EMU
 #define FD_LAUNCH(kernel, grid, block, lds, stream, ...) hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)
 #else
 #define FD_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
     do {                                                                                                        \
-        if (g_trace_on) {                                                                                       \
-            TraceRec tr_{#kernel, g_trace_layer, nullptr, nullptr};                                             \
+        if (fd_hs().trace_on) {                                                                                       \
+            TraceRec tr_{#kernel, fd_hs().trace_layer, nullptr, nullptr};                                             \
             (void)hipEventCreate(&tr_.e0); (void)hipEventCreate(&tr_.e1);                                       \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tr_.e0, tr_.e1, 0, __VA_ARGS__);           \
-            g_trace.push_back(tr_);                                                                             \
-        } else if (g_ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
+            fd_hs().trace.push_back(tr_);                                                                             \
+        } else if (fd_hs().ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, fd_hs().ev_start, fd_hs().ev_stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
     } while (0)
 #endif
@@ -60,7 +53,7 @@ int fail(int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    fd_hs().err = buf;
     return code;
 }
 

@@ -6,9 +6,9 @@ int fd_trace_begin(void)
 #ifdef FD_EMU
     return fail(FD_ERR_STATE, "kernel tracing needs the HIP build");
 #else
-    for (auto &t : g_trace) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
-    g_trace.clear();
-    g_trace_on = true;
+    for (auto &t : fd_hs().trace) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    fd_hs().trace.clear();
+    fd_hs().trace_on = true;
     return FD_OK;
 #endif
 }
@@ -19,19 +19,19 @@ int fd_trace_end(void *stream, fd_trace_record *records, int32_t max_records, in
     (void)stream; (void)records; (void)max_records; (void)n_records;
     return fail(FD_ERR_STATE, "kernel tracing needs the HIP build");
 #else
-    if (!g_trace_on) return fail(FD_ERR_STATE, "fd_trace_end without fd_trace_begin");
-    g_trace_on = false;
+    if (!fd_hs().trace_on) return fail(FD_ERR_STATE, "fd_trace_end without fd_trace_begin");
+    fd_hs().trace_on = false;
     int rc = FD_OK;
     if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(FD_ERR_HIP, "synchronisation failed");
-    const int n = (int)g_trace.size();
+    const int n = (int)fd_hs().trace.size();
     if (n_records) *n_records = n;
     for (int i = 0; i < n; ++i) {
         float ms = 0.0f;
-        if (rc == FD_OK && hipEventElapsedTime(&ms, g_trace[i].e0, g_trace[i].e1) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
-        if (records && i < max_records) { records[i].kernel = g_trace[i].name; records[i].layer = g_trace[i].layer; records[i].ms = ms; }
-        (void)hipEventDestroy(g_trace[i].e0); (void)hipEventDestroy(g_trace[i].e1);
+        if (rc == FD_OK && hipEventElapsedTime(&ms, fd_hs().trace[i].e0, fd_hs().trace[i].e1) != hipSuccess) rc = fail(FD_ERR_HIP, "hipEventElapsedTime failed");
+        if (records && i < max_records) { records[i].kernel = fd_hs().trace[i].name; records[i].layer = fd_hs().trace[i].layer; records[i].ms = ms; }
+        (void)hipEventDestroy(fd_hs().trace[i].e0); (void)hipEventDestroy(fd_hs().trace[i].e1);
     }
-    g_trace.clear();
+    fd_hs().trace.clear();
     return rc;
 #endif
 }
@@ -51,10 +51,10 @@ int fd_forward_timed(fd_plan *plan, const void *x_nchw, void *y, void *stream, f
     int rc = FD_OK;
     for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
         if (plan->layers[i].skipped || plan->layers[i].fused_into >= 0) continue;
-        g_ev_start = ev[2 * i]; g_ev_stop = ev[2 * i + 1];
+        fd_hs().ev_start = ev[2 * i]; fd_hs().ev_stop = ev[2 * i + 1];
         rc = run_layer(plan, plan->layers[i], static_cast<const float *>(x_nchw), static_cast<float *>(y), s);
     }
-    g_ev_start = g_ev_stop = nullptr;
+    fd_hs().ev_start = fd_hs().ev_stop = nullptr;
     if (rc == FD_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(FD_ERR_HIP, "hipStreamSynchronize failed");
     for (int i = 0; i < n_layers && rc == FD_OK; ++i) {
         if (plan->layers[i].skipped || plan->layers[i].fused_into >= 0) { ms_per_layer[i] = 0.0f; continue; }

@@ -458,7 +458,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
     TLayer &Hd = plan->layers[hi];
     TLayer &Hp = plan->layers[Hd.d.src];
     if (from_layer == hi) {
-        g_trace_layer = hi;
+        fd_hs().trace_layer = hi;
         const int nb = ceil_div(Hd.M, 256);
         if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_part(plan, hi), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
         else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_part(plan, hi), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
@@ -481,7 +481,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         TLayer &L = plan->layers[i];
         const fd_layer_desc &d = L.d;
         int nblk = 0;
-        g_trace_layer = i;
+        fd_hs().trace_layer = i;
         switch (d.op) {
         case FD_OP_STEM: {
             const int nblocks_w = ceil_div((long)plan->B * L.out_h * L.out_w, 256);   // blocks of 256 pixels of the flat [B*Ho*Wo] order (they may straddle images)
@@ -521,7 +521,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
         }
         }
     }
-    g_trace_layer = -1;
+    fd_hs().trace_layer = -1;
     return flush_weights(c);                                  // one launch reduces the weight-gradient partials of every unit of this range
 }
 

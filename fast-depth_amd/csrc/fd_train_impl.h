@@ -80,7 +80,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         const TLayer &L = plan->layers[i];
         const fd_layer_desc &d = L.d;
         const fd_layer_params &q = params[i];
-        g_trace_layer = i;
+        fd_hs().trace_layer = i;
         if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
         T *z = twt<T>(plan, L.z_off);
         const TLayer *P = d.src >= 0 ? &plan->layers[d.src] : nullptr;
@@ -164,7 +164,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
     else
         FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
     int rc = check_launch("fd_head_apply_f32");
-    g_trace_layer = -1;
+    fd_hs().trace_layer = -1;
     if (rc) return rc;
     plan->forward_done = true;
     return FD_OK;
