@@ -9,9 +9,12 @@ One "step" = one inference forward of a batch of 32 synthetic 224x224 RGB frames
 (BASELINE.json configs[1]: unpruned model, batch 32, fp32, 1xMI355X, HIP kernels).  With N > 1 every rank
 runs its own batch of 32 (weak scaling; inference shards over frames with no collective, SURVEY.md 8(e));
 the timed region is bracketed by barrier + torch.cuda.synchronize() and the max over ranks is taken.  Setup (plan creation,
-weight packing and 40 untimed forwards that bring a freshly leased GPU up to its clocks: `config.untimed_device_wakeup_steps_before_warmup`)
+weight packing and 0.3 s of untimed forwards that take a freshly leased GPU past its power-management transient: `config.untimed_device_wakeup_steps_before_warmup`)
 precedes the W warm-up steps; exactly K full steps are timed.
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  windows_ms_per_step, host_enqueue_ms_per_step
+                    six consecutive windows of K steps (the first IS the headline) and the host's enqueue time per step of the headline window:
+                    shows whether a run sat on a clock transient (a later window faster), on the host, or on neither
   roofline          the kernel symbol with the largest share of device time, timed live with HIP events on the launch stream,
                     priced against the fp32 MFMA peak or HBM bandwidth (MI355X_MICROARCH.md); `traffic` from the committed PMC summary
   whole_step        algorithmic bytes / flops of the step and its layer-wise roofline bound sum_l max(bytes/HBM, flops/MFMA)
@@ -481,6 +484,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    last_host_enqueue = [0.0]
+
     def time_forward(mod, xin, steps, warmup, fn=None):
         ring = xin if isinstance(xin, list) else None
         it = [0]
@@ -496,10 +501,12 @@ def main():
             t0 = time.perf_counter()
             for _ in range(steps):
                 y = fn()
+            t_host = time.perf_counter() - t0                     # the host has enqueued all K steps; the device is still running them
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
             barrier()
         assert torch.isfinite(y).all()
+        last_host_enqueue[0] = t_host
         return max_over_ranks(elapsed)
 
     def make_train_engine(dtype):
@@ -580,14 +587,28 @@ def main():
         return
 
     # ---- headline: configs[1] ---------------------------------------------------------------------------------------------------------
-    # Device wake-up, part of setup like plan creation and weight packing: a freshly leased GPU ramps its clocks over the first tens of
-    # milliseconds of work, and a K = 20, W = 5 run (16 ms timed) would otherwise report the ramp (measured: 40.2 k instead of 41.0 k
-    # frames/s).  These forwards are untimed and come BEFORE the W warm-up steps; the timed region is still exactly K full steps.
-    PREROLL = 40
+    # Device wake-up, part of setup like plan creation and weight packing.  A freshly leased GPU does not run at its sustained clocks at once: measured on
+    # the round-5 boxes with six back-to-back windows of K = 20 steps (`windows_ms_per_step`, profiles/r05/bench_driver_protocol_*.json), the step
+    # time is 0.75 ms, then 0.79 - 0.80 ms for a 15 - 30 ms stretch that begins 40 - 70 ms after the first forward (power management settling), then
+    # 0.75 ms for good.  With the round-4 wake-up of 40 forwards (30 ms) the K = 20, W = 5 window (16 ms) started 34 ms in and fell into that stretch
+    # in one run out of three (40.1 k instead of 42.4 k frames/s; the round-4 driver run: 39.7 k).  The wake-up therefore runs forwards for
+    # WAKEUP_S seconds (>= 40 of them), untimed, BEFORE the W warm-up steps; the timed region is still exactly K full steps.
+    WAKEUP_S = 0.3
+    PREROLL = 0
+    t_wake = time.perf_counter()
     with torch.no_grad():
-        for _ in range(PREROLL):
-            model(x)
+        while PREROLL < 40 or time.perf_counter() - t_wake < WAKEUP_S:
+            for _ in range(20):
+                model(x)
+            torch.cuda.synchronize()
+            PREROLL += 20
     elapsed = time_forward(model, x_ring, args.steps, args.warmup)
+    host_enqueue_ms = last_host_enqueue[0] / args.steps * 1e3
+    # The headline is the window above (the contract's K steps after W warm-up steps).  NWIN - 1 further windows of K steps each follow it
+    # back to back, untimed by the contract: they show whether the first window sat on a clock ramp (later windows faster), on the host
+    # (host_enqueue_ms_per_step close to ms_per_step) or on neither.
+    NWIN = 6
+    windows = [round(elapsed / args.steps * 1e3, 4)] + [round(time_forward(model, x_ring, args.steps, 0) / args.steps * 1e3, 4) for _ in range(NWIN - 1)]
     roof, whole, kernels, n_kernels = inference_profile(eng, x, args.profile_steps, MFMA_F32_PEAK_TFLOPS)
     ms_per_step = elapsed / args.steps * 1e3
     whole["frac_of_roofline"] = round(whole["roofline_bound_ms"] / ms_per_step, 4)
@@ -638,6 +659,7 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "windows_ms_per_step": windows, "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
             "data": "synthetic (U[0,1) NYU-v2-shaped frames, random-init weights with calibrated BN statistics)",
             "config": {"workload": "configs[1]: MobileNet-NNConv5(dw)+skipadd unpruned, batch=32 per GPU, 224x224 fp32 "
                                    "inference forward, inputs resident in HBM", "batch_per_gpu": args.batch,
