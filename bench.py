@@ -516,13 +516,9 @@ def main():
         tm = tm.to(dev).train()
         kw = dict(lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=(dist.group.WORLD if dist is not None else None), force_buckets=force_dist, dtype=dtype,
                   grad_exchange_dtype=torch.bfloat16 if args.grad_exchange == "bf16" else torch.float32)
-        try:
-            return TrainEngine(tm, _elide_collectives=os.environ.get("FD_BENCH_FORCE_DIST") == "2", **kw)   # (measurement hook, one rank: the machinery without the ncclAllReduce calls)
-        except Exception as e:                                 # the library's own RCCL communicator could not be set up: the torch.distributed route still is RCCL
-            if dist is None:
-                raise
-            sys.stderr.write("bench.py: library-issued exchange unavailable (%r); falling back to torch.distributed.all_reduce per bucket\n" % (e,))
-            return TrainEngine(tm, exchange="torch", **kw)
+        # exchange="auto": the library-issued RCCL exchange where every rank's communicator comes up, otherwise torch.distributed.all_reduce per bucket --
+        # decided JOINTLY by the ranks inside TrainEngine (a rank-local fallback here would pair one rank's all-reduce with its peers' rendezvous broadcast)
+        return TrainEngine(tm, _elide_collectives=os.environ.get("FD_BENCH_FORCE_DIST") == "2", **kw)   # (measurement hook, one rank: the machinery without the ncclAllReduce calls)
 
     gt = torch.Generator().manual_seed(1)
     # synthetic depth, U[0.7, 10) m: one target per input batch of the ring (the train loops rotate (input, target) pairs like the inference loop)

@@ -348,6 +348,73 @@ template <typename T> struct fd_lane<T, 8> {
     static __device__ __forceinline__ vec lds_round(vec v) { return cvt(fd_pack8v(T{}, v)); }
 };
 
+// ---- BatchNorm statistics rows (round 5): order-independent, bit-reproducible accumulation of per-workgroup partial sums ----------
+// The train step's BatchNorm reductions -- forward (sum z, sum z^2), backward (sum G, sum G*xhat) -- used to be "one fp32 partial row per
+// workgroup -> a finalisation launch that sums 25 ... 6272 rows -> a table": 76 launches at the per-launch floor per step.  Now every
+// producer workgroup ADDS its partial sums into a few shared rows with 64-bit INTEGER no-return atomics, and the consumer kernels derive their
+// per-channel coefficients from those rows in their prologue (fd_kernels_train.h: fd_stat_table_block).  Integer addition is associative and
+// commutative, so the totals -- and everything derived from them -- are the same bits whatever order the workgroups arrive in.
+//
+// Fixed point without a range / precision compromise: a partial v (fp32) is placed EXACTLY -- mantissa shifted, no rounding -- into one of
+// FD_STAT_BINS accumulators chosen by its own binary exponent; bin b holds multiples of 2^-frac[b]:
+//     forward  (sums of z, z^2):        |v| < 2^-8  -> frac 56,   2^-8  <= |v| < 2^16 -> frac 32,   |v| >= 2^16 -> frac 8
+//     backward (sums of G, G * xhat):   |v| < 2^-32 -> frac 80,   2^-32 <= |v| < 2^-8 -> frac 56,   |v| >= 2^-8  -> frac 32
+// so a 24-bit mantissa lands at bit positions < 2^48 of an int64 and 2^14 partials fit with room to spare, across 72 binary orders of magnitude
+// (below the lowest bin's 2^-33 * 2^-frac0 ... values lose low bits: < 2^-89 (forward) / 2^-113 (backward) each; fp32 denormals count as 0; above 2^40
+// (forward) / 2^16 (backward) per PARTIAL the value saturates -- a diverged network).  The total of a column is then the EXACT sum of the fp32 partials,
+// reconstructed in double from the three bins (fd_stat_total).
+// One address takes an atomic every ~22 ns whatever the scope (tools/microbench/stat_atomics.hip, MI355X: 6272 workgroups x 128 columns into ONE row
+// 135 us, into 8 rows 18 us), so a unit's partials are dealt to nr rows (a power of two <= 16, chosen by the plan so that an address sees <= ~256
+// adds: row = workgroup number & (nr - 1)) and the consumer adds the nr x 3 integers of a column.
+// Layout of a unit's rows: int64 [nr][FD_STAT_BINS][2][C]  (2 = first / second sum).  The plan zeroes all rows of a step with one memset.
+#define FD_STAT_BINS 3
+#define FD_STAT_MAX_ROWS 16
+#define FD_STAT_FWD 0
+#define FD_STAT_BWD 1
+struct fd_stat_rows { long long *rows; int nr; };        // nr: power of two; rows == nullptr: no statistics wanted
+#ifdef FD_EMU
+inline void fd_atomic_add_i64(long long *p, long long v) { *p += v; }
+#else
+__device__ __forceinline__ void fd_atomic_add_i64(long long *p, long long v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // result unused: a no-return global_atomic_add_x2
+}
+#endif
+template <int DIR> struct fd_stat_fmt {
+    static constexpr int lo = DIR == FD_STAT_FWD ? -8 : -32, hi = DIR == FD_STAT_FWD ? 16 : -8;     // bin boundaries (binary exponents)
+    static constexpr int f0 = DIR == FD_STAT_FWD ? 56 : 80, f1 = f0 - 24, f2 = f0 - 48;
+};
+// adds the fp32 partial v of column c (sum `which`) of workgroup number blk to the unit's rows
+template <int DIR>
+__device__ __forceinline__ void fd_stat_add(const fd_stat_rows &d, long blk, int C, int which, int c, float v)
+{
+    typedef fd_stat_fmt<DIR> F;
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    int e = (int)((u >> 23) & 255u) - 127;
+    if (e == -127) return;                                  // +-0 and denormals: nothing to add
+    const int bin = e < F::lo ? 0 : (e < F::hi ? 1 : 2);
+    const int frac = bin == 0 ? F::f0 : (bin == 1 ? F::f1 : F::f2);
+    if (e > 47 - frac) e = 47 - frac;                       // (saturation, highest bin only: |partial| >= 2^40 forward / 2^16 backward)
+    const long long m = (long long)((u & 0x7fffffu) | 0x800000u);
+    const int sh = e + frac - 23;                           // >= 0 except below the lowest bin's exact range
+    long long iv = sh >= 0 ? (m << sh) : (sh > -24 ? (m >> -sh) : 0);
+    if (u >> 31) iv = -iv;
+    if (iv == 0) return;
+    fd_atomic_add_i64(d.rows + ((((long)(blk & (d.nr - 1)) * FD_STAT_BINS + bin) * 2 + which) * C + c), iv);
+}
+// the exact total of column c (sum `which`) over the partials in rows r0, r0 + rstep, ... < nr (r0 = 0, rstep = 1: of the whole unit), as a double
+template <int DIR>
+__device__ __forceinline__ double fd_stat_total(const long long *__restrict__ rows, int nr, int C, int which, int c, int r0, int rstep)
+{
+    typedef fd_stat_fmt<DIR> F;
+    long long a0 = 0, a1 = 0, a2 = 0;
+    for (int r = r0; r < nr; r += rstep) {
+        const long long *p = rows + (((long)r * FD_STAT_BINS) * 2 + which) * C + c;
+        a0 += p[0]; a1 += p[2 * (long)C]; a2 += p[4 * (long)C];
+    }
+    return ldexp((double)a0, -F::f0) + ldexp((double)a1, -F::f1) + ldexp((double)a2, -F::f2);
+}
+
 // ---- device-coherent accesses ("last arriver" reductions: stream-K partial tiles, fused two-level reductions of the train step) ----
 // Device-coherent accesses for partial results and their arrival counters.  MI355X has one L2 per XCD and the L2s are not coherent
 // with each other inside a kernel; an agent-scope FENCE would make them so by writing back / invalidating the whole L2

@@ -52,70 +52,43 @@ __device__ __forceinline__ fd_f32x8 fd_actmask4(fd_f32x8 y)
     return r;
 }
 
-// ---- deterministic partial reductions of the backward pass (bodies shared by the single kernels and by
-// fd_bwd_reduce_pair_f32; (bx, by, ny) = column block, slice, slice count: see fd_two_level_tail) -------------------------------
-// (the weight-gradient partials are reduced by fd_reduce_weights_batch_f32 below)
-// BatchNorm backward finalize: partial sums of (G, G*xhat) -> dbeta, dgamma and the coefficient table of dz
-__device__ __forceinline__ void fd_bn_bwd_finalize_dev(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
-                                                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
-                                                       double *__restrict__ slices, int *__restrict__ counters, double (*sh)[64][2], int *s_last,
-                                                       int bx, int by, int ny)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = bx * 64 + lane;
-    const int r0 = by * rps;
-    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
-    float sc_c = 0.0f, mean_c = 0.0f, invstd_c = 0.0f;       // the unit's forward table: requested before the row sums (independent of them)
-    if (wave == 0 && c < C) { sc_c = st[FD_ST_SCALE * C + c]; mean_c = st[FD_ST_MEAN * C + c]; invstd_c = st[FD_ST_INVSTD * C + c]; }
-    double s, q;
-    fd_sum_partial_rows(part, r0, r1, wave, C, c, c < C, s, q);
-    sh[wave][lane][0] = s; sh[wave][lane][1] = q;
-    __syncthreads();
-    if (wave == 0) {
-        s = 0.0; q = 0.0;
-        for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
-    }
-    __syncthreads();
-    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, s_last, sh, bx, by, ny)) return;
-    if (wave == 0 && c < C) {
-        dbeta[c] = (float)s;
-        dgamma[c] = (float)q;
-        const double sc = sc_c, mean = mean_c, invstd = invstd_c;
-        coef[FD_CF_A * C + c] = (float)sc;
-        coef[FD_CF_C1 * C + c] = (float)(s / n);
-        coef[FD_CF_MU * C + c] = (float)mean;
-        coef[FD_CF_C2 * C + c] = (float)(invstd * q / n);
-    }
-}
-
-static __global__ void __launch_bounds__(1024)
-fd_bn_bwd_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, const float *__restrict__ st,
-                       float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
-                       double *__restrict__ slices, int *__restrict__ counters)
-{
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
-    fd_bn_bwd_finalize_dev(part, nblk, rps, C, n, st, dgamma, dbeta, coef, slices, counters, sh, &s_last, blockIdx.x, blockIdx.y, gridDim.y);
-}
-
-// BatchNorm-backward finalisation of a unit INSIDE the unit's own first backward kernel (the backward mirror of fd_bn_finalize_block, fd_kernels_train.h):
-// the partial rows (sum G, sum G*xhat) its consumer's backward kernel left are few (<= FD_FIN_MAX_ROWS: the 14 x 14 / 7 x 7 units), so every workgroup
-// sums them for the CB channels of its block -- same fixed order everywhere: identical bits -- and keeps the four coefficients in LDS; the designated
-// workgroup also writes the parameter gradients (dgamma, dbeta) and the table.  Replaces a fd_bn_bwd_finalize_f32 launch at the per-launch floor.
-// sh: >= 4 KiB of LDS that is dead until the next barrier; s_cf: [4][CB] floats (A, C1, MU, C2) that nothing else touches.
+// ---- BatchNorm backward finalisation: the unit's statistics rows (sum G, sum G*xhat -- added by its consumer's backward-data kernel, fd_stat_add)
+// -> dbeta, dgamma and the coefficient table of dz.  Either inside the unit's own first backward kernel (fd_bstat_table_block: every workgroup
+// derives the coefficients of ITS channels from the same integers -- identical bits --, the designated workgroup also writes the parameter
+// gradients and the table) or as a launch of its own (fd_bn_bwd_finalize_rows_f32: one work-item per channel).
 struct fd_bn_bwd_fin {
-    const float *part;               // null: the table `coef` was finalised by its own launch
-    int nblk;
+    const long long *rows;           // null: the table `coef` was finalised by its own launch
+    int nr;                          // statistics rows (power of two)
     int cf_off;                      // byte offset of s_cf in the kernel's dynamic LDS (the plan appends it to the kernel's own request)
     double n;
     const float *st;                 // the unit's forward table
     float *dgamma, *dbeta, *coef;
 };
-
-#ifndef FD_BWD_FIN_U
-#define FD_BWD_FIN_U 4
-#endif
-__device__ __forceinline__ void fd_bn_bwd_finalize_block(const fd_bn_bwd_fin &f, double *sh, float *s_cf, int c0, int CB, int C, int tid, bool writer)
+struct fd_bn_bwd_coef { float a, c1, mu, c2; };
+__device__ __forceinline__ fd_bn_bwd_coef fd_bn_bwd_coef_of(double s, double q, double n, float sc_c, float mean_c, float invstd_c)
+{
+    fd_bn_bwd_coef k;
+    k.a = sc_c; k.c1 = (float)(s / n); k.mu = mean_c; k.c2 = (float)((double)invstd_c * q / n);
+    return k;
+}
+__device__ __forceinline__ void fd_bn_bwd_publish(const fd_bn_bwd_fin &f, int C, int c, double s, double q, const fd_bn_bwd_coef &k)
+{
+    f.dbeta[c] = (float)s;
+    f.dgamma[c] = (float)q;
+    f.coef[FD_CF_A * C + c] = k.a; f.coef[FD_CF_C1 * C + c] = k.c1; f.coef[FD_CF_MU * C + c] = k.mu; f.coef[FD_CF_C2 * C + c] = k.c2;
+}
+static __global__ void __launch_bounds__(256)
+fd_bn_bwd_finalize_rows_f32(const fd_bn_bwd_fin f, int C)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc_c = f.st[FD_ST_SCALE * C + c], mean_c = f.st[FD_ST_MEAN * C + c], invstd_c = f.st[FD_ST_INVSTD * C + c];
+    const double s = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 0, c, 0, 1), q = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 1, c, 0, 1);
+    fd_bn_bwd_publish(f, C, c, s, q, fd_bn_bwd_coef_of(s, q, f.n, sc_c, mean_c, invstd_c));
+}
+// Channel-block form (the backward mirror of fd_stat_table_block, fd_kernels_train.h): 256 work-items, the CB <= 64 channels [c0, c0 + CB).
+// sh: >= 4 KiB of LDS that is dead until the next barrier; s_cf: [4][CB] floats (A, C1, MU, C2) that nothing else touches.
+__device__ __forceinline__ void fd_bstat_table_block(const fd_bn_bwd_fin &f, double *sh, float *s_cf, int c0, int CB, int C, int tid, bool writer)
 {
     const int ch = tid & (CB - 1), rg = tid / CB, RG = 256 / CB;
     const int c = c0 + ch;
@@ -123,31 +96,19 @@ __device__ __forceinline__ void fd_bn_bwd_finalize_block(const fd_bn_bwd_fin &f,
     float sc_c = 0.0f, mean_c = 0.0f, invstd_c = 0.0f;
     if (rg == 0 && ok) { sc_c = f.st[FD_ST_SCALE * C + c]; mean_c = f.st[FD_ST_MEAN * C + c]; invstd_c = f.st[FD_ST_INVSTD * C + c]; }
     double s = 0.0, q = 0.0;
-    if (ok) {
-        for (int b = rg; b < f.nblk; b += RG * FD_BWD_FIN_U) {      // (FD_BWD_FIN_U rows in flight: the block is inlined into register-heavy kernels)
-            float vs[FD_BWD_FIN_U], vq[FD_BWD_FIN_U];
-#pragma unroll
-            for (int u = 0; u < FD_BWD_FIN_U; ++u) {
-                const int row = b + RG * u < f.nblk ? b + RG * u : f.nblk - 1;
-                vs[u] = f.part[(long)row * 2 * C + c]; vq[u] = f.part[(long)row * 2 * C + C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < FD_BWD_FIN_U; ++u)
-                if (b + RG * u < f.nblk) { s += (double)vs[u]; q += (double)vq[u]; }
-        }
+    if (ok && rg < f.nr) {
+        s = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 0, c, rg, RG);
+        q = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 1, c, rg, RG);
     }
     sh[2 * tid] = s; sh[2 * tid + 1] = q;
     __syncthreads();
     if (rg == 0) {
         s = 0.0; q = 0.0;
         for (int r = 0; r < RG; ++r) { s += sh[2 * (r * CB + ch)]; q += sh[2 * (r * CB + ch) + 1]; }
-        const float a = ok ? sc_c : 0.0f, c1 = ok ? (float)(s / f.n) : 0.0f, mu = ok ? mean_c : 0.0f, c2 = ok ? (float)((double)invstd_c * q / f.n) : 0.0f;
-        s_cf[FD_CF_A * CB + ch] = a; s_cf[FD_CF_C1 * CB + ch] = c1; s_cf[FD_CF_MU * CB + ch] = mu; s_cf[FD_CF_C2 * CB + ch] = c2;
-        if (writer && ok) {
-            f.dbeta[c] = (float)s;
-            f.dgamma[c] = (float)q;
-            f.coef[FD_CF_A * C + c] = a; f.coef[FD_CF_C1 * C + c] = c1; f.coef[FD_CF_MU * C + c] = mu; f.coef[FD_CF_C2 * C + c] = c2;
-        }
+        fd_bn_bwd_coef k = fd_bn_bwd_coef_of(s, q, f.n, sc_c, mean_c, invstd_c);
+        if (!ok) { k.a = 0.0f; k.c1 = 0.0f; k.mu = 0.0f; k.c2 = 0.0f; }
+        s_cf[FD_CF_A * CB + ch] = k.a; s_cf[FD_CF_C1 * CB + ch] = k.c1; s_cf[FD_CF_MU * CB + ch] = k.mu; s_cf[FD_CF_C2 * CB + ch] = k.c2;
+        if (writer && ok) fd_bn_bwd_publish(f, C, c, s, q, k);
     }
     __syncthreads();
 }
@@ -388,7 +349,7 @@ fd_sgd_f32(const fd_sgd_rec *__restrict__ table, int n_tensors, float lr, float 
 template <int ACT>
 __global__ void __launch_bounds__(256)
 fd_head_bwd_reduce_f32(const float *__restrict__ dpred, const float *__restrict__ zlow, const float *__restrict__ st,
-                       float *__restrict__ g, float *__restrict__ part, long npix, int h, int w, int up)
+                       float *__restrict__ g, fd_stat_rows sr, long npix, int h, int w, int up)
 {
     __shared__ float red[8];
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
@@ -415,8 +376,8 @@ fd_head_bwd_reduce_f32(const float *__restrict__ dpred, const float *__restrict_
     if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = dy; red[(threadIdx.x >> 6) * 2 + 1] = dyx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[(long)blockIdx.x * 2] = red[0] + red[2] + red[4] + red[6];
-        part[(long)blockIdx.x * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+        fd_stat_add<FD_STAT_BWD>(sr, blockIdx.x, 1, 0, 0, red[0] + red[2] + red[4] + red[6]);
+        fd_stat_add<FD_STAT_BWD>(sr, blockIdx.x, 1, 1, 0, red[1] + red[3] + red[5] + red[7]);
     }
 }
 
@@ -427,7 +388,7 @@ template <typename T, int ACT_IN, int PPB>
 __global__ void __launch_bounds__(256)
 fd_head_bwd(const float *__restrict__ g, const float *__restrict__ zlow, const float *__restrict__ coef,
                 const T *__restrict__ zin, const float *__restrict__ st_in, const float *__restrict__ w,
-                T *__restrict__ g_in, float *__restrict__ part_in, float *__restrict__ wpart, long npix, int Cin)
+                T *__restrict__ g_in, fd_stat_rows sr_in, float *__restrict__ wpart, long npix, int Cin)
 {
     // work-item (group = tid>>3 in 0..31, l8): channel groups c = l8*4 + 32*j; block covers 32*PPB pixels
     FD_DYN_SMEM(smem_raw);
@@ -463,8 +424,8 @@ fd_head_bwd(const float *__restrict__ g, const float *__restrict__ zlow, const f
             const float *r = red + (gI * Cin + c4) * 3;
             a += r[k]; b += r[4 + k]; d += r[8 + k];
         }
-        part_in[(long)blockIdx.x * 2 * Cin + c] = a;
-        part_in[(long)blockIdx.x * 2 * Cin + Cin + c] = b;
+        fd_stat_add<FD_STAT_BWD>(sr_in, blockIdx.x, Cin, 0, c, a);
+        fd_stat_add<FD_STAT_BWD>(sr_in, blockIdx.x, Cin, 1, c, b);
         wpart[(long)blockIdx.x * Cin + c] = d;
     }
 }
@@ -480,7 +441,7 @@ template <int ACT_IN, int ADD_SG>
 __device__ __forceinline__ void              // blk: linear workgroup number (blockIdx.x of the plain kernel; the paired launch fd_pw_bwd_f32 passes its own)
 fd_pw_dgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
-                const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part,
+                const float *__restrict__ SG, float *__restrict__ Gin, fd_stat_rows sr,
                 int M, int N, int K, int m_tiles, int k_tiles, const unsigned blk)
 {
     constexpr int BM = 64, BKO = 64, BR = 32;                 // output tile 64 x 64, reduction step 32
@@ -607,18 +568,18 @@ fd_pw_dgrad_f32_body(const float *__restrict__ G, const float *__restrict__ Z, c
     if (lane < 32) { red[(wm * 2 + 0) * 64 + wk * 32 + lane] = s; red[(wm * 2 + 1) * 64 + wk * 32 + lane] = q; }
     __syncthreads();
     if (tid < 64 && k0 + tid < K) {
-        part[(long)mt * 2 * K + k0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
-        part[(long)mt * 2 * K + K + k0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+        fd_stat_add<FD_STAT_BWD>(sr, mt, K, 0, k0 + tid, red[0 * 64 + tid] + red[2 * 64 + tid]);
+        fd_stat_add<FD_STAT_BWD>(sr, mt, K, 1, k0 + tid, red[1 * 64 + tid] + red[3 * 64 + tid]);
     }
 }
 template <int ACT_IN, int ADD_SG>
 __global__ void __launch_bounds__(256)
 fd_pw_dgrad_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
-                const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part,
+                const float *__restrict__ SG, float *__restrict__ Gin, fd_stat_rows sr,
                 int M, int N, int K, int m_tiles, int k_tiles)
 {
-    fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, part, M, N, K, m_tiles, k_tiles, blockIdx.x);
+    fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, sr, M, N, K, m_tiles, k_tiles, blockIdx.x);
 }
 
 
@@ -721,11 +682,11 @@ template <int ACT_IN, int ADD_SG>
 __global__ void __launch_bounds__(256)
 fd_pw_bwd_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
               const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
-              const float *__restrict__ SG, float *__restrict__ Gin, float *__restrict__ part, float *__restrict__ wpart,
+              const float *__restrict__ SG, float *__restrict__ Gin, fd_stat_rows sr, float *__restrict__ wpart,
               int M, int N, int K, int m_tiles, int k_tiles, int n_dgrad, int tiles_w, int rows_per_split)
 {
     if ((int)blockIdx.x < n_dgrad) {
-        fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, part, M, N, K, m_tiles, k_tiles, blockIdx.x);
+        fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, sr, M, N, K, m_tiles, k_tiles, blockIdx.x);
     } else {
         const int b = (int)blockIdx.x - n_dgrad;
         const int by = b / tiles_w;
@@ -741,7 +702,7 @@ fd_pw_bwd_f32(const float *__restrict__ G, const float *__restrict__ Z, const fl
 //   MODE 0: G_in = mask_in(y_in) * (din (+ skipgrad))                              (input was a_in)
 //   MODE 1: G_in(low res) = mask_in(y_in) * sum_{2x2} din                          (input was up2(a_in))
 //   MODE 2: as MODE 1, and skipgrad_out = din at full resolution                   (input was up2(a_in) + a_skip)
-// plus the producer's BN partials  part[blk*2*C + {0,C} + c].
+// plus the producer's BN partial sums, added to ITS statistics rows (fd_stat_add).
 // ------------------------------------------------------------------------------------------------
 // (body: bm = logical (tile, channel block, image) of this workgroup, grid_x = tiles per image -- the plain kernel passes fd_xcd_image_map() /
 // gridDim.x, the paired launch fd_dw_bwd its own numbering)
@@ -749,7 +710,7 @@ template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N, boo
 __device__ __forceinline__ void
 fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
-                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
+                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, fd_stat_rows sr,
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x,
                 const fd_bn_bwd_fin &fin)
 {
@@ -784,7 +745,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
         wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
     vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
-    const bool fin_here = FIN && fin.part != nullptr;               // this unit's BatchNorm backward is finalised here, after the first batch of patch loads has been issued
+    const bool fin_here = FIN && fin.rows != nullptr;               // this unit's BatchNorm backward is finalised here, after the first batch of patch loads has been issued
     if (c_ok && !fin_here) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = K == 3 ? FD_DW_U3 : 8;
@@ -807,7 +768,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
         }
         if (fin_here && base == pt) {
             float *s_cf = reinterpret_cast<float *>(smem_raw + fin.cf_off);
-            fd_bn_bwd_finalize_block(fin, reinterpret_cast<double *>(smem_raw), s_cf, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
+            fd_bstat_table_block(fin, reinterpret_cast<double *>(smem_raw), s_cf, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
             if (c_ok) { cA = LN::ldf(s_cf + FD_CF_A * CB + c4 * N); c1 = LN::ldf(s_cf + FD_CF_C1 * CB + c4 * N); cM = LN::ldf(s_cf + FD_CF_MU * CB + c4 * N); c2 = LN::ldf(s_cf + FD_CF_C2 * CB + c4 * N); }
         }
 #pragma unroll
@@ -953,8 +914,8 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
     if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
         const long blk = (long)bm.z * grid_x + bm.x;
         if (c0 + tid * N < Cp) {
-            LN::stf(part + blk * 2 * Cp + c0 + tid * N, ssum);
-            LN::stf(part + blk * 2 * Cp + Cp + c0 + tid * N, ssx);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 0, c0 + tid * N + j, ssum[j]); fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 1, c0 + tid * N + j, ssx[j]); }
         }
     }
 }
@@ -962,11 +923,11 @@ template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N>
 __global__ void __launch_bounds__(256)
 fd_dw_dgrad(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
-                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part,
+                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, fd_stat_rows sr,
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr)
 {
     const fd_bn_bwd_fin no_fin{};
-    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG, N>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, part, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit, pstr,
+    fd_dw_dgrad_body<T, K, S, MODE, ACT_IN, ADD_SG, N>(G, Z, coef, w, Zin, st_in, SG, Gin, SGout, sr, Hin, Win, Ho, Wo, C, cbq, TH, TW, tiles_x, csplit, pstr,
                                                     fd_xcd_image_map(), (int)gridDim.x, no_fin);
 }
 
@@ -1049,7 +1010,7 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     if (MODE == 2) { s2 = LN::ldf(st2 + FD_ST_SCALE * C + tab_c); t2 = LN::ldf(st2 + FD_ST_SHIFT * C + tab_c); }
     const int npx_in = TH_in * TW_in;
     constexpr int U = sizeof(T) == 2 ? (K == 3 ? FD_DW_WU3 : FD_DW_WU5) : 4;
-    const bool fin_now = FIN && fin.part != nullptr && ti == 0;   // the unit's BatchNorm backward finalised here (every role of a paired launch computes the same bits; role 0 writes them)
+    const bool fin_now = FIN && fin.rows != nullptr && ti == 0;   // the unit's BatchNorm backward finalised here (every role of a paired launch computes the same bits; role 0 writes them)
     fd_px_walk wk(pt, npt, TW_in);
     for (int base = pt; base < npx_in || (fin_now && base == pt); base += npt * U) {
         vec v[U], sk[U];
@@ -1075,7 +1036,7 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
             }
         }
         if (fin_now && base == pt)
-            fd_bn_bwd_finalize_block(fin, reinterpret_cast<double *>(smem_raw), reinterpret_cast<float *>(smem_raw + fin.cf_off), c0, CB, C, tid, false);
+            fd_bstat_table_block(fin, reinterpret_cast<double *>(smem_raw), reinterpret_cast<float *>(smem_raw + fin.cf_off), c0, CB, C, tid, false);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int px = base + u * npt;
@@ -1092,7 +1053,7 @@ fd_dw_wgrad_body(const T *__restrict__ zin, const float *__restrict__ st1, const
     // dz of this work-item's output strip (pixel-thread pt stages strip pt: TH*TW/4 <= npt) -> s_dz
     FD_OPAQUE(tab_c);
     {
-        const bool cf_lds = FIN && fin.part != nullptr;
+        const bool cf_lds = FIN && fin.rows != nullptr;
         const float *cf = cf_lds ? reinterpret_cast<const float *>(smem_raw + fin.cf_off) + c4 * N : coef + tab_c;     // [4][CB] in LDS / [4][C] in memory
         const int cfp = cf_lds ? CB : C;
         const vec cA = LN::ldf(cf + FD_CF_A * cfp), c1 = LN::ldf(cf + FD_CF_C1 * cfp), cM = LN::ldf(cf + FD_CF_MU * cfp), c2 = LN::ldf(cf + FD_CF_C2 * cfp);
@@ -1179,12 +1140,13 @@ template <typename T> struct fd_dw_bwd_args {
     const T *G, *Z, *Zin, *Zskip, *SG;
     T *Gin, *SGout;
     const float *coef, *w, *st_in, *st_skip;
-    float *part, *wpart;
+    fd_stat_rows sr;                                   // statistics rows of the PRODUCER (sum G_in, sum G_in * xhat_in)
+    float *wpart;
     int Hin, Win, Ho, Wo, C, cbq, csplit, pstr;        // pstr: LDS patch pitch in floats
     int d_th, d_tw, d_tiles_x, d_gx, d_gy;             // backward-data: INPUT-space tiles; grid (d_gx tiles, d_gy channel blocks) per image
     int w_th, w_tw, w_tiles_x, w_tpw, w_gx, w_gy;      // backward-weights: OUTPUT-space tiles, tpw of them per workgroup
     int B;
-    fd_bn_bwd_fin fin;                                 // part != null: this unit's BatchNorm backward is finalised by these workgroups (fd_bn_bwd_finalize_block)
+    fd_bn_bwd_fin fin;                                 // rows != null: this unit's BatchNorm backward is finalised by these workgroups (fd_bstat_table_block)
 };
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG, int N, bool FIN = false>
 __global__ void __launch_bounds__(256)
@@ -1194,7 +1156,7 @@ fd_dw_bwd(const fd_dw_bwd_args<T> a)
     fd_blk3 bm = pb.b;
     if (pb.role == 0) {
         bm.y = bm.x / a.d_gx; bm.x -= bm.y * a.d_gx;
-        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG, N, FIN>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.part, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
+        fd_dw_dgrad_body<T, K, S, MODE, ACT1, ADD_SG, N, FIN>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.SGout, a.sr, a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq,
                                                       a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, bm, a.d_gx, a.fin);
     } else {
         bm.y = bm.x / a.w_gx; bm.x -= bm.y * a.w_gx;
@@ -1208,7 +1170,7 @@ __device__ __forceinline__ void
 fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef,
                 const float *__restrict__ w, const T *__restrict__ Zin, const float *__restrict__ st_in,
                 const T *__restrict__ Zskip, const float *__restrict__ st_skip,
-                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, float *__restrict__ part, float *__restrict__ wpart,
+                const T *__restrict__ SG, T *__restrict__ Gin, T *__restrict__ SGout, fd_stat_rows sr, float *__restrict__ wpart,
                 int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr, const fd_blk3 bm, const int grid_x,
                 const fd_bn_bwd_fin &fin)
 {
@@ -1248,7 +1210,7 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
         wreg[j] = (i < K * K * CB && c0 + cc < C) ? w[(long)(c0 + cc) * K * K + t] : 0.0f;
     }
     vec cA = LN::zero(), c1 = LN::zero(), cM = LN::zero(), c2 = LN::zero();
-    const bool fin_here = FIN && fin.part != nullptr;               // (see fd_dw_dgrad_body)
+    const bool fin_here = FIN && fin.rows != nullptr;               // (see fd_dw_dgrad_body)
     if (c_ok && !fin_here) { cA = LN::ldf(coef + FD_CF_A * C + cg); c1 = LN::ldf(coef + FD_CF_C1 * C + cg); cM = LN::ldf(coef + FD_CF_MU * C + cg); c2 = LN::ldf(coef + FD_CF_C2 * C + cg); }
     const int npx = PH * PW;
     constexpr int U = 8;
@@ -1271,7 +1233,7 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
         }
         if (fin_here && base == pt) {
             float *s_cf = reinterpret_cast<float *>(smem_raw + fin.cf_off);
-            fd_bn_bwd_finalize_block(fin, reinterpret_cast<double *>(smem_raw), s_cf, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
+            fd_bstat_table_block(fin, reinterpret_cast<double *>(smem_raw), s_cf, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
             if (c_ok) { cA = LN::ldf(s_cf + FD_CF_A * CB + c4 * N); c1 = LN::ldf(s_cf + FD_CF_C1 * CB + c4 * N); cM = LN::ldf(s_cf + FD_CF_MU * CB + c4 * N); c2 = LN::ldf(s_cf + FD_CF_C2 * CB + c4 * N); }
         }
 #pragma unroll
@@ -1490,8 +1452,8 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
     if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
         const long blk = (long)bm.z * grid_x + bm.x;
         if (c0 + tid * N < Cp) {
-            LN::stf(part + blk * 2 * Cp + c0 + tid * N, ssum);
-            LN::stf(part + blk * 2 * Cp + Cp + c0 + tid * N, ssx);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 0, c0 + tid * N + j, ssum[j]); fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 1, c0 + tid * N + j, ssx[j]); }
         }
     }
     // the pixel groups' tap sums meet in LDS: red[pg][ky*K + kx][c4] (fixed order -> deterministic); one partial row per tile
@@ -1524,7 +1486,7 @@ template <typename T, int K, int S, int MODE, int ACT_IN, int ACT2, int ADD_SG, 
 __global__ void __launch_bounds__(256)
 fd_dw_bwd1(const fd_dw_bwd_args<T> a)
 {
-    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG, N, FIN>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.part, a.wpart,
+    fd_dw_bwd1_body<T, K, S, MODE, ACT_IN, ACT2, ADD_SG, N, FIN>(a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.Zskip, a.st_skip, a.SG, a.Gin, a.SGout, a.sr, a.wpart,
                                                          a.Hin, a.Win, a.Ho, a.Wo, a.C, a.cbq, a.d_th, a.d_tw, a.d_tiles_x, a.csplit, a.pstr, fd_xcd_image_map(), (int)gridDim.x, a.fin);
 }
 
@@ -1546,7 +1508,7 @@ template <typename T, int ACT_IN, int ADD_SG>
 __global__ void __launch_bounds__(256)
 fd_dw3s2_dgrad_rows(const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef, const float *__restrict__ w,
                     const T *__restrict__ Zin, const float *__restrict__ st_in, const T *__restrict__ SG, T *__restrict__ Gin,
-                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int TH2)
+                    fd_stat_rows sr, int Hin, int Win, int Ho, int Wo, int C, int TH2)
 {
     __shared__ float red[4 * 64 * 8];
     const int CG = C >> 2;
@@ -1608,8 +1570,8 @@ fd_dw3s2_dgrad_rows(const T *__restrict__ G, const T *__restrict__ Z, const floa
     }
     if (fd_wg_sum_by_channel_group(ssum, ssx, red, CG, tid)) {
         const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
-        fd_st4(part + row * 2 * C + tid * 4, ssum);
-        fd_st4(part + row * 2 * C + C + tid * 4, ssx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fd_stat_add<FD_STAT_BWD>(sr, row, C, 0, tid * 4 + j, ssum[j]); fd_stat_add<FD_STAT_BWD>(sr, row, C, 1, tid * 4 + j, ssx[j]); }
     }
 }
 

@@ -33,6 +33,7 @@
 //     for the intermediate tensor (3x3 stride 1 / 2, 5x5, and 5x5 on the nearest-x2 upsampling of the tile: FDW template parameter).
 #pragma once
 #include "fd_device.h"
+#include "fd_bn_stats.h"
 
 // the depthwise layer fused behind a pointwise GEMM (fd_pw_gemm16_f32<..., FDW = its kernel size>)
 struct fd_dwfuse {
@@ -53,14 +54,17 @@ __device__ long long fd_gemm16_probe[4 * 4096];          // measurement aid (too
 //   * A = the producer's RAW output: every A fragment becomes act(a * s[k] + t[k]) right before its first MFMA (the producer's BatchNorm table,
 //     zero beyond K, sits in LDS behind the ring; a lane's four k of a K tile are the same for all TM fragments: two ds_read_b128 per K tile);
 //   * Wt = the LIVE weights [N][K] (K % 32 == 0: pitch K32 = K), no bias, no activation: the RAW conv output leaves the kernel;
-//   * the epilogue adds the per-column partial statistics of the tile's valid rows, part[mt*2*N + {0, N} + col] (fd_bn_finalize_f32 / _block).
+//   * the epilogue adds the per-column partial statistics of the tile's valid rows to the unit's statistics rows (fd_stat_add);
+//   * tr.fin.rows != null: the PRODUCER's BatchNorm is finalised here -- the four follower waves (kh = 1: idle while the leaders issue the prologue's
+//     LDS-DMA) derive the [2][K] table from the producer's statistics rows; workgroup 0 is the writer.
 // Replaces fd_pw_gemm_train_f32 (the 32x32x2 structure) on the units one round of workgroups covers -- the 14x14 / 7x7 maps at batch 32.
 #ifndef FD_G16_TRAIN_AHEAD
 #define FD_G16_TRAIN_AHEAD 2       // (0 / 2 / 4 measured equal: 42.4 / 42.2 / 42.5 us on the 512 x 512 units -- the cost of the transform is its instruction count, not its latency)
 #endif
 struct fd_g16_train {
-    const float *st;           // the producer's table [4][K] (scale, shift, mean, invstd)
-    float *part;               // partial statistics rows of THIS unit
+    const float *st;           // the producer's table [4][K] (scale, shift, mean, invstd) when it was finalised by a launch of its own
+    fd_stat_rows sr;           // statistics rows of THIS unit
+    fd_bn_fin fin;             // rows != null: the producer's finalisation runs in this kernel
 };
 
 // ABL (measurement aid, 0 in the product): 1 = no LDS-DMA in the steady state (stages keep the first tiles), 2 = also no fragment reads,
@@ -144,7 +148,7 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
     // than every DMA piece, so the prologue's counted vmcnt wait covers them)
     constexpr int TABQ = 2;                                  // K32 <= 1024 (checked by the plan)
     float tsc[TABQ], tsh[TABQ];
-    if (TRAIN != 0) {
+    if (TRAIN != 0 && !tr.fin.rows) {
 #pragma unroll
         for (int j = 0; j < TABQ; ++j) {
             const int k = tid + 512 * j, kc = k < K ? k : 0;
@@ -199,8 +203,12 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
         if (T >= STAGES) fd_wait_vmcnt<(STAGES - 1) * RG>(); else fd_wait_vmcnt<0>();
     }
     if (TRAIN != 0) {
+        if (tr.fin.rows) {
+            if (!leader) fd_stat_table_all<256>(tr.fin, K, K32, tid - 256, blockIdx.x == 0, [&](int k, float a, float b) { tab[k] = a; tab[K32 + k] = b; });
+        } else {
 #pragma unroll
-        for (int j = 0; j < TABQ; ++j) { const int k = tid + 512 * j; if (k < K32) { tab[k] = tsc[j]; tab[K32 + k] = tsh[j]; } }
+            for (int j = 0; j < TABQ; ++j) { const int k = tid + 512 * j; if (k < K32) { tab[k] = tsc[j]; tab[K32 + k] = tsh[j]; } }
+        }
         fd_block_barrier_lds();
     } else {
         fd_block_barrier();
@@ -302,8 +310,8 @@ fd_pw_gemm16_f32(const float *__restrict__ A, const float *__restrict__ Wt, cons
             float a = 0.0f, b = 0.0f;
 #pragma unroll
             for (int gg = 0; gg < 8; ++gg) { a += red[(gg * 2 + 0) * 64 + tid]; b += red[(gg * 2 + 1) * 64 + tid]; }
-            tr.part[(long)mt * 2 * N + n0 + tid] = a;
-            tr.part[(long)mt * 2 * N + N + n0 + tid] = b;
+            fd_stat_add<FD_STAT_FWD>(tr.sr, mt, N, 0, n0 + tid, a);
+            fd_stat_add<FD_STAT_FWD>(tr.sr, mt, N, 1, n0 + tid, b);
         }
     }
     if (FDW != 0) {

@@ -5,16 +5,19 @@
 // imagenet/mobilenet.py:25,32,36 and models.py:66,73, module in .train()): the statistics of a unit's conv
 // output are only known after the whole conv has run, so BN cannot be folded into the weights.  The design:
 //   * every unit stores its RAW conv output z (this is also exactly what backward needs: the activation mask
-//     and x_hat are functions of z), and its epilogue accumulates per-channel sum(z), sum(z^2) partials;
-//   * a tiny finalize kernel turns the partials into (scale s = gamma*invstd, shift t = beta - mean*s, mean,
-//     invstd) and updates running_mean / running_var (momentum 0.1, UNBIASED variance);
+//     and x_hat are functions of z), and its epilogue ADDS its per-channel sum(z), sum(z^2) partials into the unit's
+//     statistics rows with 64-bit integer atomics (fd_stat_add, fd_device.h: exact, order-independent);
+//   * the CONSUMER's workgroups turn the rows into (scale s = gamma*invstd, shift t = beta - mean*s) for their own
+//     channels in their prologue (fd_stat_table_block); one designated workgroup also writes the table (+ mean, invstd) the
+//     backward pass reads and updates running_mean / running_var (momentum 0.1, UNBIASED variance)
+//     and num_batches_tracked.  fd_bn_finalize_rows_f32 does the same as a launch of its own where no consumer can;
 //   * the CONSUMER applies  a = act(z*s + t)  while it loads its input ("normalise on read"), so the
 //     normalised / activated tensor is never written to HBM.  Nearest-x2 upsampling and the additive skips stay
 //     fused into the consumer's read exactly as in the inference kernels (models.py:723-729).
-// Reductions are two-level and deterministic (per-workgroup partials in a fixed layout, summed in fixed order by the
-// "last arriver" of the finalisation kernel: fd_two_level_tail).
+// Reductions are deterministic: per-workgroup partials in fixed order, then exact integer accumulation across workgroups.
 #pragma once
 #include "fd_device.h"
+#include "fd_bn_stats.h"
 
 // measurement aid (tools/microbench/dwtrain.hip): shader-clock timestamps of a workgroup's phases; nothing in product builds
 #ifdef FD_DW_PROBE
@@ -38,11 +41,6 @@ __device__ int fd_dw_abl;                                 // ablation bits (micr
 #define FD_DW_WU3 6      // backward-weights of the 16-bit plans, 3x3 / 5x5 units (fp32 plans: 4)
 #define FD_DW_WU5 8
 #endif
-// per-channel table written by fd_bn_finalize_f32:  [0..C) scale, [C..2C) shift, [2C..3C) mean, [3C..4C) invstd
-#define FD_ST_SCALE 0
-#define FD_ST_SHIFT 1
-#define FD_ST_MEAN 2
-#define FD_ST_INVSTD 3
 
 // bytes of an LDS patch image of npx pixels at pitch pstr (LDS elements), at least 8 KiB (the region doubles as fp32 reduction scratch) and a
 // multiple of 16 bytes (the fp32 tap table follows it)
@@ -109,11 +107,11 @@ __device__ __forceinline__ float fd_round1(fd_half, float v) { return (float)(_F
 
 // Forward: z[p][co] = sum_t tap[p][t] * w[co][t] as 32x32x2 MFMAs (a wave = 64 pixels = two 32-row tiles, K = 27 taps padded to 28, raw torch
 // weights w[Cout][27]); the accumulators are rounded to T, transposed through a wave-private LDS tile for 16-byte NHWC stores, and their
-// per-channel sums over the valid pixels go to part[blk*2*Cout + {0: sum, Cout: sum of squares} + c], blk = image * gridDim.x + block.
+// per-channel sums over the valid pixels are added to the unit's statistics rows (fd_stat_add; blk = image * gridDim.x + block picks the row).
 // LDS: max(band, 4 x [64][36] output tiles) + [4][2][32] statistics.
 template <typename T>
 __global__ void __launch_bounds__(256)
-fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__restrict__ z, float *__restrict__ part, int H, int W, int Cout, int tile_floats)
+fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__restrict__ z, fd_stat_rows sr, int H, int W, int Cout, int tile_floats)
 {
     FD_DYN_SMEM(smem_raw);
     float *smem = reinterpret_cast<float *>(smem_raw);
@@ -189,8 +187,8 @@ fd_stem_train(const float *__restrict__ x, const float *__restrict__ w, T *__res
         if (tid < 64) {
             const int which = tid >> 5, c = tid & 31;
             if (n0 + c < Cout)
-                part[blk_row * 2 * Cout + which * Cout + n0 + c] =
-                    (red[(0 * 2 + which) * 32 + c] + red[(1 * 2 + which) * 32 + c]) + (red[(2 * 2 + which) * 32 + c] + red[(3 * 2 + which) * 32 + c]);
+                fd_stat_add<FD_STAT_FWD>(sr, blk_row, Cout, which, n0 + c,
+                                         (red[(0 * 2 + which) * 32 + c] + red[(1 * 2 + which) * 32 + c]) + (red[(2 * 2 + which) * 32 + c] + red[(3 * 2 + which) * 32 + c]));
         }
         __syncthreads();                                      // red and the output tiles are reused by the next channel chunk
     }
@@ -232,12 +230,13 @@ __device__ __forceinline__ bool fd_wg_sum_by_channel_group(V &a, V &b, float *re
 // 16-byte channel group of one output column) and walks down TH output rows keeping the 3 x 3 window of the ACTIVATED input
 // act1(z_in * s1 + t1) in registers -- per output row it loads and activates the 3*S new vectors; the horizontal neighbours are the words its
 // neighbour work-items load (L1 / L2 hits).  Raw weights w[C][9]; output raw z (rounded to T) + this workgroup's per-channel sums of the
-// rounded values: part[blk*2*C + {0, C} + c], blk = (image * gridDim.y + strip) * gridDim.x + column block.
+// rounded values, added to the unit's statistics rows (blk = (image * gridDim.y + strip) * gridDim.x + column block).  fin.rows != null: the
+// PRODUCER's BatchNorm is finalised here (C <= 256 channels: work-item c finalises channel c into LDS; workgroup (0, 0, 0) is the writer).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int S, int ACT1>
 __global__ void __launch_bounds__(256)
 fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w, T *__restrict__ zout,
-                  float *__restrict__ part, int H, int W, int Ho, int Wo, int C, int TH)
+                  fd_stat_rows sr, int H, int W, int Ho, int Wo, int C, int TH, fd_bn_fin fin)
 {
     __shared__ float red[4 * 64 * 8];
     const int CG = C >> 2;                                   // a power of two, 8 <= CG <= 64 (plan)
@@ -253,7 +252,13 @@ fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, cons
     fd_f32x4 wv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) { wv[t].x = w[(c4 * 4 + 0) * 9 + t]; wv[t].y = w[(c4 * 4 + 1) * 9 + t]; wv[t].z = w[(c4 * 4 + 2) * 9 + t]; wv[t].w = w[(c4 * 4 + 3) * 9 + t]; }
-    const fd_f32x4 sc = fd_ld4(st1 + FD_ST_SCALE * C + c4 * 4), sh = fd_ld4(st1 + FD_ST_SHIFT * C + c4 * 4);
+    fd_f32x4 sc, sh;
+    if (fin.rows) {                                          // (scale, shift) of all C <= 256 channels -> red[0 .. 2C) -> this work-item's four
+        fd_stat_table_all<256>(fin, C, C, tid, blk.x == 0 && blk.y == 0 && blk.z == 0, [&](int c, float a, float b) { red[c] = a; red[C + c] = b; });
+        __syncthreads();
+        sc = fd_ld4(red + c4 * 4); sh = fd_ld4(red + C + c4 * 4);
+        __syncthreads();                                     // red is the statistics scratch again
+    } else { sc = fd_ld4(st1 + FD_ST_SCALE * C + c4 * 4); sh = fd_ld4(st1 + FD_ST_SHIFT * C + c4 * 4); }
     const T *img = zin + (long)n * H * W * C + c4 * 4;
     const int x0 = xo * S - 1;                               // leftmost input column of the window
     const bool okl = x0 >= 0, okr = (x0 + 2) < W;            // the centre column x0 + 1 is always inside
@@ -287,75 +292,9 @@ fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, cons
     }
     if (fd_wg_sum_by_channel_group(ssum, ssq, red, CG, tid)) {
         const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
-        fd_st4(part + row * 2 * C + tid * 4, ssum);
-        fd_st4(part + row * 2 * C + C + tid * 4, ssq);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// BatchNorm finalisation of the PRODUCER inside its depthwise consumer (<= FD_FIN_MAX_ROWS partial rows: the 14 x 14 / 7 x 7 pointwise units).
-// Every workgroup of the consumer sums the producer's partial rows for the CB channels of its block (256 / CB row groups, all rows
-// of a group in flight, double, fixed order: every workgroup computes the same bits) and derives (scale, shift) into LDS; the
-// workgroup the caller designates (tile 0 of image 0, one per channel block) also writes the table the backward pass reads,
-// the running statistics and num_batches_tracked.  Replaces a fd_bn_finalize_f32 launch (~5 us at the per-launch floor)
-// that sat between the two kernels; the extra work is one more global round trip in front of the patch loads.
-// sh: >= 4 KiB of LDS that is dead until the next barrier; s_st: [2][CB] floats that nothing else touches.
-// ------------------------------------------------------------------------------------------------
-#define FD_FIN_MAX_ROWS 128
-struct fd_bn_fin {
-    const float *part;               // null: the table st1 was finalised by its own launch
-    int nblk;
-    double n, n_unbiased;
-    float eps, momentum;
-    const float *gamma, *beta;
-    float *run_mean, *run_var, *st;
-    long long *nbt;
-};
-
-__device__ __forceinline__ void fd_bn_finalize_block(const fd_bn_fin &f, double *sh, float *s_st, int c0, int CB, int C, int tid, bool writer)
-{
-    const int ch = tid & (CB - 1), rg = tid / CB, RG = 256 / CB;
-    const int c = c0 + ch;
-    const bool ok = c < C;
-    float g_c = 0.0f, b_c = 0.0f, rm_c = 0.0f, rv_c = 0.0f;
-    if (rg == 0 && ok) { g_c = f.gamma[c]; b_c = f.beta[c]; if (writer) { rm_c = f.run_mean[c]; rv_c = f.run_var[c]; } }
-    double s = 0.0, q = 0.0;
-    if (ok) {
-        for (int b = rg; b < f.nblk; b += RG * 8) {
-            float vs[8], vq[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = b + RG * u < f.nblk ? b + RG * u : f.nblk - 1;
-                vs[u] = f.part[(long)row * 2 * C + c]; vq[u] = f.part[(long)row * 2 * C + C + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (b + RG * u < f.nblk) { s += (double)vs[u]; q += (double)vq[u]; }
-        }
+        for (int j = 0; j < 4; ++j) { fd_stat_add<FD_STAT_FWD>(sr, row, C, 0, tid * 4 + j, ssum[j]); fd_stat_add<FD_STAT_FWD>(sr, row, C, 1, tid * 4 + j, ssq[j]); }
     }
-    sh[2 * tid] = s; sh[2 * tid + 1] = q;
-    __syncthreads();
-    if (rg == 0) {
-        s = 0.0; q = 0.0;
-        for (int r = 0; r < RG; ++r) { s += sh[2 * (r * CB + ch)]; q += sh[2 * (r * CB + ch) + 1]; }
-        const double mean = s / f.n;
-        double var = q / f.n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double invstd = 1.0 / sqrt(var + (double)f.eps);
-        const double sc = (double)g_c * invstd;
-        const float scf = ok ? (float)sc : 0.0f, shf = ok ? (float)((double)b_c - mean * sc) : 0.0f;
-        s_st[ch] = scf; s_st[CB + ch] = shf;
-        if (writer && ok) {
-            f.st[FD_ST_SCALE * C + c] = scf;
-            f.st[FD_ST_SHIFT * C + c] = shf;
-            f.st[FD_ST_MEAN * C + c] = (float)mean;
-            f.st[FD_ST_INVSTD * C + c] = (float)invstd;
-            f.run_mean[c] = (float)((1.0 - f.momentum) * rm_c + f.momentum * mean);
-            f.run_var[c] = (float)((1.0 - f.momentum) * rv_c + f.momentum * var * (f.n_unbiased / (f.n_unbiased - 1.0)));
-            if (c == 0 && f.nbt) f.nbt[0] += 1;
-        }
-    }
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -363,14 +302,14 @@ __device__ __forceinline__ void fd_bn_finalize_block(const fd_bn_fin &f, double 
 //   input  = act1(z_in * s1 + t1)                                   (MODE 0)
 //          = up2(act1(z_in * s1 + t1))                              (MODE 1)
 //          = up2(act1(z_in * s1 + t1)) + act2(z_skip * s2 + t2)     (MODE 2)
-// weights are the live parameter w[C][K*K]; output is the raw conv result + stats partials
-// part[blk*2*C + {0,C} + c] with blk = image * gridDim.x + tile (logical indices: fd_xcd_image_map).
+// weights are the live parameter w[C][K*K]; output is the raw conv result; the workgroup's per-channel partial sums are added to the unit's
+// statistics rows (blk = image * gridDim.x + tile, logical indices: fd_xcd_image_map).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int N>
 __global__ void __launch_bounds__(256)
 fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip,
                     const float *__restrict__ st2, const float *__restrict__ w, T *__restrict__ zout,
-                    float *__restrict__ part, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr,
+                    fd_stat_rows sr, int Hin, int Win, int Ho, int Wo, int C, int cbq, int TH, int TW, int tiles_x, int csplit, int pstr,
                     fd_bn_fin fin)
 {
     constexpr int P = K / 2;
@@ -411,7 +350,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     const int npx_in = TH_in * TW_in;
     // producer finalised here (MODE 0..2: its table is per channel of this tensor): the (scale, shift) of this block's channels land at the END of the dynamic LDS
     // (requested AFTER the first batch of patch loads, below: the partial rows' round trip runs under the patch's)
-    const bool fin_here = MODE != 3 && fin.part != nullptr;
+    const bool fin_here = MODE != 3 && fin.rows != nullptr;
     if (c_ok) {
         if (from_skip) { s1 = LN::ldf(st2 + FD_ST_SCALE * C2 + cl); t1 = LN::ldf(st2 + FD_ST_SHIFT * C2 + cl); }
         else if (!fin_here) { s1 = LN::ldf(st1 + FD_ST_SCALE * C1 + cl); t1 = LN::ldf(st1 + FD_ST_SHIFT * C1 + cl); }
@@ -445,7 +384,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
         }
         if (fin_here && base == pt) {
             float *s_st = s_w + K * K * CB;
-            fd_bn_finalize_block(fin, reinterpret_cast<double *>(smem_raw), s_st, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
+            fd_stat_table_block(fin, reinterpret_cast<double *>(smem_raw), s_st, c0, CB, C, tid, bm.x == 0 && bm.z == 0);
             if (c_ok) { s1 = LN::ldf(s_st + c4 * N); t1 = LN::ldf(s_st + CB + c4 * N); }
         }
 #pragma unroll
@@ -503,8 +442,8 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     if (fd_wg_sum_by_channel_group(ssum, ssq, reinterpret_cast<float *>(smem_raw), lanes_c, tid)) {
         const long blk = (long)bm.z * gridDim.x + bm.x;
         if (c0 + tid * N < C) {
-            LN::stf(part + blk * 2 * C + c0 + tid * N, ssum);
-            LN::stf(part + blk * 2 * C + C + c0 + tid * N, ssq);
+#pragma unroll
+            for (int j = 0; j < N; ++j) { fd_stat_add<FD_STAT_FWD>(sr, blk, C, 0, c0 + tid * N + j, ssum[j]); fd_stat_add<FD_STAT_FWD>(sr, blk, C, 1, c0 + tid * N + j, ssq[j]); }
         }
     }
     FD_DW_PROBE_AT(4);
@@ -516,12 +455,13 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
 // Same LDS-DMA / swizzle / 3-stage-ring structure as fd_pw_gemm_f32; the BatchNorm + activation of the PRODUCER
 // is applied to the A fragments after the ds_read (a table of scale/shift per k sits in LDS).  The table is zero
 // for k >= K, which also neutralises a ragged last K tile (the W source chunk is clamped to finite data).
-// Epilogue: raw z + per-column partial statistics part[mt*2*N + {0,N} + col].
+// Epilogue: raw z + per-column partial statistics, added to the unit's statistics rows (row chosen by mt).  fin.rows != null: the producer's
+// BatchNorm is finalised here -- every workgroup derives the whole [2][K] table after its first LDS-DMA stages are issued; workgroup 0 is the writer.
 // ------------------------------------------------------------------------------------------------
 template <int ACT1>
 __global__ void __launch_bounds__(256)
 fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1, const float *__restrict__ Wt,
-                     float *__restrict__ out, float *__restrict__ part, int M, int N, int K, int m_tiles, int n_tiles)
+                     float *__restrict__ out, fd_stat_rows sr, int M, int N, int K, int m_tiles, int n_tiles, fd_bn_fin fin)
 {
     constexpr int BM = 64, BN = 64, BK = 32, ROWS = BM + BN, STAGE = ROWS * BK, RG = ROWS / 8 / 4;
     FD_DYN_SMEM(smem_raw);
@@ -541,12 +481,14 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
     // at the head of every workgroup
     constexpr int TABQ = 4;                                  // K <= 1024 (checked by the plan)
     float tsv[TABQ], ttv[TABQ];
+    if (!fin.rows) {
 #pragma unroll
-    for (int i = 0; i < TABQ; ++i) {
-        const int k = tid + 256 * i;
-        const int kc = k < K ? k : 0;
-        const float a = st1[FD_ST_SCALE * K + kc], b = st1[FD_ST_SHIFT * K + kc];
-        tsv[i] = k < K ? a : 0.0f; ttv[i] = k < K ? b : 0.0f;
+        for (int i = 0; i < TABQ; ++i) {
+            const int k = tid + 256 * i;
+            const int kc = k < K ? k : 0;
+            const float a = st1[FD_ST_SCALE * K + kc], b = st1[FD_ST_SHIFT * K + kc];
+            tsv[i] = k < K ? a : 0.0f; ttv[i] = k < K ? b : 0.0f;
+        }
     }
     const float *src[RG];
     int src_chunk[RG];
@@ -582,10 +524,13 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
     const int T = K32 / BK;
     issue(0);
     if (T > 1) issue(1);
+    if (fin.rows) fd_stat_table_all<256>(fin, K, K32, tid, blockIdx.x == 0, [&](int k, float a, float b) { tab[k] = a; tab[K32 + k] = b; });
+    else {
 #pragma unroll
-    for (int i = 0; i < TABQ; ++i) {
-        const int k = tid + 256 * i;
-        if (k < K32) { tab[k] = tsv[i]; tab[K32 + k] = ttv[i]; }
+        for (int i = 0; i < TABQ; ++i) {
+            const int k = tid + 256 * i;
+            if (k < K32) { tab[k] = tsv[i]; tab[K32 + k] = ttv[i]; }
+        }
     }
     fd_block_barrier_lds();                                  // scale/shift table visible
     for (int t = 0; t < T; ++t) {
@@ -616,28 +561,37 @@ fd_pw_gemm_train_f32(const float *__restrict__ A, const float *__restrict__ st1,
     if (lane < 32) { red[(wm * 2 + 0) * 64 + wn * 32 + lane] = s; red[(wm * 2 + 1) * 64 + wn * 32 + lane] = q; }
     __syncthreads();
     if (tid < 64 && n0 + tid < N) {
-        part[(long)mt * 2 * N + n0 + tid] = red[0 * 64 + tid] + red[2 * 64 + tid];
-        part[(long)mt * 2 * N + N + n0 + tid] = red[1 * 64 + tid] + red[3 * 64 + tid];
+        fd_stat_add<FD_STAT_FWD>(sr, mt, N, 0, n0 + tid, red[0 * 64 + tid] + red[2 * 64 + tid]);
+        fd_stat_add<FD_STAT_FWD>(sr, mt, N, 1, n0 + tid, red[1 * 64 + tid] + red[3 * 64 + tid]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Head, train mode: z_low[p] = sum_k act1(zin[p][k]*s1[k]+t1[k]) * w[k]  at the low resolution (the nearest-x2
 // upsampling commutes with the 1x1 conv; BN statistics over the replicated tensor equal the low-res ones, the
-// unbiased correction uses the full-resolution count -- SURVEY.md Appendix F).  part[blk*2 + {0,1}].
+// unbiased correction uses the full-resolution count -- SURVEY.md Appendix F).  The workgroup's (sum, sum of squares) go to the head's 1-channel
+// statistics rows.  fin.rows != null: the producer's BatchNorm (Cin <= FD_HEAD_FIN_MAX channels) is finalised here, workgroup 0 is the writer.
 // ------------------------------------------------------------------------------------------------
+#define FD_HEAD_FIN_MAX 256
 template <typename T, int ACT1>
 __global__ void __launch_bounds__(256)
 fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w,
-                  float *__restrict__ zlow, float *__restrict__ part, long npix, int Cin)
+                  float *__restrict__ zlow, fd_stat_rows sr, long npix, int Cin, fd_bn_fin fin)
 {
     __shared__ float red[8];
+    __shared__ __attribute__((aligned(16))) float s_tab[2 * FD_HEAD_FIN_MAX];
+    const float *tsc = st1 + FD_ST_SCALE * Cin, *tsh = st1 + FD_ST_SHIFT * Cin;
+    if (fin.rows) {
+        fd_stat_table_all<256>(fin, Cin, Cin, threadIdx.x, blockIdx.x == 0, [&](int c, float a, float b) { s_tab[c] = a; s_tab[FD_HEAD_FIN_MAX + c] = b; });
+        __syncthreads();
+        tsc = s_tab; tsh = s_tab + FD_HEAD_FIN_MAX;
+    }
     const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
     const int l8 = threadIdx.x & 7;
     float s = 0.0f;
     if (g < npix) {
         for (int c = l8 * 4; c < Cin; c += 32) {
-            const fd_f32x4 a = fd_bn_act4<ACT1>(fd_ld4(zin + g * Cin + c), fd_ld4(st1 + FD_ST_SCALE * Cin + c), fd_ld4(st1 + FD_ST_SHIFT * Cin + c));
+            const fd_f32x4 a = fd_bn_act4<ACT1>(fd_ld4(zin + g * Cin + c), fd_ld4(tsc + c), fd_ld4(tsh + c));
             const fd_f32x4 q = fd_ld4(w + c);
             s = fmaf(a.x, q.x, s); s = fmaf(a.y, q.y, s); s = fmaf(a.z, q.z, s); s = fmaf(a.w, q.w, s);
         }
@@ -651,142 +605,28 @@ fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const fl
     if ((threadIdx.x & 63) == 0) { red[wave * 2] = v; red[wave * 2 + 1] = sq; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[(long)blockIdx.x * 2] = red[0] + red[2] + red[4] + red[6];
-        part[(long)blockIdx.x * 2 + 1] = red[1] + red[3] + red[5] + red[7];
+        fd_stat_add<FD_STAT_FWD>(sr, blockIdx.x, 1, 0, 0, red[0] + red[2] + red[4] + red[6]);
+        fd_stat_add<FD_STAT_FWD>(sr, blockIdx.x, 1, 1, 0, red[1] + red[3] + red[5] + red[7]);
     }
 }
 
-// Sum of the partial rows r0 + wave, r0 + wave + 16, ... (< r1) of columns c (first sum) and C + c (second sum) of a [rows][2C] buffer, in
-// row order, in double: eight rows' loads are in flight at a time (a single-level finalisation of up to 256 rows is two such batches per wave).
-__device__ __forceinline__ void fd_sum_partial_rows(const float *__restrict__ part, int r0, int r1, int wave, int C, int c, bool ok, double &s, double &q)
-{
-    s = 0.0; q = 0.0;
-    if (!ok || r1 <= r0) return;
-    // EVERY batch -- the last, partial one included -- is issued as eight row loads in flight (row index clamped, the add masked): round 3 walked the
-    // remainder (all of a <= 112-row reduction: the 14 x 14 and 7 x 7 units, i.e. most of the 76 finalisations of a step) one dependent load pair at a
-    // time, 6 - 7 serial round trips of ~0.5 us inside a launch that sits between every producer and its consumer.  Same ascending row order as before.
-    for (int b = r0 + wave; b < r1; b += 16 * 8) {
-        float vs[8], vq[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int row = b + 16 * u < r1 ? b + 16 * u : r1 - 1;
-            vs[u] = part[(long)row * 2 * C + c]; vq[u] = part[(long)row * 2 * C + C + c];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (b + 16 * u < r1) { s += (double)vs[u]; q += (double)vq[u]; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two-level deterministic reduction in ONE launch ("last arriver").  The rows of a partial buffer (up to 6272 workgroups of
-// the producer) are cut into gridDim.y slices of `rps` rows; workgroup (x, y) sums slice y for the 64 columns of block x (16
-// waves split the rows, fixed order) and, when there is more than one slice, publishes its sums with device-scope stores and
-// bumps counter[x]; the workgroup that finds the counter complete adds the slice sums IN SLICE ORDER (independent of who
-// arrives last) and runs the finalisation for its 64 columns.  No workgroup waits; the counters return to 0.
-// fd_tail_begin returns true in the workgroup that owns the final result of column block x; s/q then hold the full sums for
-// wave 0's lanes.  (A separate slice-sum launch per reduction cost ~5 us x 71 launches per train step.)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool fd_two_level_tail(double &s, double &q, bool has_q, bool col_ok, int col, int width2,
-                                                  double *__restrict__ slices, int *__restrict__ counters, int *s_last,
-                                                  double (*sh)[64][2], int bx, int by, int ny)
-{
-    // called by all 1024 work-items after wave 0 holds the slice sums (s, q) of its lanes' columns; (bx, by) of ny slices: normally
-    // blockIdx / gridDim.y, explicit so that one launch can run two reductions side by side (fd_bwd_reduce_pair_f32)
-    if (ny == 1) return true;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave == 0 && col_ok) {
-        fd_store_dev(slices + (long)by * width2 + col, s);
-        if (has_q) fd_store_dev(slices + (long)by * width2 + (width2 >> 1) + col, q);
-    }
-    fd_release_wg();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int old = fd_atomic_inc(counters + bx);
-        *s_last = old == ny - 1;
-        if (*s_last) fd_store_dev(counters + bx, 0);
-    }
-    __syncthreads();
-    if (!*s_last) return false;
-    fd_acquire_wg();
-    // the slice sums are added in a fixed order: wave w takes slices w, w+16, ... (all its loads in flight at once), then the 16
-    // per-wave sums are added in wave order
-    constexpr int MAXK = 8;                                  // ny <= 128 (fd_train_impl.h red_geom)
-    double vs[MAXK], vq[MAXK];
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-        const int y = wave + 16 * k;
-        const bool ok = col_ok && y < ny;
-        vs[k] = ok ? fd_load_dev(slices + (long)y * width2 + col) : 0.0;
-        vq[k] = (ok && has_q) ? fd_load_dev(slices + (long)y * width2 + (width2 >> 1) + col) : 0.0;
-    }
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) { a += vs[k]; b += vq[k]; }
-    sh[wave][lane][0] = a; sh[wave][lane][1] = b;
-    __syncthreads();
-    if (wave == 0) {
-        s = 0.0; q = 0.0;
-        for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------------
-// BatchNorm finalize: partial sums -> per-channel (scale, shift, mean, invstd) + running-statistics update.
-//   mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), running_var uses var_b * n_u/(n_u-1).
-// Grid (ceil(C/64), slices): lane = channel, wave w sums partial rows w, w+16, ... of its slice in double, fixed order.
-// ------------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(1024)
-fd_bn_finalize_f32(const float *__restrict__ part, int nblk, int rps, int C, double n, double n_unbiased, float eps, float momentum,
-                   const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ run_mean,
-                   float *__restrict__ run_var, float *__restrict__ st, double *__restrict__ slices, int *__restrict__ counters,
-                   long long *__restrict__ nbt)
-{
-    __shared__ double sh[16][64][2];
-    __shared__ int s_last;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    const int r0 = blockIdx.y * rps;
-    int r1 = r0 + rps; if (r1 > nblk) r1 = nblk;
-    // the affine parameters and running statistics do not depend on the reduction: requested first, so that their latency runs under the row sums
-    // (this launch sits between every producer and its consumer: its dependent round trips are the train step's most repeated cost)
-    float g_c = 0.0f, b_c = 0.0f, rm_c = 0.0f, rv_c = 0.0f;
-    if (wave == 0 && c < C) { g_c = gamma[c]; b_c = beta[c]; rm_c = run_mean[c]; rv_c = run_var[c]; }
-    double s, q;
-    fd_sum_partial_rows(part, r0, r1, wave, C, c, c < C, s, q);
-    sh[wave][lane][0] = s; sh[wave][lane][1] = q;
-    __syncthreads();
-    if (wave == 0) {
-        s = 0.0; q = 0.0;
-        for (int w = 0; w < 16; ++w) { s += sh[w][lane][0]; q += sh[w][lane][1]; }
-    }
-    __syncthreads();
-    if (!fd_two_level_tail(s, q, true, c < C, c, 2 * C, slices, counters, &s_last, sh, blockIdx.x, blockIdx.y, gridDim.y)) return;
-    if (wave == 0 && c < C) {
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const double invstd = 1.0 / sqrt(var + (double)eps);
-        const double sc = (double)g_c * invstd;
-        st[FD_ST_SCALE * C + c] = (float)sc;
-        st[FD_ST_SHIFT * C + c] = (float)((double)b_c - mean * sc);
-        st[FD_ST_MEAN * C + c] = (float)mean;
-        st[FD_ST_INVSTD * C + c] = (float)invstd;
-        run_mean[c] = (float)((1.0 - momentum) * rm_c + momentum * mean);
-        run_var[c] = (float)((1.0 - momentum) * rv_c + momentum * var * (n_unbiased / (n_unbiased - 1.0)));
-        if (c == 0 && nbt) nbt[0] += 1;                       // nn.BatchNorm2d.num_batches_tracked (one finalising workgroup owns channel 0)
-    }
-}
-
-// prediction of the train-mode forward: pred = act(z_low*s + t), written as 2x2 blocks (up == 1) or 1:1
+// prediction of the train-mode forward: pred = act(z_low*s + t), written as 2x2 blocks (up == 1) or 1:1.  fin.rows != null: the head's own
+// 1-channel BatchNorm is finalised here (work-item 0 of every workgroup derives (s, t); workgroup 0 is the writer)
 template <int ACT>
 __global__ void __launch_bounds__(256)
-fd_head_apply_f32(const float *__restrict__ zlow, const float *__restrict__ st, float *__restrict__ y, long npix, int h, int w, int up)
+fd_head_apply_f32(const float *__restrict__ zlow, const float *__restrict__ st, float *__restrict__ y, long npix, int h, int w, int up, fd_bn_fin fin)
 {
+    __shared__ float s_st[2];
     const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    const float zq = zlow[g < npix ? g : npix - 1];
+    float sc, sf;
+    if (fin.rows) {
+        fd_stat_table_all<256>(fin, 1, 1, threadIdx.x, blockIdx.x == 0, [&](int, float a, float b) { s_st[0] = a; s_st[1] = b; });
+        __syncthreads();
+        sc = s_st[0]; sf = s_st[1];
+    } else { sc = st[FD_ST_SCALE]; sf = st[FD_ST_SHIFT]; }
     if (g >= npix) return;
-    const float v = fd_act<ACT>(zlow[g] * st[FD_ST_SCALE] + st[FD_ST_SHIFT]);
+    const float v = fd_act<ACT>(zq * sc + sf);
     if (!up) { y[g] = v; return; }
     const int ox = (int)(g % w);
     const long t = g / w;

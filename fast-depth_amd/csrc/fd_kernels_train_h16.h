@@ -53,12 +53,13 @@ fd_pack_train_w_h16(const fd_pack_table<T> table)
 // Forward.  Skeleton of fd_pw_gemm_h16 (LDS-DMA 3-stage ring, swizzled 128-byte rows, XCD-aware 1-D grid); the scale/shift
 // table of the producer sits in LDS as [2][K64] floats, zero beyond K (so a ragged last K tile contributes act(0) * 0).
 // Epilogue: z rounded to T, transposed through LDS for 16-byte NHWC stores, per-column statistics of the ROUNDED values
-// -> part[mt*2*N + {0,N} + col].
+// added to the unit's statistics rows.  fin.rows != null: the producer's BatchNorm is finalised here (fd_stat_table_all after the first LDS-DMA
+// stages have been issued; workgroup 0 is the writer).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ACT1, int TN = 1>   // TN = column tiles of 32 per wave: the workgroup's tile is 64 x (64*TN).  TN = 2 (N >= 128): every
 __global__ void __launch_bounds__(256)        // normalised A fragment feeds two MFMAs (the fp32 table math per fragment is this kernel's VALU load)
 fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, const T *__restrict__ Wt, T *__restrict__ out,
-                     float *__restrict__ part, int M, int N, int K, int K64, int m_tiles, int n_tiles)
+                     fd_stat_rows sr, int M, int N, int K, int K64, int m_tiles, int n_tiles, fd_bn_fin fin)
 {
     constexpr int BM = 64, BN = 64 * TN, BK = 64;
     constexpr int ROWS = BM + BN, STAGE = ROWS * 128, RG = ROWS / 8 / 4;
@@ -76,12 +77,14 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     // at the head of every workgroup (the units with K <= 128 run a single K tile: their workgroups are all head and tail)
     constexpr int TABQ = 4;                                       // K64 <= 1024 (checked by the plan)
     float tsv[TABQ], ttv[TABQ];
+    if (!fin.rows) {
 #pragma unroll
-    for (int i = 0; i < TABQ; ++i) {
-        const int k = tid + 256 * i;
-        const int kc = k < K ? k : 0;
-        const float a = st1[FD_ST_SCALE * K + kc], b = st1[FD_ST_SHIFT * K + kc];
-        tsv[i] = k < K ? a : 0.0f; ttv[i] = k < K ? b : 0.0f;
+        for (int i = 0; i < TABQ; ++i) {
+            const int k = tid + 256 * i;
+            const int kc = k < K ? k : 0;
+            const float a = st1[FD_ST_SCALE * K + kc], b = st1[FD_ST_SHIFT * K + kc];
+            tsv[i] = k < K ? a : 0.0f; ttv[i] = k < K ? b : 0.0f;
+        }
     }
     const T *src[RG];
     int src_k[RG];
@@ -124,10 +127,13 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     const int Tn = K64 / BK;
     issue(0);
     if (FD_H16_STAGES > 2 && Tn > 1) issue(1);
+    if (fin.rows) fd_stat_table_all<256>(fin, K, K64, tid, blockIdx.x == 0, [&](int k, float a, float b) { tab[k] = a; tab[K64 + k] = b; });
+    else {
 #pragma unroll
-    for (int i = 0; i < TABQ; ++i) {
-        const int k = tid + 256 * i;
-        if (k < K64) { tab[k] = tsv[i]; tab[K64 + k] = ttv[i]; }
+        for (int i = 0; i < TABQ; ++i) {
+            const int k = tid + 256 * i;
+            if (k < K64) { tab[k] = tsv[i]; tab[K64 + k] = ttv[i]; }
+        }
     }
     fd_block_barrier_lds();                                       // table visible
     for (int t = 0; t < Tn; ++t) {
@@ -182,8 +188,8 @@ fd_pw_gemm_train_h16(const T *__restrict__ A, const float *__restrict__ st1, con
     }
     __syncthreads();
     if (tid < BN && n0 + tid < N) {
-        part[(long)mt * 2 * N + n0 + tid] = red[0 * BN + tid] + red[2 * BN + tid];
-        part[(long)mt * 2 * N + N + n0 + tid] = red[1 * BN + tid] + red[3 * BN + tid];
+        fd_stat_add<FD_STAT_FWD>(sr, mt, N, 0, n0 + tid, red[0 * BN + tid] + red[2 * BN + tid]);
+        fd_stat_add<FD_STAT_FWD>(sr, mt, N, 1, n0 + tid, red[1 * BN + tid] + red[3 * BN + tid]);
     }
 }
 
@@ -208,8 +214,7 @@ fd_bn_bwd_apply_h16(const T *G, T *DZ, const T *__restrict__ Z, const float *__r
     }
 }
 
-// The same map for the units whose BatchNorm-backward partial rows are few (<= FD_FIN_MAX_ROWS: the 14 x 14 / 7 x 7 maps at batch 32), with the
-// finalisation inside (fd_bn_bwd_finalize_block): workgroup (x, y) owns channels [64x, 64x + 64) of the rows 32y + r, 32(y + gridDim.y) + r, ...
+// The same map with the unit's BatchNorm-backward finalisation inside (fd_bstat_table_block over the unit's statistics rows): workgroup (x, y) owns channels [64x, 64x + 64) of the rows 32y + r, 32(y + gridDim.y) + r, ...
 // (a row's 64 channels = 128 bytes = one line: 8 work-items), sums the partial rows of its channels while its first row's loads are in flight, and
 // row y == 0 also writes dgamma / dbeta and the coefficient table.  One launch per unit instead of fd_bn_bwd_finalize_f32 + fd_bn_bwd_apply_h16.
 template <typename T>
@@ -225,7 +230,7 @@ fd_bn_bwd_apply_fin_h16(const T *G, T *DZ, const T *__restrict__ Z, int M, int N
     const long rq = r < M ? r : M - 1;
     const long cq = c_ok ? c0 + cl : 0;
     fd_u16x8 gq = fd_ld8(G + rq * N + cq), zq = fd_ld8(Z + rq * N + cq);
-    fd_bn_bwd_finalize_block(fin, sh, s_cf, c0, 64, N, tid, blockIdx.y == 0);
+    fd_bstat_table_block(fin, sh, s_cf, c0, 64, N, tid, blockIdx.y == 0);
     float cA[8], c1[8], cM[8], c2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { cA[j] = s_cf[FD_CF_A * 64 + cl + j]; c1[j] = s_cf[FD_CF_C1 * 64 + cl + j]; cM[j] = s_cf[FD_CF_MU * 64 + cl + j]; c2[j] = s_cf[FD_CF_C2 * 64 + cl + j]; }
@@ -253,7 +258,7 @@ fd_bn_bwd_apply_fin_h16(const T *G, T *DZ, const T *__restrict__ Z, int M, int N
 template <typename T, int ACT_IN, int ADD_SG, int TN>   // TN: 32-column tiles per wave (workgroup tile 64 x 64*TN of G_in): every dz fragment feeds TN MFMAs
 __device__ __forceinline__ void                       // blk: linear workgroup number (blockIdx.x of the plain kernel; the paired launch fd_pw_bwd_h16 passes its own)
 fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
-                const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles,
+                const T *__restrict__ SG, T *__restrict__ Gin, fd_stat_rows sr, int M, int N, int K, int N64, int m_tiles, int k_tiles,
                 const unsigned blk)
 {
     constexpr int BM = 64, BKO = 64 * TN, BR = 64;
@@ -404,17 +409,17 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
     }
     __syncthreads();
     if (tid < BKO && k0 + tid < K) {
-        part[(long)mt * 2 * K + k0 + tid] = red[0 * BKO + tid] + red[2 * BKO + tid];
-        part[(long)mt * 2 * K + K + k0 + tid] = red[1 * BKO + tid] + red[3 * BKO + tid];
+        fd_stat_add<FD_STAT_BWD>(sr, mt, K, 0, k0 + tid, red[0 * BKO + tid] + red[2 * BKO + tid]);
+        fd_stat_add<FD_STAT_BWD>(sr, mt, K, 1, k0 + tid, red[1 * BKO + tid] + red[3 * BKO + tid]);
     }
 }
 
 template <typename T, int ACT_IN, int ADD_SG, int TN = 1>
 __global__ void __launch_bounds__(256)
 fd_pw_dgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
-                const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, int M, int N, int K, int N64, int m_tiles, int k_tiles)
+                const T *__restrict__ SG, T *__restrict__ Gin, fd_stat_rows sr, int M, int N, int K, int N64, int m_tiles, int k_tiles)
 {
-    fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, part, M, N, K, N64, m_tiles, k_tiles, blockIdx.x);
+    fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, sr, M, N, K, N64, m_tiles, k_tiles, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -563,11 +568,11 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
 template <typename T, int ACT_IN, int ADD_SG, int TN>
 __global__ void __launch_bounds__(256)
 fd_pw_bwd_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
-              const T *__restrict__ SG, T *__restrict__ Gin, float *__restrict__ part, float *__restrict__ wpart,
+              const T *__restrict__ SG, T *__restrict__ Gin, fd_stat_rows sr, float *__restrict__ wpart,
               int M, int N, int K, int N64, int m_tiles, int k_tiles_d, int n_dgrad, int k_tiles_w, int tiles_w, int rows_per_split)
 {
     if ((int)blockIdx.x < n_dgrad) {
-        fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, part, M, N, K, N64, m_tiles, k_tiles_d, blockIdx.x);
+        fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, sr, M, N, K, N64, m_tiles, k_tiles_d, blockIdx.x);
     } else {
         const int b = (int)blockIdx.x - n_dgrad;
         const int by = b / tiles_w;

@@ -51,32 +51,27 @@ inline int dw_dgrad_cols(const TLayer &L) { return L.d.ksize == 5 ? FD_T_DW5_DTW
 inline int dw_dz_patch(int t, int k, int s) { return (t + k - 2) / s + (s == 2 ? 2 : 1); }
 inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr, int le) { return lds_patch_bytes((long)ph * pw, pstr, le) + (size_t)k * k * cb * 4; }
 
-// Where the BatchNorm-backward partial rows (sum G, sum G*xhat) of unit u are written by its consumer's backward kernels.  A unit that finalises them
-// inside its own first backward kernel (TLayer::bwd_fin, fd_bn_bwd_finalize_block) reads them while that kernel writes its PRODUCER's rows, so such
-// units alternate between two extra buffers; everything else shares the one buffer, as before.
-inline float *bwd_part(fd_train_plan *p, int u) { return tws(p, (u >= 0 && p->layers[u].bwd_fin) ? p->partb_off[u & 1] : p->part_off); }
-
-int bn_bwd_finalize(BwdCtx &c, int i, int nblk)
-{
-    TLayer &L = c.p->layers[i];
-    const RedGeom rg = red_geom(nblk, L.d.cout);
-    FD_LAUNCH(fd_bn_bwd_finalize_f32, rg.grid, dim3(1024), 0, c.s, bwd_part(c.p, i), nblk, rg.rps, L.d.cout, L.n_stat,
-              tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off), red_slices(c.p), red_counters(c.p));
-    return check_launch("fd_bn_bwd_finalize_f32");
-}
-// unit u's partial rows are complete (its consumer's backward kernels have been launched): few rows and a capable first kernel -> that kernel finalises them
-// (TLayer::bwd_fin_rows, consumed when unit u is processed -- possibly by a later range call); otherwise the separate launch
-int finalize_or_defer(BwdCtx &c, int u, int nblk)
-{
-    TLayer &U = c.p->layers[u];
-    if (U.bwd_fin && nblk <= FD_FIN_MAX_ROWS) { U.bwd_fin_rows = nblk; return FD_OK; }
-    U.bwd_fin_rows = 0;
-    return bn_bwd_finalize(c, u, nblk);
-}
+// (bwd_rows(plan, u, nblk), fd_train_plan.h: the statistics rows of unit u as the backward-data kernel of its consumer -- nblk workgroups per channel -- sees them)
 inline fd_bn_bwd_fin bwd_fin_args(BwdCtx &c, int i, size_t cf_off)
 {
     TLayer &L = c.p->layers[i];
-    return fd_bn_bwd_fin{bwd_part(c.p, i), L.bwd_fin_rows, (int)cf_off, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off)};
+    return fd_bn_bwd_fin{stat_ptr(c.p, L.sb_off), L.nr_b, (int)cf_off, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off)};
+}
+int bn_bwd_finalize(BwdCtx &c, int i)
+{
+    TLayer &L = c.p->layers[i];
+    const fd_bn_bwd_fin fa = bwd_fin_args(c, i, 0);
+    FD_LAUNCH(fd_bn_bwd_finalize_rows_f32, dim3((unsigned)ceil_div(L.d.cout, 256)), dim3(256), 0, c.s, fa, L.d.cout);
+    return check_launch("fd_bn_bwd_finalize_rows_f32");
+}
+// unit u's statistics rows are complete (its consumer's backward kernels have been launched): a capable first kernel of u finalises them itself
+// (TLayer::bwd_fin_rows, consumed when unit u is processed -- possibly by a later range call); otherwise the separate launch
+int finalize_or_defer(BwdCtx &c, int u)
+{
+    TLayer &U = c.p->layers[u];
+    if (U.bwd_fin) { U.bwd_fin_rows = U.nr_b; return FD_OK; }
+    U.bwd_fin_rows = 0;
+    return bn_bwd_finalize(c, u);
 }
 
 template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG>
@@ -97,7 +92,7 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         FD_LAUNCH((fd_dw_dgrad<T, K, S, MODE, ACT_IN, ADD_SG, NL>), grid, dim3(256), lds, c.s, twt<T>(c.p, L.g_off), twt<T>(c.p, L.z_off), tws(c.p, L.coef_off),
                   c.params[i].conv_weight, twt<T>(c.p, P.z_off), tws(c.p, P.st_off), ADD_SG ? twt<T>(c.p, P.sg_off) : (const T *)nullptr,
-                  twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, bwd_part(c.p, L.d.src),
+                  twt<T>(c.p, P.g_off), Kp ? twt<T>(c.p, Kp->sg_off) : (T *)nullptr, bwd_rows(c.p, L.d.src, (long)tiles_x * tiles_y * c.p->B),
                   L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.cbq, TH, TW, tiles_x, L.csplit, L.bpstr);
     });
     *nblk_out = tiles_x * tiles_y * c.p->B;
@@ -189,7 +184,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     a.Zskip = Kp ? twt<T>(c.p, Kp->z_off) : nullptr; a.SG = ADD_SG ? twt<T>(c.p, P.sg_off) : nullptr;
     a.Gin = twt<T>(c.p, P.g_off); a.SGout = Kp ? twt<T>(c.p, Kp->sg_off) : nullptr;
     a.coef = tws(c.p, L.coef_off); a.w = c.params[i].conv_weight; a.st_in = tws(c.p, P.st_off); a.st_skip = Kp ? tws(c.p, Kp->st_off) : nullptr;
-    a.part = bwd_part(c.p, L.d.src); a.wpart = tws(c.p, L.wp_off);
+    a.wpart = tws(c.p, L.wp_off);
     a.Hin = L.in_h; a.Win = L.in_w; a.Ho = L.out_h; a.Wo = L.out_w; a.C = L.d.cin; a.cbq = L.cbq; a.csplit = L.csplit; a.pstr = L.bpstr; a.B = c.p->B;
     // backward-data geometry (launch_dw_dgrad)
     a.d_th = dw_dgrad_rows(c.p, L); a.d_tw = dw_dgrad_cols(L);
@@ -222,8 +217,8 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             int th2 = h2;
             while (th2 > 2 && (long)gxd * ceil_div(h2, th2) * c.p->B < 1024) th2 = (th2 + 1) / 2;
             const int gyd = ceil_div(h2, th2);
-            if ((size_t)gxd * gyd * c.p->B * 2 * L.d.cin * 4 > c.p->part_bytes) return fail(FD_ERR_STATE, "BatchNorm partial buffer too small for the stride-2 register-window backward kernel");
-            FD_LAUNCH((fd_dw3s2_dgrad_rows<T, ACT1, ADD_SG>), dim3(gxd, gyd, c.p->B), dim3(256), 0, c.s, a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.part,
+            a.sr = bwd_rows(c.p, L.d.src, (long)gxd * gyd * c.p->B);
+            FD_LAUNCH((fd_dw3s2_dgrad_rows<T, ACT1, ADD_SG>), dim3(gxd, gyd, c.p->B), dim3(256), 0, c.s, a.G, a.Z, a.coef, a.w, a.Zin, a.st_in, a.SG, a.Gin, a.sr,
                       L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, th2);
             int rcr = check_launch("fd_dw3s2_dgrad_rows");
             if (rcr) return rcr;
@@ -254,9 +249,10 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
         if (lds1 > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward: LDS request %zu exceeds 160 KiB", lds1);
         const int wblk1 = a.d_gx * c.p->B;
         if ((size_t)wblk1 * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+        a.sr = bwd_rows(c.p, L.d.src, wblk1);
         fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
             constexpr int NL = decltype(nt)::value;
-            if (a.fin.part) {                                 // (the instance with the in-kernel finalisation costs registers: only where it replaces a launch)
+            if (a.fin.rows) {                                 // (the instance with the in-kernel finalisation costs registers: only where it replaces a launch)
                 (void)hipFuncSetAttribute((const void *)fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
                 FD_LAUNCH((fd_dw_bwd1<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>), dim3((unsigned)a.d_gx, (unsigned)a.d_gy, (unsigned)c.p->B), dim3(256), lds1, c.s, a);
             } else {
@@ -272,10 +268,11 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     const int wblk = a.w_gx * c.p->B;
     if ((size_t)wblk * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
     if (L.bwd_fin_rows) a.fin = bwd_fin_args(c, i, lds - (size_t)4 * cb * 4);
+    a.sr = bwd_rows(c.p, L.d.src, (long)a.d_gx * c.p->B);
     const long total = (long)c.p->B * ((long)a.d_gx * a.d_gy + (long)a.w_gx * a.w_gy);
     fd_by_lane_width<T>(L.dw_n, [&](auto nt) {
         constexpr int NL = decltype(nt)::value;
-        if (a.fin.part) {
+        if (a.fin.rows) {
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_dw_bwd<T, K, S, MODE, ACT1, ACT2, ADD_SG, NL, true>), dim3((unsigned)total), dim3(256), lds, c.s, a);
         } else {
@@ -323,7 +320,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     // dz = BatchNorm-backward(G, z), in place over G: the operand of both GEMMs below
     {
         const long chunks = (long)M * N / 8;
-        if (L.bwd_fin_rows) {                                 // few partial rows: the apply pass finalises the unit's BatchNorm backward itself
+        if (L.bwd_fin_rows) {                                 // the apply pass finalises the unit's BatchNorm backward itself
             const int gx = ceil_div(N, 64), gy = std::max(1, std::min(ceil_div(M, 32), 1024 / gx));
             const fd_bn_bwd_fin fa = bwd_fin_args(c, i, 0);
             FD_LAUNCH((fd_bn_bwd_apply_fin_h16<T>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, c.s, Gsrc, G, twt<T>(c.p, L.z_off), M, N, fa);
@@ -355,7 +352,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     do {                                                                                                                                           \
         (void)hipFuncSetAttribute((const void *)fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         FD_LAUNCH((fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>), dim3(n_dgrad + (unsigned)(tiles_w * splits)), dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), \
-                  tws(c.p, P.st_off), ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_part(c.p, L.d.src), tws(c.p, L.wp_off), M, N, K, L.n64, \
+                  tws(c.p, P.st_off), ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, L.n64, \
                   m_tiles, k_tiles, (int)n_dgrad, k_tiles_w, tiles_w, rows);                                                                       \
     } while (0)
         if (add) { if (tn == 2) FD_PWBWD_H16(1, 2); else FD_PWBWD_H16(1, 1); }
@@ -378,7 +375,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
     do {                                                                                                                                           \
         (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);    \
         FD_LAUNCH((fd_pw_dgrad_h16<T, ACT_IN, ADDV, TNV>), grid, dim3(256), lds_d, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), tws(c.p, P.st_off), \
-                  ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_part(c.p, L.d.src), M, N, K, L.n64, m_tiles, k_tiles);          \
+                  ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), M, N, K, L.n64, m_tiles, k_tiles);          \
     } while (0)
         if (add) { if (tn == 2) FD_DGRAD_H16(1, 2); else FD_DGRAD_H16(1, 1); }
         else { if (tn == 2) FD_DGRAD_H16(0, 2); else FD_DGRAD_H16(0, 1); }
@@ -414,11 +411,11 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         if (add) {
             (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 1>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_part(c.p, L.d.src), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
         } else {
             (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 0>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      (const float *)nullptr, tws(c.p, P.g_off), bwd_part(c.p, L.d.src), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+                      (const float *)nullptr, tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
         }
         if ((rc = check_launch("fd_pw_bwd_f32"))) return rc;
         return defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight);
@@ -435,11 +432,11 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         if (add) {
             (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
             FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 1>), grid, dim3(256), lds_d, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_part(c.p, L.d.src), M, N, K, m_tiles, k_tiles);
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), M, N, K, m_tiles, k_tiles);
         } else {
             (void)hipFuncSetAttribute((const void *)fd_pw_dgrad_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
             FD_LAUNCH((fd_pw_dgrad_f32<ACT_IN, 0>), grid, dim3(256), lds_d, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      (const float *)nullptr, tws(c.p, P.g_off), bwd_part(c.p, L.d.src), M, N, K, m_tiles, k_tiles);
+                      (const float *)nullptr, tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), M, N, K, m_tiles, k_tiles);
         }
         return check_launch("fd_pw_dgrad_f32");
     }
@@ -459,22 +456,27 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
     TLayer &Hp = plan->layers[Hd.d.src];
     if (from_layer == hi) {
         fd_hs().trace_layer = hi;
+        if (!plan->bwd_stats_clean) {       // a second backward after one forward: the backward rows hold the previous pass's sums
+            for (int i = 0; i < n_layers; ++i)
+                if (hipMemsetAsync(plan->ws + plan->layers[i].sb_off, 0, stat_rows_bytes(plan->layers[i].nr_cap, plan->layers[i].d.cout), s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync(statistics rows) failed");
+        }
+        plan->bwd_stats_clean = false;
         const int nb = ceil_div(Hd.M, 256);
-        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_part(plan, hi), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
-        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_part(plan, hi), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_rows(plan, hi, nb), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_rows(plan, hi, nb), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
         if ((rc = check_launch("fd_head_bwd_reduce_f32"))) return rc;
-        if ((rc = bn_bwd_finalize(c, hi, nb))) return rc;
+        if ((rc = bn_bwd_finalize(c, hi))) return rc;
         constexpr int PPB = 16;
         const int nb2 = ceil_div(Hd.M, 32 * PPB);
         const size_t lds = (size_t)32 * Hd.d.cin * 3 * 4;
         float *wpart = tws(plan, Hd.wp_off);
         if ((size_t)nb2 * Hd.d.cin > Hd.wp_elems) return fail(FD_ERR_STATE, "weight-gradient partial region too small for the head");
-        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), bwd_part(plan, Hd.d.src), wpart, Hd.M, Hd.d.cin);
-        else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), bwd_part(plan, Hd.d.src), wpart, Hd.M, Hd.d.cin);
+        if (Hp.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU6_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), bwd_rows(plan, Hd.d.src, nb2), wpart, Hd.M, Hd.d.cin);
+        else FD_LAUNCH((fd_head_bwd<T, FD_ACT_RELU_, PPB>), dim3(nb2), dim3(256), lds, s, tws(plan, Hd.g_off), tws(plan, Hd.z_off), tws(plan, Hd.coef_off), twt<T>(plan, Hp.z_off), tws(plan, Hp.st_off), params[hi].conv_weight, twt<T>(plan, Hp.g_off), bwd_rows(plan, Hd.d.src, nb2), wpart, Hd.M, Hd.d.cin);
         if ((rc = check_launch("fd_head_bwd"))) return rc;
         if ((rc = defer_weights(c, wpart, nb2, Hd.d.cin, 0, 0, grads[hi].conv_weight))) return rc;
-        // the BN partials of the head's producer are now in `part` (nb2 workgroups)
-        if ((rc = finalize_or_defer(c, Hd.d.src, nb2))) return rc;
+        // the BatchNorm partial sums of the head's producer are in its statistics rows
+        if ((rc = finalize_or_defer(c, Hd.d.src))) return rc;
     }
     // ---- remaining units in reverse order; invariant: coef_i and the BN grads of unit i are final when unit i is processed
     for (int i = std::min(hi - 1, (int)from_layer); i >= to_layer; --i) {
@@ -498,7 +500,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
                 bool paired = false;
                 if ((rc = dispatch_dw_bwd_pair<T>(c, i, &nblk, &paired))) return rc;
                 if (paired) {
-                    if ((rc = finalize_or_defer(c, d.src, nblk))) return rc;
+                    if ((rc = finalize_or_defer(c, d.src))) return rc;
                     break;
                 }
             }
@@ -508,7 +510,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             if (P.d.act == FD_ACT_RELU6) rc = add ? dispatch_dw_dgrad<T, FD_ACT_RELU6_, 1>(c, i, &nblk) : dispatch_dw_dgrad<T, FD_ACT_RELU6_, 0>(c, i, &nblk);
             else rc = add ? dispatch_dw_dgrad<T, FD_ACT_RELU_, 1>(c, i, &nblk) : dispatch_dw_dgrad<T, FD_ACT_RELU_, 0>(c, i, &nblk);
             if (rc) return rc;
-            if ((rc = finalize_or_defer(c, d.src, nblk))) return rc;
+            if ((rc = finalize_or_defer(c, d.src))) return rc;
             break;
         }
         case FD_OP_PW: {
@@ -516,7 +518,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             if constexpr (F32) rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd<FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd<FD_ACT_RELU_>(c, i, &nblk);
             else rc = P.d.act == FD_ACT_RELU6 ? launch_pw_bwd_h16<T, FD_ACT_RELU6_>(c, i, &nblk) : launch_pw_bwd_h16<T, FD_ACT_RELU_>(c, i, &nblk);
             if (rc) return rc;
-            if ((rc = finalize_or_defer(c, d.src, nblk))) return rc;
+            if ((rc = finalize_or_defer(c, d.src))) return rc;
             break;
         }
         }
@@ -553,12 +555,19 @@ int fd_cast_gradients(const void *src, void *dst, int64_t numel, int32_t to_bf16
 /* ---- data-parallel gradient exchange issued by the library itself: RCCL all-reduce over xGMI (the reference's only multi-GPU
  * idiom is torch.nn.DataParallel, imagenet/mobilenet.py:68).  RCCL is bound at RUN time (dlopen "librccl.so.1": inside a torch process that is the
  * RCCL torch itself loaded, by SONAME; a torch-free host gets the system library), so the library has no link-time dependency on it and loads on
- * hosts without RCCL.  One communicator + one non-blocking HIP stream + one event per bucket; no host synchronisation anywhere. ---- */
-#ifndef FD_EMU
+ * hosts without RCCL.  One communicator + one non-blocking HIP stream + one event per bucket; no host synchronisation anywhere.
+ * The binding is injectable (fd_comm_bind_library, csrc/fd_tuning.h): the CPU test tier binds tests/rccl_stub -- the four nccl* entry points over POSIX
+ * shared memory -- to the EMULATOR build, so that this very code (bucket tiling, the 16-bit cast -> sum -> cast back, the order of the hand-overs, the
+ * mean folded into fd_sgd_step) runs at world size 2 without a GPU.  Without a bound library the emulator build offers a one-rank communicator whose
+ * all-reduce is the identity. ---- */
 #include <dlfcn.h>
+#ifdef FD_EMU
+#define hipEventReleaseToDevice 0
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 #endif
 struct fd_comm {
-    void *comm = nullptr;                 // ncclComm_t
+    void *comm = nullptr;                 // ncclComm_t (null: the emulator's one-rank communicator, all-reduce = identity)
     hipStream_t stream = nullptr;         // the collectives' stream
     std::vector<hipEvent_t> bucket_done;  // recorded on the compute stream after a bucket's last backward kernel
     hipEvent_t all_done = nullptr, t0 = nullptr, t1 = nullptr, tb = nullptr;   // t0 / t1: first collective issued / last one finished; tb: backward finished on the compute stream (timing enabled)
@@ -569,7 +578,6 @@ struct fd_comm {
 
 extern "C++" {
 namespace {
-#ifndef FD_EMU
 struct fd_nccl_uid { char internal[FD_COMM_ID_BYTES]; };
 struct RcclApi {
     int (*GetUniqueId)(fd_nccl_uid *) = nullptr;
@@ -579,12 +587,16 @@ struct RcclApi {
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
+std::string &rccl_path() { static std::string p; return p; }      // set by fd_comm_bind_library before the first use
 RcclApi &rccl()
 {
     static RcclApi api = [] {
         RcclApi a;
         void *h = nullptr;
-        for (const char *name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!rccl_path().empty()) h = dlopen(rccl_path().c_str(), RTLD_NOW | RTLD_LOCAL);
+#ifndef FD_EMU
+        else for (const char *name : {"librccl.so.1", "librccl.so"}) if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+#endif
         if (!h) return a;
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -602,45 +614,50 @@ int rccl_fail(const char *what, int rc)
     return fail(FD_ERR_HIP, "%s: RCCL error %d (%s)", what, rc, a.GetErrorString ? a.GetErrorString(rc) : "?");
 }
 constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclBfloat16 = 9;    // rccl.h: ncclRedOp_t / ncclDataType_t
+#ifdef FD_EMU
+constexpr bool kOneRankWithoutLibrary = true;     // the emulator's fallback communicator
+#else
+constexpr bool kOneRankWithoutLibrary = false;
 #endif
 }  // namespace
 }  // extern "C++"
 
+int fd_comm_bind_library(const char *path)
+{
+    if (!path || !*path) return fail(FD_ERR_INVALID, "fd_comm_bind_library: empty path");
+    if (!rccl_path().empty() && rccl_path() != path) return fail(FD_ERR_STATE, "fd_comm_bind_library: already bound to %s", rccl_path().c_str());
+    rccl_path() = path;
+    if (!rccl().ok) return fail(FD_ERR_STATE, "fd_comm_bind_library: %s does not provide ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy (or the binding was made before this call)", path);
+    return FD_OK;
+}
+
 int fd_comm_unique_id(void *id_out)
 {
-#ifdef FD_EMU
     if (!id_out) return fail(FD_ERR_INVALID, "null argument");
-    memset(id_out, 0, FD_COMM_ID_BYTES);                      // (the CPU emulator's communicator has exactly one rank: no rendezvous)
-    return FD_OK;
-#else
-    if (!id_out) return fail(FD_ERR_INVALID, "null argument");
-    if (!rccl().ok) return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy)");
+    if (!rccl().ok) {
+        if (kOneRankWithoutLibrary) { memset(id_out, 0, FD_COMM_ID_BYTES); return FD_OK; }       // (the emulator's one-rank communicator: no rendezvous)
+        return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded (or lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy)");
+    }
     fd_nccl_uid id{};
     const int rc = rccl().GetUniqueId(&id);
     if (rc) return rccl_fail("ncclGetUniqueId", rc);
     memcpy(id_out, id.internal, FD_COMM_ID_BYTES);
     return FD_OK;
-#endif
 }
 
 int fd_comm_create(const void *id, int32_t rank, int32_t world, fd_comm **out)
 {
-#ifdef FD_EMU
-    // the CPU emulator build (tests/hipemu) runs the exchange's control flow -- bucket tiling, ranges, the 16-bit casts -- with a one-rank communicator whose
-    // all-reduce is the identity; more ranks need RCCL, i.e. the HIP build
-    if (!id || !out || rank != 0 || world != 1) return fail(FD_ERR_STATE, "the CPU emulator offers a one-rank communicator only (RCCL needs the HIP build)");
-    fd_comm *c = new fd_comm();
-    *out = c;
-    return FD_OK;
-#else
     if (!id || !out || world <= 0 || rank < 0 || rank >= world) return fail(FD_ERR_INVALID, "fd_comm_create: bad argument (rank %d of %d)", rank, world);
-    if (!rccl().ok) return fail(FD_ERR_STATE, "librccl.so.1 could not be loaded");
+    if (!rccl().ok && !(kOneRankWithoutLibrary && world == 1))
+        return fail(FD_ERR_STATE, kOneRankWithoutLibrary ? "the CPU emulator offers a one-rank communicator only unless a collective library is bound (fd_comm_bind_library)" : "librccl.so.1 could not be loaded");
     fd_comm *c = new fd_comm();
     c->rank = rank; c->world = world;
-    fd_nccl_uid uid{};
-    memcpy(uid.internal, id, FD_COMM_ID_BYTES);
-    int rc = rccl().CommInitRank(&c->comm, world, uid, rank);          // (on the calling thread's current device, like every entry point here)
-    if (rc) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    if (rccl().ok) {
+        fd_nccl_uid uid{};
+        memcpy(uid.internal, id, FD_COMM_ID_BYTES);
+        const int rc = rccl().CommInitRank(&c->comm, world, uid, rank);          // (on the calling thread's current device, like every entry point here)
+        if (rc) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    }
     // Every event here is consumed by another stream of the SAME device (or only read for its timestamp): a device-scope release.  A default HIP event
     // performs a SYSTEM-scope fence when it is recorded -- an L2 write-back + invalidate in the middle of backward; measured on one rank: the exchange
     // machinery cost +155 us per step with default events (6 records per step), with or without the ncclAllReduce calls themselves.
@@ -654,19 +671,16 @@ int fd_comm_create(const void *id, int32_t rank, int32_t world, fd_comm **out)
     }
     *out = c;
     return FD_OK;
-#endif
 }
 
 void fd_comm_destroy(fd_comm *c)
 {
     if (!c) return;
-#ifndef FD_EMU
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     for (hipEvent_t e : c->bucket_done) (void)hipEventDestroy(e);
     for (hipEvent_t e : {c->all_done, c->t0, c->t1, c->tb}) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-#endif
     delete c;
 }
 
@@ -682,49 +696,49 @@ int fd_train_backward_allreduce(fd_train_plan *plan, const fd_layer_params *para
         expect = buckets[b].to_layer - 1;
     }
     if (expect != -1) return fail(FD_ERR_INVALID, "the buckets stop at layer %d: they must cover every layer", expect + 1);
-#ifndef FD_EMU
     hipStream_t s = static_cast<hipStream_t>(stream);
     while ((int)comm->bucket_done.size() < n_buckets) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return fail(FD_ERR_HIP, "hipEventCreate failed");
         comm->bucket_done.push_back(e);
     }
-#endif
-    // the summing all-reduce of `count` values in place on the communicator's stream (emulator: one rank, the identity)
+    comm->timed = false;
+    // the summing all-reduce of `count` values in place on the communicator's stream (no library bound, emulator: one rank, the identity)
     auto all_reduce = [&](void *buf, size_t count, bool bf16) -> int {
-#ifdef FD_EMU
-        (void)buf; (void)count; (void)bf16;
-        return FD_OK;
-#else
-        if (comm->elide) return FD_OK;
+        if (comm->elide || !comm->comm) return FD_OK;
         const int nrc = rccl().AllReduce(buf, buf, count, bf16 ? kNcclBfloat16 : kNcclFloat32, kNcclSum, comm->comm, comm->stream);
         return nrc ? rccl_fail("ncclAllReduce", nrc) : FD_OK;
-#endif
+    };
+    // Whatever happens after the first hand-over, the caller's stream must not run ahead of collectives that are already enqueued on the gradient
+    // buffers: every exit below that point -- error or not -- joins the communication stream back into `s`.
+    bool handed_over = false;
+    auto join = [&]() -> bool {
+        return hipEventRecord(comm->all_done, comm->stream) == hipSuccess && hipStreamWaitEvent(s, comm->all_done, 0) == hipSuccess;
+    };
+    auto bail = [&](int rc) -> int {
+        if (handed_over && !join()) (void)hipStreamSynchronize(comm->stream);      // (last resort: the host waits)
+        return rc;
     };
     for (int b = 0; b < n_buckets; ++b) {
         const fd_grad_bucket &k = buckets[b];
         int rc = fd_train_backward_range(plan, params, grads, n_layers, dy, k.from_layer, k.to_layer, stream);
-        if (rc) return rc;
-#ifndef FD_EMU
+        if (rc) return bail(rc);
         // the bucket's gradients are complete on the compute stream: the collective's stream waits for exactly that point
         if (hipEventRecord(comm->bucket_done[b], s) != hipSuccess || hipStreamWaitEvent(comm->stream, comm->bucket_done[b], 0) != hipSuccess)
-            return fail(FD_ERR_HIP, "event hand-over to the communication stream failed");
+            return bail(fail(FD_ERR_HIP, "event hand-over to the communication stream failed"));
+        handed_over = true;
         if (b == 0) (void)hipEventRecord(comm->t0, comm->stream);
-#endif
         if (k.grad16) {                                          // 16-bit exchange: convert, all-reduce the bf16 copy, convert back -- all in stream order
-            if ((rc = fd_cast_gradients(k.grad, k.grad16, k.numel, 1, comm->stream))) return rc;
-            if ((rc = all_reduce(k.grad16, (size_t)k.numel, true))) return rc;
-            if ((rc = fd_cast_gradients(k.grad16, k.grad, k.numel, 0, comm->stream))) return rc;
-        } else if ((rc = all_reduce(k.grad, (size_t)k.numel, false))) return rc;
+            if ((rc = fd_cast_gradients(k.grad, k.grad16, k.numel, 1, comm->stream))) return bail(rc);
+            if ((rc = all_reduce(k.grad16, (size_t)k.numel, true))) return bail(rc);
+            if ((rc = fd_cast_gradients(k.grad16, k.grad, k.numel, 0, comm->stream))) return bail(rc);
+        } else if ((rc = all_reduce(k.grad, (size_t)k.numel, false))) return bail(rc);
     }
-#ifndef FD_EMU
     (void)hipEventRecord(comm->tb, s);
     (void)hipEventRecord(comm->t1, comm->stream);
-    comm->timed = true;
     // whatever the caller enqueues next on its stream (fd_sgd_step) runs after the last collective
-    if (hipEventRecord(comm->all_done, comm->stream) != hipSuccess || hipStreamWaitEvent(s, comm->all_done, 0) != hipSuccess)
-        return fail(FD_ERR_HIP, "event hand-over from the communication stream failed");
-#endif
+    if (!join()) { (void)hipStreamSynchronize(comm->stream); return fail(FD_ERR_HIP, "event hand-over from the communication stream failed"); }
+    comm->timed = true;
     return FD_OK;
 }
 
@@ -732,10 +746,6 @@ void fd_comm_elide_collectives(fd_comm *comm, int32_t on) { if (comm) comm->elid
 
 int fd_comm_last_exchange_ms(fd_comm *comm, float *ms_exchange, float *ms_exposed)
 {
-#ifdef FD_EMU
-    (void)comm; (void)ms_exchange; (void)ms_exposed;
-    return fail(FD_ERR_STATE, "the RCCL exchange needs the HIP build");
-#else
     if (!comm || !ms_exchange || !ms_exposed) return fail(FD_ERR_INVALID, "null argument");
     if (!comm->timed) return fail(FD_ERR_STATE, "no exchange has been issued on this communicator");
     if (hipEventSynchronize(comm->t1) != hipSuccess || hipEventSynchronize(comm->tb) != hipSuccess || hipEventElapsedTime(ms_exchange, comm->t0, comm->t1) != hipSuccess)
@@ -743,7 +753,6 @@ int fd_comm_last_exchange_ms(fd_comm *comm, float *ms_exchange, float *ms_expose
     // exposed: how long after the last backward kernel the last collective ended (an event pair in the "wrong" order is a fully hidden exchange)
     if (hipEventElapsedTime(ms_exposed, comm->tb, comm->t1) != hipSuccess || *ms_exposed < 0.0f) *ms_exposed = 0.0f;
     return FD_OK;
-#endif
 }
 
 int fd_val_transform(const void *rgb_u8, const float *depth, int32_t n, int32_t height, int32_t width, int32_t out_h, int32_t out_w,

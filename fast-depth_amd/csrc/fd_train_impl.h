@@ -6,12 +6,12 @@ namespace {
 
 template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
-                    T *zout, float *part, hipStream_t s, int batch, const fd_bn_fin &fin)
+                    T *zout, fd_stat_rows part, hipStream_t s, int batch, const fd_bn_fin &fin)
 {
     L.lds_rounding = (L.lds_rounding & ~1) | ((!L.rows_th && L.dw_n == 8) ? 1 : 0);
     if (L.rows_th) {                                          // register-window kernel (3x3, plain input, large maps)
-        if (L.d.stride == 1) FD_LAUNCH((fd_dw3_rows_train<T, 1, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th);
-        else FD_LAUNCH((fd_dw3_rows_train<T, 2, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th);
+        if (L.d.stride == 1) FD_LAUNCH((fd_dw3_rows_train<T, 1, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th, fin);
+        else FD_LAUNCH((fd_dw3_rows_train<T, 2, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th, fin);
         return check_launch("fd_dw3_rows_train");
     }
     const int key = L.d.ksize * 100 + L.d.stride * 10 + L.mode;
@@ -36,7 +36,7 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
 // the skip tensor's activation, always an encoder unit)
 template <typename T>
 int dispatch_dw_train(const TLayer &L, int act1, int act2, const T *zin, const float *st1, const T *zskip, const float *st2,
-                      const float *w, T *zout, float *part, hipStream_t s, int batch, const fd_bn_fin &fin)
+                      const float *w, T *zout, fd_stat_rows part, hipStream_t s, int batch, const fd_bn_fin &fin)
 {
     if (act1 == FD_ACT_RELU6 && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU6_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch, fin);
     if (act1 == FD_ACT_RELU && act2 == FD_ACT_RELU6) return launch_dw_train<T, FD_ACT_RELU_, FD_ACT_RELU6_>(L, zin, st1, zskip, st2, w, zout, part, s, batch, fin);
@@ -52,7 +52,6 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
     constexpr bool F32 = std::is_same<T, float>::value;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float *x = static_cast<const float *>(x_nchw);
-    float *part = tws(plan, plan->part_off);
     plan->eps = bn_eps;
     plan->x_saved = x_nchw;
     if constexpr (!F32) {
@@ -76,18 +75,30 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         int rc = flush();
         if (rc) return rc;
     }
+    // the statistics rows of every unit, both directions, start the step at zero: one memset instead of 57 finalisation launches
+    if (hipMemsetAsync(plan->ws + plan->stat_off, 0, plan->stat_bytes, s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync(statistics rows) failed");
+    plan->bwd_stats_clean = true;
+    // the finalisation of unit u as its consumer's kernel (or fd_bn_finalize_rows_f32) performs it
+    auto fin_of = [&](int u) {
+        const TLayer &U = plan->layers[u];
+        const fd_layer_params &pq = params[u];
+        return fd_bn_fin{stat_ptr(plan, U.sf_off), U.nr_f, U.n_stat, U.n_unbiased, bn_eps, bn_momentum, pq.bn_weight, pq.bn_bias,
+                         const_cast<float *>(pq.bn_mean), const_cast<float *>(pq.bn_var), tws(plan, U.st_off), reinterpret_cast<long long *>(pq.bn_num_batches_tracked)};
+    };
+    for (int i = 0; i < n_layers; ++i)
+        if (!params[i].conv_weight || !params[i].bn_weight || !params[i].bn_bias || !params[i].bn_mean || !params[i].bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
     for (int i = 0; i < n_layers; ++i) {
         const TLayer &L = plan->layers[i];
         const fd_layer_desc &d = L.d;
         const fd_layer_params &q = params[i];
         fd_hs().trace_layer = i;
-        if (!q.conv_weight || !q.bn_weight || !q.bn_bias || !q.bn_mean || !q.bn_var) return fail(FD_ERR_INVALID, "layer %d: null parameter pointer", i);
         T *z = twt<T>(plan, L.z_off);
         const TLayer *P = d.src >= 0 ? &plan->layers[d.src] : nullptr;
         const T *zin = P ? twt<T>(plan, P->z_off) : nullptr;
         const float *st1 = P ? tws(plan, P->st_off) : nullptr;
         int rc = FD_OK;
-        float *part_i = L.fin_by_consumer ? tws(plan, plan->partb_off[0]) : part;
+        const fd_stat_rows part = fwd_rows(plan, L);
+        const fd_bn_fin fin = (P && P->fin_by_consumer) ? fin_of(d.src) : fd_bn_fin{};       // the producer's finalisation runs in this unit's kernel
         switch (d.op) {
         case FD_OP_STEM:
             FD_LAUNCH((fd_stem_train<T>), L.grid, dim3(256), L.lds, s, x, q.conv_weight, z, part, L.in_h, L.in_w, d.cout, (int)(L.lds / 4) - 4 * 2 * 32);
@@ -95,12 +106,6 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
             break;
         case FD_OP_DW: {
             const TLayer *K = d.skip >= 0 ? &plan->layers[d.skip] : nullptr;
-            fd_bn_fin fin{};
-            if (P->fin_by_consumer) {                         // the producer's finalisation runs in this kernel (fd_bn_finalize_block)
-                const fd_layer_params &pq = params[d.src];
-                fin = fd_bn_fin{tws(plan, plan->partb_off[0]), P->nblk, P->n_stat, P->n_unbiased, bn_eps, bn_momentum, pq.bn_weight, pq.bn_bias,
-                                const_cast<float *>(pq.bn_mean), const_cast<float *>(pq.bn_var), tws(plan, P->st_off), reinterpret_cast<long long *>(pq.bn_num_batches_tracked)};
-            }
             rc = dispatch_dw_train<T>(L, P->d.act, K ? K->d.act : FD_ACT_RELU6, zin, st1, K ? twt<T>(plan, K->z_off) : (const T *)nullptr,
                                       K ? tws(plan, K->st_off) : nullptr, q.conv_weight, z, part, s, plan->B, fin);
             break;
@@ -109,13 +114,13 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
             if (L.head) {
                 const long npix = L.M;
                 float *zl = tws(plan, L.z_off);
-                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_train<T, FD_ACT_RELU6_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, zl, part, npix, d.cin);
-                else FD_LAUNCH((fd_head_train<T, FD_ACT_RELU_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, zl, part, npix, d.cin);
+                if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_train<T, FD_ACT_RELU6_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, zl, part, npix, d.cin, fin);
+                else FD_LAUNCH((fd_head_train<T, FD_ACT_RELU_>), L.grid, dim3(256), 0, s, zin, st1, q.conv_weight, zl, part, npix, d.cin, fin);
                 rc = check_launch("fd_head_train");
             } else {
                 if constexpr (F32) {
                     if (L.pw16_tm) {
-                        const fd_g16_train tr{st1, part_i};
+                        const fd_g16_train tr{st1, part, fin};
 #define FD_PW16T(TMV, ACTV)                                                                                                                          \
     do {                                                                                                                                              \
         (void)hipFuncSetAttribute((const void *)fd_pw_gemm16_f32<TMV, FD_G16_STAGES, 0, 0, 0, ACTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds); \
@@ -132,15 +137,15 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
                         rc = check_launch("fd_pw_gemm16_f32");
                         break;
                     }
-                    if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part_i, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
-                    else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part_i, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles);
+                    if (P->d.act == FD_ACT_RELU6) FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU6_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles, fin);
+                    else FD_LAUNCH((fd_pw_gemm_train_f32<FD_ACT_RELU_>), L.grid, dim3(256), L.lds, s, zin, st1, q.conv_weight, z, part, (int)L.M, d.cout, d.cin, L.m_tiles, L.n_tiles, fin);
                     rc = check_launch("fd_pw_gemm_train_f32");
                 } else {
                     T *wt = twt<T>(plan, L.wt_off);      // 16-bit operand copies of the master weights: made for all units at the start of the step
 #define FD_PWT_H16(ACTV, TNV)                                                                                                                     \
     do {                                                                                                                                          \
         (void)hipFuncSetAttribute((const void *)fd_pw_gemm_train_h16<T, ACTV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds);     \
-        FD_LAUNCH((fd_pw_gemm_train_h16<T, ACTV, TNV>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part_i, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles); \
+        FD_LAUNCH((fd_pw_gemm_train_h16<T, ACTV, TNV>), L.grid, dim3(256), L.lds, s, zin, st1, wt, z, part, (int)L.M, d.cout, d.cin, L.k64, L.m_tiles, L.n_tiles, fin); \
     } while (0)
                     if (P->d.act == FD_ACT_RELU6) { if (L.pw_tn == 2) FD_PWT_H16(FD_ACT_RELU6_, 2); else FD_PWT_H16(FD_ACT_RELU6_, 1); }
                     else { if (L.pw_tn == 2) FD_PWT_H16(FD_ACT_RELU_, 2); else FD_PWT_H16(FD_ACT_RELU_, 1); }
@@ -152,17 +157,16 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         }
         if (rc) return rc;
         if (L.fin_by_consumer) continue;
-        const RedGeom rg = red_geom(L.nblk, d.cout);
-        FD_LAUNCH(fd_bn_finalize_f32, rg.grid, dim3(1024), 0, s, part, L.nblk, rg.rps, d.cout, L.n_stat, L.n_unbiased, bn_eps, bn_momentum,
-                  q.bn_weight, q.bn_bias, const_cast<float *>(q.bn_mean), const_cast<float *>(q.bn_var), tws(plan, L.st_off), red_slices(plan), red_counters(plan),
-                  reinterpret_cast<long long *>(q.bn_num_batches_tracked));
-        if ((rc = check_launch("fd_bn_finalize_f32"))) return rc;
+        const fd_bn_fin own = fin_of(i);
+        FD_LAUNCH(fd_bn_finalize_rows_f32, dim3((unsigned)ceil_div(d.cout, 256)), dim3(256), 0, s, own, d.cout);
+        if ((rc = check_launch("fd_bn_finalize_rows_f32"))) return rc;
     }
     const TLayer &Hd = plan->layers.back();
+    const fd_bn_fin hfin = Hd.fin_by_consumer ? fin_of(n_layers - 1) : fd_bn_fin{};     // the head's own BatchNorm: finalised by the kernel that writes the prediction
     if (Hd.d.act == FD_ACT_RELU6)
-        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU6_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU6_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample, hfin);
     else
-        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
+        FD_LAUNCH((fd_head_apply_f32<FD_ACT_RELU_>), dim3(ceil_div(Hd.M, 256)), dim3(256), 0, s, tws(plan, Hd.z_off), tws(plan, Hd.st_off), static_cast<float *>(y), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample, hfin);
     int rc = check_launch("fd_head_apply_f32");
     fd_hs().trace_layer = -1;
     if (rc) return rc;
@@ -192,7 +196,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
     const size_t esz = h16 ? 2 : 4;
     p->esz = esz;
     p->layers.resize(n_layers);
-    size_t off = 0, max_part = 0, max_wpart = 0, max_g = 0, max_width = 0;
+    size_t off = 0, max_g = 0;
 #define FD_BAD(...) do { int rc_ = fail(FD_ERR_INVALID, __VA_ARGS__); delete p; return rc_; } while (0)
     for (int i = 0; i < n_layers; ++i) {
         TLayer &L = p->layers[i];
@@ -291,16 +295,11 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                     L.lds = 0;
                 }
             }
-            if (d.src == i - 1 && !L.rows_th && L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE)) {
-                // the pointwise producer's BatchNorm is finalised by this kernel's workgroups (fd_bn_finalize_block) when its partial rows are few:
-                // the 14 x 14 / 7 x 7 units at B = 32 (98 / 25 rows) -- one launch at the per-launch floor less per unit
-                TLayer &P = p->layers[d.src];
-                // (every consumer workgroup re-reads the rows of its channel block: bounded, so that the re-reads stay far below the layer's own traffic --
-                // decode_conv4.0's 4096 workgroups behind a 128-row producer would read 130 MB of partial rows)
-                if (P.d.op == FD_OP_PW && !P.head && P.nblk <= FD_FIN_MAX_ROWS && (long)P.nblk * L.grid.x * L.grid.y * L.grid.z <= 131072) {
-                    P.fin_by_consumer = true;
-                    L.lds += (size_t)2 * cb * 4;
-                }
+            if (L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && !(L.rows_th && d.cin > 256)) {
+                // the producer's BatchNorm is finalised by this kernel's workgroups from the producer's statistics rows (fd_stat_table_block in the LDS-tiled
+                // kernel, which keeps the block's (scale, shift) behind its tap table; the register-window kernel holds all C <= 256 channels in its static LDS)
+                p->layers[d.src].fin_by_consumer = true;
+                if (!L.rows_th) L.lds += (size_t)2 * cb * 4;
             }
             const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
@@ -322,6 +321,10 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w * 8, 256));
                 L.nblk = (int)L.grid.x;
                 L.wp_elems = (size_t)ceil_div((long)batch * L.out_h * L.out_w, 32 * 16) * d.cin;
+                if (!(tune & FD_TUNE_NO_CONSUMER_FINALIZE)) {
+                    if (d.cin <= FD_HEAD_FIN_MAX) p->layers[d.src].fin_by_consumer = true;     // its producer: finalised in fd_head_train
+                    L.fin_by_consumer = true;                                                   // the head's own 1-channel BatchNorm: in fd_head_apply_f32
+                }
             } else {
                 if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample only as the 1-channel head", i);
                 L.out_h = L.in_h; L.out_w = L.in_w;
@@ -354,6 +357,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                         L.nblk = L.m_tiles;
                     }
                 }
+                // the producer's BatchNorm is finalised by this GEMM's workgroups (fd_stat_table_all into the [2][K] table they keep in LDS anyway)
+                if (!(tune & FD_TUNE_NO_CONSUMER_FINALIZE)) p->layers[d.src].fin_by_consumer = true;
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
                     const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
                     int splits = std::max(1, std::min(ceil_div(h16 ? FD_WGRAD_TARGET_WGS_H16 : FD_WGRAD_TARGET_WGS_F32, (long)nt * kt), ceil_div(M, 256)));
@@ -381,19 +386,11 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         }
         L.st_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         L.coef_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
-        max_part = std::max(max_part, (size_t)L.nblk * 2 * d.cout);
-        // (the depthwise backward-data kernel leaves one row of the PRODUCER's statistics per input-space tile: sized for the smallest tile a build
-        // switch may select, 4 rows x 8 columns)
-        if (d.op == FD_OP_DW) max_part = std::max(max_part, (size_t)ceil_div(L.in_w, 8) * ceil_div(L.in_h, 4) * batch * d.cin);
-        // (the register-window backward-data kernel of the stride-2 units, fd_dw3s2_dgrad_rows: one row of 2 * C floats per 256 (input column,
-        // channel group) pairs x strip of >= 2 low-resolution rows x image -- more rows than the tiled kernels leave once C > 128)
-        if (d.op == FD_OP_DW && d.stride == 2) max_part = std::max(max_part, (size_t)ceil_div((long)L.in_w * (d.cin / 4), 256) * ceil_div(L.in_h / 2, 2) * batch * 2 * d.cin);
-        max_width = std::max(max_width, (size_t)2 * d.cout);
-        if (d.op == FD_OP_DW) max_width = std::max(max_width, (size_t)d.ksize * d.ksize * d.cin);
-        if (d.op == FD_OP_STEM) max_width = std::max(max_width, (size_t)27 * d.cout);
-        if (d.op == FD_OP_PW) max_width = std::max(max_width, (size_t)d.cin * d.cout);
+        // statistics rows: reserved for the row count a producer of M / 64 workgroups per channel would take (the pointwise GEMMs' 64-row tiles: no kernel
+        // of either direction has more workgroups per channel), used with the count the actual producer's workgroup number asks for
+        L.nr_cap = stat_nr(ceil_div(L.M, 64));
+        L.nr_f = std::min(L.nr_cap, stat_nr(L.nblk));
         max_g = std::max(max_g, L.z_elems);
-        max_wpart = std::max(max_wpart, L.wp_elems);
         L.wp_off = off; off += align_up(std::max(L.wp_elems, (size_t)1) * 4, 256);
     }
     TLayer &last = p->layers.back();
@@ -413,13 +410,14 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         }
         if (L.skip_consumer >= 0) { L.sg_off = off; off += align_up(L.z_elems * esz, 256); }
     }
-    // backward reductions reuse the same partial buffer: BN-backward partials are 2 floats per channel per workgroup too
-    p->part_off = off; p->part_bytes = align_up(std::max(max_part, (size_t)1) * 4 * 2, 256); off += p->part_bytes;
-    p->partb_off[0] = off; off += p->part_bytes;
-    p->partb_off[1] = off; off += p->part_bytes;
-    // slice sums (double) of the fused two-level reductions: ceil(rows / 64) x 2 x width, bounded through rows x width <= the partial buffers
-    p->part2_off = off; p->part2_bytes = align_up((2 * max_part / 16 + max_wpart / 16 + 8 * std::max(max_width, (size_t)1) + 128) * 8, 256); off += p->part2_bytes;   // two reductions can share a launch
-    p->cnt_off = off; p->cnt_bytes = align_up((2 * ceil_div((long)std::max(max_width, (size_t)1), 64) + 2) * 4, 256); off += p->cnt_bytes;   // arrival counters, one per 64 columns
+    // the statistics rows of every unit, forward then backward, in ONE region (zeroed by a single memset per step)
+    p->stat_off = off;
+    for (int i = 0; i < n_layers; ++i) {
+        TLayer &L = p->layers[i];
+        L.sf_off = off; off += align_up(stat_rows_bytes(L.nr_cap, L.d.cout), 256);
+        L.sb_off = off; off += align_up(stat_rows_bytes(L.nr_cap, L.d.cout), 256);
+    }
+    p->stat_bytes = off - p->stat_off;
     for (int i = 0; i < n_layers; ++i) p->layers[i].bwd_fin = bwd_fin_candidate(p, i);
     p->ws_bytes = off;
     *out_plan = p;
@@ -436,10 +434,6 @@ int fd_train_plan_bind_workspace(fd_train_plan *plan, void *device_ptr, size_t b
     if (reinterpret_cast<uintptr_t>(device_ptr) % 256) return fail(FD_ERR_INVALID, "workspace must be 256-byte aligned");
     plan->ws = static_cast<unsigned char *>(device_ptr);
     plan->forward_done = false;
-    // arrival counters of the two-level reductions start at 0 (the kernels return them to 0)
-    // (synchronous: the first launch may come on any stream)
-    if (hipMemset(plan->ws + plan->cnt_off, 0, plan->cnt_bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
-        return fail(FD_ERR_HIP, "hipMemset(reduction counters) failed");
     return FD_OK;
 }
 

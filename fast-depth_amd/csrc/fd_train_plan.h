@@ -3,8 +3,9 @@
 //
 // Workspace layout of a train plan:
 //   [z_i]   raw conv output of every unit, NHWC, fp32 or bf16 (plan dtype), all kept (they are the saved tensors of backward)
-//   [st_i]  per-unit BatchNorm table [4][C]: scale, shift, mean, invstd (fd_bn_finalize_f32)
-//   [part]  one shared buffer for per-workgroup reduction partials (consumed right after each producer)
+//   [st_i]  per-unit BatchNorm table [4][C]: scale, shift, mean, invstd (written by the unit's finalising workgroup: fd_bn_publish)
+//   [stat]  per-unit BatchNorm statistics rows, forward (sum z, sum z^2) and backward (sum G, sum G*xhat): int64 [nr][3 bins][2][C] each (fd_device.h:
+//           fd_stat_add / fd_stat_total), ONE contiguous region zeroed by a single memset at the start of every forward
 //   backward only: [g_a, g_b] ping-pong dLoss/d(BN output) buffers, [skipgrad_k] decoder->skip gradient buffers,
 //   [coef_i] per-unit BN-backward coefficient tables, [wpart_i] per-unit weight-gradient partials (reduced by ONE launch per backward
 //   range: fd_reduce_weights_batch_f32).
@@ -63,10 +64,14 @@ struct TLayer {
     int pw16_tm = 0, pw16_stride = 0;                         // fp32 plans: the forward runs on fd_pw_gemm16_f32<TM, ..., TRAIN> (one workgroup per CU, rows in strides of pw16_stride)
     size_t lds = 0;
     dim3 grid;
-    int nblk = 0;                    // reduction partials this unit's forward kernel writes
-    bool bwd_fin = false;            // the unit's first backward kernel can finalise its BatchNorm backward (bwd_fin_candidate); its partial rows live in partb_off[i & 1]
-    mutable int bwd_fin_rows = 0;    // > 0: it does so in this step -- that many partial rows are waiting (set when the consumer's backward kernels were launched)
-    bool fin_by_consumer = false;    // pointwise unit with <= FD_FIN_MAX_ROWS partial rows whose LDS-tiled depthwise consumer finalises its BatchNorm (no fd_bn_finalize_f32 launch)
+    int nblk = 0;                    // workgroups per channel of this unit's forward kernel that add a partial sum to its statistics rows
+    int nr_cap = 1;                  // statistics rows reserved per direction (stat_nr of the unit's pixel count / 64)
+    int nr_f = 1;                    // rows its forward kernel deals its partials to (stat_nr(nblk), <= nr_cap)
+    mutable int nr_b = 1;            // rows the backward kernel of its CONSUMER dealt the (sum G, sum G*xhat) partials to (set at that launch)
+    size_t sf_off = 0, sb_off = 0;   // forward / backward statistics rows
+    bool bwd_fin = false;            // the unit's first backward kernel can finalise its BatchNorm backward (bwd_fin_candidate)
+    mutable int bwd_fin_rows = 0;    // > 0: it does so in this step (= nr_b; set when the consumer's backward kernels were launched)
+    bool fin_by_consumer = false;    // this unit's BatchNorm is finalised inside its consumer's forward kernel (no fd_bn_finalize_rows_f32 launch)
     size_t z_off = 0, z_elems = 0;   // raw output
     size_t st_off = 0;               // [4][C] table
     size_t coef_off = 0;             // backward coefficient table [4][C]
@@ -90,8 +95,8 @@ struct fd_train_plan {
     int B = 0, H = 0, W = 0, dtype = FD_F32;
     uint32_t flags = 0, tune = 0;    // public plan flags (include/fastdepth_hip.h) / private tuning mask (fd_tuning.h)
     size_t esz = 4;                  // bytes per stored activation / activation-gradient element
-    size_t partb_off[2] = {0, 0};    // partial rows of the units finalised inside a kernel that writes the next rows meanwhile: forward [0]; backward [unit & 1]
-    size_t ws_bytes = 0, part_off = 0, part_bytes = 0, part2_off = 0, part2_bytes = 0, cnt_off = 0, cnt_bytes = 0;
+    size_t ws_bytes = 0, stat_off = 0, stat_bytes = 0;   // the statistics rows of all units (both directions): zeroed per step
+    bool bwd_stats_clean = false;    // the backward rows are still zero (no backward has run since the last forward's memset)
     unsigned char *ws = nullptr;
     bool forward_done = false;
     float eps = 1e-5f;
@@ -103,18 +108,29 @@ namespace {
 inline float *tws(fd_train_plan *p, size_t off) { return reinterpret_cast<float *>(p->ws + off); }
 template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reinterpret_cast<T *>(p->ws + off); }
 
-// Launch geometry of the fused two-level reductions (fd_two_level_tail): up to 256 partial rows are finalised by a single
-// workgroup per 64 columns (16 rows per wave, all loads of 8 rows in flight: cheaper than slices + arrival counter + second level, which is
-// three more dependent round trips -- the 14x14 / 7x7 units have 25 ... 98 rows); more rows are cut into slices that the grid's y dimension sums first.
-struct RedGeom { int rps; dim3 grid; };
-inline RedGeom red_geom(int nrows, long width)
+// Statistics rows a producer of `nblk` workgroups per channel deals its partial sums to: one address takes an atomic every ~22 ns (measured,
+// tools/microbench/stat_atomics.hip), so an address should see at most ~FD_STAT_ADDS_PER_ROW of them during the producer's life; a power of two
+// <= FD_STAT_MAX_ROWS (the consumer adds nr x 3 integers per channel and sum).
+#ifndef FD_STAT_ADDS_PER_ROW
+#define FD_STAT_ADDS_PER_ROW 256
+#endif
+inline int stat_nr(long nblk)
 {
-    if (nrows <= 256) return RedGeom{nrows, dim3((unsigned)ceil_div(width, 64), 1)};
-    const int rps = std::max(64, ceil_div(nrows, 128));       // at most 128 slices (fd_two_level_tail: 8 per wave)
-    return RedGeom{rps, dim3((unsigned)ceil_div(width, 64), (unsigned)ceil_div(nrows, rps))};
+    int nr = 1;
+    while (nr < FD_STAT_MAX_ROWS && (long)nr * FD_STAT_ADDS_PER_ROW < nblk) nr *= 2;
+    return nr;
 }
-inline double *red_slices(fd_train_plan *p) { return reinterpret_cast<double *>(p->ws + p->part2_off); }
-inline int *red_counters(fd_train_plan *p) { return reinterpret_cast<int *>(p->ws + p->cnt_off); }
+inline size_t stat_rows_bytes(int nr, int C) { return (size_t)nr * FD_STAT_BINS * 2 * C * sizeof(long long); }
+inline long long *stat_ptr(fd_train_plan *p, size_t off) { return reinterpret_cast<long long *>(p->ws + off); }
+// this unit's forward rows as its producer kernel sees them
+inline fd_stat_rows fwd_rows(fd_train_plan *p, const TLayer &L) { return fd_stat_rows{stat_ptr(p, L.sf_off), L.nr_f}; }
+// unit u's backward rows as the backward-data kernel of its consumer (nblk workgroups per channel) sees them; remembers the row count for u's finalisation
+inline fd_stat_rows bwd_rows(fd_train_plan *p, int u, long nblk)
+{
+    const TLayer &U = p->layers[u];
+    U.nr_b = std::min(U.nr_cap, stat_nr(nblk));
+    return fd_stat_rows{stat_ptr(p, U.sb_off), U.nr_b};
+}
 
 // calls fn(fd_int<4>) or -- 16-bit storage types only -- fn(fd_int<8>): the lane width (fd_lane) of the LDS-tiled depthwise kernels
 template <typename T, typename F> inline void fd_by_lane_width(int n, F &&fn)
@@ -154,9 +170,9 @@ inline bool bwd_fin_candidate(const fd_train_plan *p, int i)
 {
     const TLayer &L = p->layers[i];
     if ((p->tune & FD_TUNE_NO_CONSUMER_FINALIZE) || L.head || L.d.src < 0) return false;
-    if (L.d.op == FD_OP_PW) return p->esz == 2;
-    // (depthwise units: built and measured, off by default -- bf16 step: the 10 launches it removes are 43 us, the paired kernels get 40 us slower (both roles
-    // sum the rows; 163 VGPRs + 36 bytes of scratch in the 3x3 instance); fp32 step +26 us.  FD_TUNE_DW_BWD_FINALIZE turns it on: tests, A/B)
+    if (L.d.op == FD_OP_PW) return p->esz == 2;           // (16-bit plans: the apply pass fd_bn_bwd_apply_fin_h16; any row count now that the rows are few)
+    // (depthwise units: built and measured in round 4 with up to 128 fp32 partial rows, off by default -- bf16 step: the 10 launches it removed were 43 us, the
+    // paired kernels got 40 us slower (163 VGPRs + 36 bytes of scratch in the 3x3 instance); fp32 step +26 us.  FD_TUNE_DW_BWD_FINALIZE turns it on: tests, A/B)
     if (L.d.op == FD_OP_DW) return (p->tune & FD_TUNE_DW_BWD_FINALIZE) && !(p->flags & FD_PLAN_NO_BWD_PAIRING) && dw_bwd_has_pair(p, i) && !dw_bwd_on_rows(p, L);
     return false;
 }

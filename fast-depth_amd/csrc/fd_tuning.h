@@ -57,6 +57,10 @@ int fd_train_plan_unit_kernels(const struct fd_train_plan *plan, int32_t layer);
  * cost of the library's own machinery from RCCL's degenerate one-rank collective (a run of small copy / fill kernels).  Only valid on one rank. */
 struct fd_comm;
 void fd_comm_elide_collectives(struct fd_comm *comm, int32_t on);
+/* Test hook: the shared library that provides ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy, instead of librccl.so.1.  Must be
+ * called before the process first touches fd_comm_* (the binding is made once).  The CPU test tier binds tests/rccl_stub (the four entry points over
+ * POSIX shared memory) to the EMULATOR build and so runs fd_train_backward_allreduce at world size 2 without a GPU (tests/test_dp_gloo.py). */
+int fd_comm_bind_library(const char *path);
 #ifdef __cplusplus
 }
 #endif

@@ -319,23 +319,45 @@ class TrainEngine(TrainCore):
                 raise capi.FastDepthError("exchange='library' needs a GPU (RCCL)")          # (a test-only library -- the CPU emulator -- brings its own one-rank communicator)
             L = self.L
             rank = self.dist.get_rank(process_group)
-            uid = torch.zeros(128, dtype=torch.uint8)
+            # Rendezvous without a one-sided failure: nothing raises between the collectives.  Rank 0 broadcasts the 128-byte id TOGETHER with a status
+            # byte (fd_comm_unique_id fails where librccl.so.1 cannot be bound), every rank then reports whether ITS fd_comm_create succeeded, and the
+            # group decides jointly (all-reduce MIN of the flag): all ranks take the library route, or all of them fall back to the torch.distributed
+            # route ("auto") / raise ("library").  A rank that raised alone would leave its peers waiting in the next collective for ever.
+            msg = torch.zeros(129, dtype=torch.uint8)
+            err0 = ""
             if rank == 0:
-                capi.check(L, L.fd_comm_unique_id(uid.data_ptr()), "fd_comm_unique_id")
-            uid_dev = uid.to(self.device)
-            self.dist.broadcast(uid_dev, src=self.dist.get_global_rank(process_group, 0) if hasattr(self.dist, "get_global_rank") else 0, group=process_group)
-            uid = uid_dev.cpu()
-            handle = ctypes.c_void_p()
-            with _device_guard(self.device):
-                capi.check(L, L.fd_comm_create(uid.contiguous().data_ptr(), rank, self.world, ctypes.byref(handle)), "fd_comm_create")
+                if L.fd_comm_unique_id(msg.data_ptr()) == 0:
+                    msg[128] = 1
+                else:
+                    err0 = L.fd_last_error().decode()
+            msg_dev = msg.to(self.device)
+            self.dist.broadcast(msg_dev, src=self.dist.get_global_rank(process_group, 0) if hasattr(self.dist, "get_global_rank") else 0, group=process_group)
+            msg = msg_dev.cpu()
+            handle, err = ctypes.c_void_p(), err0
+            ok = bool(msg[128].item())
+            if ok:
+                with _device_guard(self.device):
+                    ok = L.fd_comm_create(msg[:128].contiguous().data_ptr(), rank, self.world, ctypes.byref(handle)) == 0
+                if not ok:
+                    err = L.fd_last_error().decode()
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=process_group)
+            if int(flag.item()) == 0:                      # agreed by every rank
+                if ok and handle:
+                    L.fd_comm_destroy(handle)              # (this rank's communicator came up, a peer's did not: nobody keeps one)
+                handle = None
+                if exchange == "library":
+                    raise capi.FastDepthError("exchange='library': the library's RCCL communicator could not be set up on every rank (%s)" % (err or "a peer rank failed"))
+                import warnings
+                warnings.warn("fastdepth_hip: library-issued gradient exchange unavailable (%s); every rank uses torch.distributed.all_reduce per bucket" % (err or "a peer rank failed"))
             self.comm = handle
-            if _elide_collectives and self.world == 1:
+            if _elide_collectives and self.world == 1 and self.comm is not None:
                 L.fd_comm_elide_collectives.argtypes = [ctypes.c_void_p, ctypes.c_int32]      # measurement hook (csrc/fd_tuning.h), one rank only
                 L.fd_comm_elide_collectives.restype = None
                 L.fd_comm_elide_collectives(handle, 1)
-            nb = len(self.buckets)
-            self.c_buckets = (capi.GradBucket * nb)()
-            for k, (fl, tl) in enumerate(self.buckets):
+            nb = len(self.buckets) if self.comm is not None else 0
+            self.c_buckets = (capi.GradBucket * max(nb, 1))()
+            for k, (fl, tl) in enumerate(self.buckets if self.comm is not None else ()):
                 g32 = self.bucket_slice(fl, tl)
                 g16 = self.bucket_slice(fl, tl, self.flat_grad16) if self.flat_grad16 is not None else None
                 self.c_buckets[k] = capi.GradBucket(fl, tl, g32.data_ptr(), g32.numel(), g16.data_ptr() if g16 is not None else None)

@@ -230,8 +230,8 @@ def test_train_step_layer_local_other_shape(dtype):
 
 
 # ---- BASELINE.json configs[2] at its stated size: batch 32, 224x224 -- the configuration bench.py times ------------------------------------------
-# At B = 32 the kernels run grids and reduction geometries that no smaller batch selects (up to 6272 partial rows per BatchNorm reduction cut
-# into up to 98 slices with a last-arriver pass, 16-way pixel splits of the weight-gradient GEMMs, 64 x 128 bf16 tiles, whole-chip one-round
+# At B = 32 the kernels run grids and reduction geometries that no smaller batch selects (up to 6272 workgroups per channel adding into 16
+# statistics rows, 16-way pixel splits of the weight-gradient GEMMs, 64 x 128 bf16 tiles, whole-chip one-round
 # grids).  The fp64 single-unit references below are a few minutes of host time.
 
 def _product_plan_gradients(m, x, tgt, dtype, flags=0, trace=None):
@@ -255,11 +255,13 @@ def _product_plan_gradients(m, x, tgt, dtype, flags=0, trace=None):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_in_kernel_batchnorm_finalisations_batch32(dtype):
-    """Round 4: at batch 32 the BatchNorm statistics of the 14x14 / 7x7 pointwise units are finalised inside the consuming depthwise kernel
-    (fd_bn_finalize_block) and, in the bf16 plan, their BatchNorm backward inside the apply pass (fd_bn_bwd_apply_fin_h16) -- 10 + 10 launches
-    fewer.  Asserted: the launch census of both plans, and that the step computes what the plan with every finalisation as its own launch
-    (FD_TUNE_NO_CONSUMER_FINALIZE) computes: the row sums are double in both, in a different order, so the tables agree to the last float bit
-    or the one next to it -- prediction to 1e-4 (fp32) / 2e-2 (bf16: re-rounding noise) of its scale, the 114 gradient tensors to 1e-2 / 1e-1 in norm."""
+    """Round 5: every unit's forward kernel ADDS its BatchNorm partial sums into the unit's statistics rows (64-bit integer atomics, fd_stat_add) and the
+    CONSUMER's workgroups derive (scale, shift) from them in their prologue -- no forward finalisation launch is left (38 fewer); in the bf16 plan the
+    BatchNorm backward of every pointwise unit is finalised inside its apply pass (fd_bn_bwd_apply_fin_h16: 18 launches fewer).  Asserted: the launch
+    census of both plans, and that the step computes what the plan with every finalisation as its own launch (FD_TUNE_NO_CONSUMER_FINALIZE) computes:
+    both read the same integers; a consumer that deals a channel's rows to several work-items adds their doubles in a different order, so the tables
+    agree to the last float bit or the one next to it -- prediction to 1e-4 (fp32) / 2e-2 (bf16: re-rounding noise) of its scale, the 114 gradient
+    tensors to 1e-2 / 1e-1 in norm."""
     from fastdepth_hip import capi
     m = _model(seed=25)
     x, tgt = _batch(32, seed=10)
@@ -267,14 +269,14 @@ def test_in_kernel_batchnorm_finalisations_batch32(dtype):
     y, flat = _product_plan_gradients(m, x, tgt, dtype, trace=names)
     y_sep, flat_sep = _product_plan_gradients(m, x, tgt, dtype, flags=capi.FD_TUNE_NO_CONSUMER_FINALIZE, trace=names_sep)
     count = lambda ns, key: sum(1 for k in ns if key in k)
-    fwd_sep, bwd_sep = count(names_sep, "fd_bn_finalize_f32"), count(names_sep, "fd_bn_bwd_finalize_f32")
+    fwd_sep, bwd_sep = count(names_sep, "fd_bn_finalize_rows_f32"), count(names_sep, "fd_bn_bwd_finalize_rows_f32")
     assert fwd_sep == 38 and bwd_sep == 38 and count(names_sep, "apply_fin") == 0
-    # (forward: conv6.3 ... conv13.3 and decode_conv1.1; decode_conv2.1's 98 rows would be re-read by 2048 consumer workgroups -- more than the plan allows)
-    assert count(names, "fd_bn_finalize_f32") == 29
+    assert count(names, "fd_bn_finalize_rows_f32") == 0
     if dtype == torch.bfloat16:
-        assert count(names, "fd_bn_bwd_apply_fin_h16") == 10 and count(names, "fd_bn_bwd_finalize_f32") == 28 and len(names) == len(names_sep) - 19
+        assert count(names, "fd_bn_bwd_apply_fin_h16") == 18 and count(names, "fd_bn_bwd_apply_h16") == 0
+        assert count(names, "fd_bn_bwd_finalize_rows_f32") == 20 and len(names) == len(names_sep) - 38 - 18
     else:
-        assert count(names, "fd_bn_bwd_finalize_f32") == 38 and len(names) == len(names_sep) - 9
+        assert count(names, "fd_bn_bwd_finalize_rows_f32") == 38 and len(names) == len(names_sep) - 38
         assert count(names, "fd_pw_gemm16_f32") == 9 and count(names_sep, "fd_pw_gemm16_f32") == 9      # conv6.3 ... conv13.3, decode_conv1.1: the fp32 forward GEMMs in train mode
     # (a last-bit difference in ten tables, carried through a train-mode network that amplifies perturbations ~300x and whose ReLU masks can flip:
     # the rigorous statement about these kernels is the layer-local test above, which runs the same default plan)
