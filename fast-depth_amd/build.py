@@ -19,12 +19,37 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 FLAGS = CFLAGS + ["-shared"]          # (one-command form, kept for callers that build a single source)
 
 
+def _deps():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "_obj") + [os.path.join(HERE, "..", "include", "fastdepth_hip.h")]
+
+
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the library's sources (file names + contents, sorted): compiled into the binary as FD_SOURCE_HASH and
+    reported by fd_version(), so that whoever loads the .so can tell whether it was built from the sources next to it."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    """The FD_SOURCE_HASH stamped into the library that is on disk now ("" if there is none / it is unstamped)."""
+    import re
+    try:
+        with open(OUT, "rb") as f:
+            m = re.search(rb"train step f32/bf16; sources ([0-9a-f]{16})\)", f.read())
+        return m.group(1).decode() if m else ""
+    except OSError:
+        return ""
+
+
 def _stale():
     if not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "_obj"] + [os.path.join(HERE, "..", "include", "fastdepth_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return built_hash() != source_hash()       # content, not mtimes: a checkout or a copy must neither force nor hide a rebuild
 
 
 def compile_and_link(out, extra=(), tag=""):
@@ -34,7 +59,7 @@ def compile_and_link(out, extra=(), tag=""):
     for src in SOURCES:
         obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC] + CFLAGS + list(extra) + ["-c", src, "-o", obj])))
+        procs.append((src, subprocess.Popen([HIPCC] + CFLAGS + ['-DFD_SOURCE_HASH="%s"' % source_hash()] + list(extra) + ["-c", src, "-o", obj])))
     failed = [src for src, p in procs if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
@@ -42,9 +67,16 @@ def compile_and_link(out, extra=(), tag=""):
     return out
 
 
+LAST_BUILD_MODE = ""
+
+
 def build(force=False, extra=()):
+    """Returns the library path; LAST_BUILD_MODE says what happened ("compiled" / "reused: stamp == source hash")."""
+    global LAST_BUILD_MODE
     if not force and not _stale():
+        LAST_BUILD_MODE = "reused (stamp %s == hash of the sources in the tree)" % built_hash()
         return OUT
+    LAST_BUILD_MODE = "compiled (sources %s)" % source_hash()
     return compile_and_link(OUT, extra)
 
 

@@ -39,7 +39,12 @@ extern "C" {
 void fd_tuning_next(uint32_t mask) { fd_hs().tune_next = mask; }
 
 const char *fd_last_error(void) { return fd_hs().err.c_str(); }
-const char *fd_version(void) { return "fastdepth_hip 0.3 (gfx950; inference f32/f16/bf16, train step f32/bf16)"; }
+// FD_SOURCE_HASH: the first 16 hex digits of the SHA-256 over csrc/ and include/fastdepth_hip.h that fast-depth_amd/build.py computed when it compiled THIS
+// binary (build.py's source_hash()); __graft_entry__.smoke() prints it next to the hash of the sources in the tree, so a reused library is visible
+#ifndef FD_SOURCE_HASH
+#define FD_SOURCE_HASH "unstamped"
+#endif
+const char *fd_version(void) { return "fastdepth_hip 0.5 (gfx950; inference f32/f16/bf16, train step f32/bf16; sources " FD_SOURCE_HASH ")"; }
 
 int fd_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t batch, int32_t height, int32_t width,
                    int32_t dtype, uint32_t flags, fd_plan **out_plan)

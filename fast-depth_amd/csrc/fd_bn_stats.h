@@ -20,34 +20,45 @@
 // ------------------------------------------------------------------------------------------------
 struct fd_bn_fin {
     const long long *rows;           // null: the table st1 was finalised by a launch of its own (fd_bn_finalize_rows_f32)
-    int nr;                          // statistics rows of the producer (power of two)
-    double n, n_unbiased;
+    int nr, cs;                      // statistics rows of the producer (power of two), their channel pitch
+    double n, n_unbiased, inv_n;     // pixels per channel, the count of the unbiased variance, 1 / n
     float eps, momentum;
     const float *gamma, *beta;
     float *run_mean, *run_var, *st;
     long long *nbt;
 };
-struct fd_bn_coef { double mean, var, invstd, scale; };
-// one channel's coefficients from its totals:  mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), scale = gamma * invstd
-__device__ __forceinline__ fd_bn_coef fd_bn_coef_of(double s, double q, double n, float eps, float g_c)
+struct fd_bn_coef { double mean, var; float invstd, scale; };
+// one channel's coefficients from its totals:  mean = S/n, var_b = Q/n - mean^2 (biased, used to normalise), scale = gamma * invstd.
+// Runs in the prologue of EVERY consumer workgroup, so it is written for few instructions: the cancellation-prone part (mean, variance) in double with
+// the reciprocal count from the host, 1 / sqrt(var + eps) as v_rsq_f32 + one Newton step (<= 1.2e-7 relative: the table is fp32 anyway).
+__device__ __forceinline__ float fd_rsqrt_nr(float x)
+{
+#ifdef FD_EMU
+    float y = 1.0f / sqrtf(x);
+#else
+    float y = __builtin_amdgcn_rsqf(x);
+#endif
+    return y * (1.5f - 0.5f * x * y * y);
+}
+__device__ __forceinline__ fd_bn_coef fd_bn_coef_of(double s, double q, double inv_n, float eps, float g_c)
 {
     fd_bn_coef k;
-    k.mean = s / n;
-    k.var = q / n - k.mean * k.mean;
+    k.mean = s * inv_n;
+    k.var = q * inv_n - k.mean * k.mean;
     if (k.var < 0.0) k.var = 0.0;
-    k.invstd = 1.0 / sqrt(k.var + (double)eps);
-    k.scale = (double)g_c * k.invstd;
+    k.invstd = fd_rsqrt_nr((float)(k.var + (double)eps));
+    k.scale = g_c * k.invstd;
     return k;
 }
-__device__ __forceinline__ float fd_bn_shift_of(const fd_bn_coef &k, float b_c) { return (float)((double)b_c - k.mean * k.scale); }
+__device__ __forceinline__ float fd_bn_shift_of(const fd_bn_coef &k, float b_c) { return (float)((double)b_c - k.mean * (double)k.scale); }
 // the finalising workgroup's side effects for channel c: the table [4][C], the running statistics (running_var takes var_b * n_u / (n_u - 1)),
 // num_batches_tracked (nn.BatchNorm2d: the owner of channel 0 counts the batch)
 __device__ __forceinline__ void fd_bn_publish(const fd_bn_fin &f, int C, int c, const fd_bn_coef &k, float b_c, float rm_c, float rv_c)
 {
-    f.st[FD_ST_SCALE * C + c] = (float)k.scale;
+    f.st[FD_ST_SCALE * C + c] = k.scale;
     f.st[FD_ST_SHIFT * C + c] = fd_bn_shift_of(k, b_c);
     f.st[FD_ST_MEAN * C + c] = (float)k.mean;
-    f.st[FD_ST_INVSTD * C + c] = (float)k.invstd;
+    f.st[FD_ST_INVSTD * C + c] = k.invstd;
     f.run_mean[c] = (float)((1.0 - f.momentum) * rm_c + f.momentum * k.mean);
     f.run_var[c] = (float)((1.0 - f.momentum) * rv_c + f.momentum * k.var * (f.n_unbiased / (f.n_unbiased - 1.0)));
     if (c == 0 && f.nbt) f.nbt[0] += 1;
@@ -64,16 +75,16 @@ __device__ __forceinline__ void fd_stat_table_block(const fd_bn_fin &f, double *
     if (rg == 0 && ok) { g_c = f.gamma[c]; b_c = f.beta[c]; if (writer) { rm_c = f.run_mean[c]; rv_c = f.run_var[c]; } }
     double s = 0.0, q = 0.0;
     if (ok && rg < f.nr) {
-        s = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, C, 0, c, rg, RG);
-        q = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, C, 1, c, rg, RG);
+        s = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, f.cs, 0, c, rg, RG);
+        q = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, f.cs, 1, c, rg, RG);
     }
     sh[2 * tid] = s; sh[2 * tid + 1] = q;
     __syncthreads();
     if (rg == 0) {
         s = 0.0; q = 0.0;
         for (int r = 0; r < RG; ++r) { s += sh[2 * (r * CB + ch)]; q += sh[2 * (r * CB + ch) + 1]; }
-        const fd_bn_coef k = fd_bn_coef_of(s, q, f.n, f.eps, g_c);
-        s_st[ch] = ok ? (float)k.scale : 0.0f; s_st[CB + ch] = ok ? fd_bn_shift_of(k, b_c) : 0.0f;
+        const fd_bn_coef k = fd_bn_coef_of(s, q, f.inv_n, f.eps, g_c);
+        s_st[ch] = ok ? k.scale : 0.0f; s_st[CB + ch] = ok ? fd_bn_shift_of(k, b_c) : 0.0f;
         if (writer && ok) fd_bn_publish(f, C, c, k, b_c, rm_c, rv_c);
     }
     __syncthreads();
@@ -84,29 +95,43 @@ __device__ __forceinline__ void fd_stat_table_block(const fd_bn_fin &f, double *
 template <int NT, typename PUT>
 __device__ __forceinline__ void fd_stat_table_all(const fd_bn_fin &f, int C, int Cpad, int tid, bool writer, PUT &&put)
 {
-    for (int c = tid; c < Cpad; c += NT) {
+    // two phases, so that the integer loads of ALL of this work-item's channels are in flight together (one channel at a time was a chain of
+    // dependent round trips: 8.6 us in front of a 1024-channel GEMM at batch 32)
+    constexpr int MAXQ = 1024 / NT;                          // Cpad <= 1024 (checked by the plans)
+    double s[MAXQ], q[MAXQ];
+    float g[MAXQ], b[MAXQ], rm[MAXQ], rv[MAXQ];
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int c = tid + NT * i;
+        s[i] = 0.0; q[i] = 0.0; g[i] = 0.0f; b[i] = 0.0f; rm[i] = 0.0f; rv[i] = 0.0f;
+        if (c < C) {                                         // (work-items beyond the channel count issue no loads: a 1-channel head must not read its rows 1024 times)
+            s[i] = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, f.cs, 0, c, 0, 1); q[i] = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, f.cs, 1, c, 0, 1);
+            g[i] = f.gamma[c]; b[i] = f.beta[c];
+            if (writer) { rm[i] = f.run_mean[c]; rv[i] = f.run_var[c]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int c = tid + NT * i;
+        if (c >= Cpad) continue;
         if (c >= C) { put(c, 0.0f, 0.0f); continue; }
-        const float g_c = f.gamma[c], b_c = f.beta[c];
-        float rm_c = 0.0f, rv_c = 0.0f;
-        if (writer) { rm_c = f.run_mean[c]; rv_c = f.run_var[c]; }
-        const double s = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, C, 0, c, 0, 1), q = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, C, 1, c, 0, 1);
-        const fd_bn_coef k = fd_bn_coef_of(s, q, f.n, f.eps, g_c);
-        put(c, (float)k.scale, fd_bn_shift_of(k, b_c));
-        if (writer) fd_bn_publish(f, C, c, k, b_c, rm_c, rv_c);
+        const fd_bn_coef k = fd_bn_coef_of(s[i], q[i], f.inv_n, f.eps, g[i]);
+        put(c, k.scale, fd_bn_shift_of(k, b[i]));
+        if (writer) fd_bn_publish(f, C, c, k, b[i], rm[i], rv[i]);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm finalisation as a launch of its own (where no consumer kernel does it: plans with FD_TUNE_NO_CONSUMER_FINALIZE, the head's 1-channel
-// statistics, unusual unit combinations): one work-item per channel, statistics rows -> table + running statistics.
+// statistics, units with many rows, unusual unit combinations): statistics rows -> table + running statistics.
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256)
 fd_bn_finalize_rows_f32(const fd_bn_fin f, int C)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float g_c = f.gamma[c], b_c = f.beta[c], rm_c = f.run_mean[c], rv_c = f.run_var[c];
-    const double s = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, C, 0, c, 0, 1), q = fd_stat_total<FD_STAT_FWD>(f.rows, f.nr, C, 1, c, 0, 1);
-    fd_bn_publish(f, C, c, fd_bn_coef_of(s, q, f.n, f.eps, g_c), b_c, rm_c, rv_c);
+    // 16 channels per workgroup, a channel's rows dealt to 16 work-items: one batch of loads whatever the row count (one work-item per channel walked
+    // 16 rows x 6 integers as a chain of dependent batches: 11 us per launch)
+    __shared__ double sh[512];
+    __shared__ float s_st[2 * 16];
+    fd_stat_table_block(f, sh, s_st, blockIdx.x * 16, 16, C, threadIdx.x, true);
 }
 

@@ -45,6 +45,7 @@ int fd_plan_export(const fd_plan *plan, void *host_buffer, size_t bytes, void *s
 
 int fd_plan_import(const void *host_buffer, size_t bytes, int32_t batch_override, fd_plan **out_plan)
 {
+    (void)fd_take_tuning();            // a deploy bundle runs the product's kernel selection: a tuning mask left in this thread's slot does not apply
     if (!host_buffer || !out_plan) return fail(FD_ERR_INVALID, "null argument");
     BundleHeader h{};
     if (bytes < sizeof h) return fail(FD_ERR_INVALID, "not a deploy bundle (too short)");

@@ -366,12 +366,13 @@ template <typename T> struct fd_lane<T, 8> {
 // One address takes an atomic every ~22 ns whatever the scope (tools/microbench/stat_atomics.hip, MI355X: 6272 workgroups x 128 columns into ONE row
 // 135 us, into 8 rows 18 us), so a unit's partials are dealt to nr rows (a power of two <= 16, chosen by the plan so that an address sees <= ~256
 // adds: row = workgroup number & (nr - 1)) and the consumer adds the nr x 3 integers of a column.
-// Layout of a unit's rows: int64 [nr][FD_STAT_BINS][2][C]  (2 = first / second sum).  The plan zeroes all rows of a step with one memset.
+// Layout of a unit's rows: int64 [nr][FD_STAT_BINS][2][cs]  (2 = first / second sum; cs = channel pitch >= C, a multiple of 16: the memory side
+// serialises atomics per 128-byte LINE and instruction, so no two (row, bin, sum) slots share a line).  The plan zeroes all rows of a step with one memset.
 #define FD_STAT_BINS 3
 #define FD_STAT_MAX_ROWS 16
 #define FD_STAT_FWD 0
 #define FD_STAT_BWD 1
-struct fd_stat_rows { long long *rows; int nr; };        // nr: power of two; rows == nullptr: no statistics wanted
+struct fd_stat_rows { long long *rows; int nr, cs; };    // nr: power of two; cs: channel pitch of the rows (>= C; >= 16 so that every [row][bin][sum] slot starts its own 128-byte line)
 #ifdef FD_EMU
 inline void fd_atomic_add_i64(long long *p, long long v) { *p += v; }
 #else
@@ -386,7 +387,7 @@ template <int DIR> struct fd_stat_fmt {
 };
 // adds the fp32 partial v of column c (sum `which`) of workgroup number blk to the unit's rows
 template <int DIR>
-__device__ __forceinline__ void fd_stat_add(const fd_stat_rows &d, long blk, int C, int which, int c, float v)
+__device__ __forceinline__ void fd_stat_add(const fd_stat_rows &d, long blk, int /*C*/, int which, int c, float v)
 {
     typedef fd_stat_fmt<DIR> F;
     const unsigned u = __builtin_bit_cast(unsigned, v);
@@ -400,11 +401,11 @@ __device__ __forceinline__ void fd_stat_add(const fd_stat_rows &d, long blk, int
     long long iv = sh >= 0 ? (m << sh) : (sh > -24 ? (m >> -sh) : 0);
     if (u >> 31) iv = -iv;
     if (iv == 0) return;
-    fd_atomic_add_i64(d.rows + ((((long)(blk & (d.nr - 1)) * FD_STAT_BINS + bin) * 2 + which) * C + c), iv);
+    fd_atomic_add_i64(d.rows + ((((long)(blk & (d.nr - 1)) * FD_STAT_BINS + bin) * 2 + which) * d.cs + c), iv);
 }
 // the exact total of column c (sum `which`) over the partials in rows r0, r0 + rstep, ... < nr (r0 = 0, rstep = 1: of the whole unit), as a double
 template <int DIR>
-__device__ __forceinline__ double fd_stat_total(const long long *__restrict__ rows, int nr, int C, int which, int c, int r0, int rstep)
+__device__ __forceinline__ double fd_stat_total(const long long *__restrict__ rows, int nr, int C /* channel pitch */, int which, int c, int r0, int rstep)
 {
     typedef fd_stat_fmt<DIR> F;
     long long a0 = 0, a1 = 0, a2 = 0;

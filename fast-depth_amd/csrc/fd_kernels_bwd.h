@@ -58,17 +58,17 @@ __device__ __forceinline__ fd_f32x8 fd_actmask4(fd_f32x8 y)
 // gradients and the table) or as a launch of its own (fd_bn_bwd_finalize_rows_f32: one work-item per channel).
 struct fd_bn_bwd_fin {
     const long long *rows;           // null: the table `coef` was finalised by its own launch
-    int nr;                          // statistics rows (power of two)
+    int nr, cs;                      // statistics rows (power of two), their channel pitch
     int cf_off;                      // byte offset of s_cf in the kernel's dynamic LDS (the plan appends it to the kernel's own request)
-    double n;
+    double inv_n;                    // 1 / (pixels per channel)
     const float *st;                 // the unit's forward table
     float *dgamma, *dbeta, *coef;
 };
 struct fd_bn_bwd_coef { float a, c1, mu, c2; };
-__device__ __forceinline__ fd_bn_bwd_coef fd_bn_bwd_coef_of(double s, double q, double n, float sc_c, float mean_c, float invstd_c)
+__device__ __forceinline__ fd_bn_bwd_coef fd_bn_bwd_coef_of(double s, double q, double inv_n, float sc_c, float mean_c, float invstd_c)
 {
     fd_bn_bwd_coef k;
-    k.a = sc_c; k.c1 = (float)(s / n); k.mu = mean_c; k.c2 = (float)((double)invstd_c * q / n);
+    k.a = sc_c; k.c1 = (float)(s * inv_n); k.mu = mean_c; k.c2 = (float)((double)invstd_c * q * inv_n);
     return k;
 }
 __device__ __forceinline__ void fd_bn_bwd_publish(const fd_bn_bwd_fin &f, int C, int c, double s, double q, const fd_bn_bwd_coef &k)
@@ -76,15 +76,6 @@ __device__ __forceinline__ void fd_bn_bwd_publish(const fd_bn_bwd_fin &f, int C,
     f.dbeta[c] = (float)s;
     f.dgamma[c] = (float)q;
     f.coef[FD_CF_A * C + c] = k.a; f.coef[FD_CF_C1 * C + c] = k.c1; f.coef[FD_CF_MU * C + c] = k.mu; f.coef[FD_CF_C2 * C + c] = k.c2;
-}
-static __global__ void __launch_bounds__(256)
-fd_bn_bwd_finalize_rows_f32(const fd_bn_bwd_fin f, int C)
-{
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float sc_c = f.st[FD_ST_SCALE * C + c], mean_c = f.st[FD_ST_MEAN * C + c], invstd_c = f.st[FD_ST_INVSTD * C + c];
-    const double s = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 0, c, 0, 1), q = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 1, c, 0, 1);
-    fd_bn_bwd_publish(f, C, c, s, q, fd_bn_bwd_coef_of(s, q, f.n, sc_c, mean_c, invstd_c));
 }
 // Channel-block form (the backward mirror of fd_stat_table_block, fd_kernels_train.h): 256 work-items, the CB <= 64 channels [c0, c0 + CB).
 // sh: >= 4 KiB of LDS that is dead until the next barrier; s_cf: [4][CB] floats (A, C1, MU, C2) that nothing else touches.
@@ -97,20 +88,28 @@ __device__ __forceinline__ void fd_bstat_table_block(const fd_bn_bwd_fin &f, dou
     if (rg == 0 && ok) { sc_c = f.st[FD_ST_SCALE * C + c]; mean_c = f.st[FD_ST_MEAN * C + c]; invstd_c = f.st[FD_ST_INVSTD * C + c]; }
     double s = 0.0, q = 0.0;
     if (ok && rg < f.nr) {
-        s = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 0, c, rg, RG);
-        q = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, C, 1, c, rg, RG);
+        s = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, f.cs, 0, c, rg, RG);
+        q = fd_stat_total<FD_STAT_BWD>(f.rows, f.nr, f.cs, 1, c, rg, RG);
     }
     sh[2 * tid] = s; sh[2 * tid + 1] = q;
     __syncthreads();
     if (rg == 0) {
         s = 0.0; q = 0.0;
         for (int r = 0; r < RG; ++r) { s += sh[2 * (r * CB + ch)]; q += sh[2 * (r * CB + ch) + 1]; }
-        fd_bn_bwd_coef k = fd_bn_bwd_coef_of(s, q, f.n, sc_c, mean_c, invstd_c);
+        fd_bn_bwd_coef k = fd_bn_bwd_coef_of(s, q, f.inv_n, sc_c, mean_c, invstd_c);
         if (!ok) { k.a = 0.0f; k.c1 = 0.0f; k.mu = 0.0f; k.c2 = 0.0f; }
         s_cf[FD_CF_A * CB + ch] = k.a; s_cf[FD_CF_C1 * CB + ch] = k.c1; s_cf[FD_CF_MU * CB + ch] = k.mu; s_cf[FD_CF_C2 * CB + ch] = k.c2;
         if (writer && ok) fd_bn_bwd_publish(f, C, c, s, q, k);
     }
     __syncthreads();
+}
+
+static __global__ void __launch_bounds__(256)
+fd_bn_bwd_finalize_rows_f32(const fd_bn_bwd_fin f, int C)
+{
+    __shared__ double sh[512];
+    __shared__ float s_cf[4 * 16];
+    fd_bstat_table_block(f, sh, s_cf, blockIdx.x * 16, 16, C, threadIdx.x, true);      // 16 channels per workgroup, a channel's rows dealt to 16 work-items
 }
 
 // ---- weight-gradient partials of a whole range of units, reduced by ONE launch at the end of the range (round 1: one launch per unit paired
@@ -352,11 +351,12 @@ fd_head_bwd_reduce_f32(const float *__restrict__ dpred, const float *__restrict_
                        float *__restrict__ g, fd_stat_rows sr, long npix, int h, int w, int up)
 {
     __shared__ float red[8];
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    // grid-stride over blocks of 256 low-resolution pixels (the plan bounds the grid: the head's ONE channel takes one addition per workgroup)
+    const float st_sc = st[FD_ST_SCALE], st_sh = st[FD_ST_SHIFT], st_mu = st[FD_ST_MEAN], st_is = st[FD_ST_INVSTD];
     float dy = 0.0f, dyx = 0.0f;
-    if (p < npix) {
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
         const float z = zlow[p];
-        const float y = z * st[FD_ST_SCALE] + st[FD_ST_SHIFT];
+        const float y = z * st_sc + st_sh;
         float d;
         if (up) {
             const int ox = (int)(p % w);
@@ -368,9 +368,10 @@ fd_head_bwd_reduce_f32(const float *__restrict__ dpred, const float *__restrict_
         } else {
             d = dpred[p];
         }
-        dy = d * fd_actmask<ACT>(y);
-        g[p] = dy;
-        dyx = dy * (z - st[FD_ST_MEAN]) * st[FD_ST_INVSTD];
+        const float gv = d * fd_actmask<ACT>(y);
+        g[p] = gv;
+        dy += gv;
+        dyx = fmaf(gv, (z - st_mu) * st_is, dyx);
     }
     for (int m = 1; m < 64; m <<= 1) { dy += __shfl_xor(dy, m); dyx += __shfl_xor(dyx, m); }
     if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = dy; red[(threadIdx.x >> 6) * 2 + 1] = dyx; }
@@ -911,13 +912,7 @@ fd_dw_dgrad_body(const T *__restrict__ G, const T *__restrict__ Z, const float *
         }
     }
     float *red = smem;
-    if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
-        const long blk = (long)bm.z * grid_x + bm.x;
-        if (c0 + tid * N < Cp) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) { fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 0, c0 + tid * N + j, ssum[j]); fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 1, c0 + tid * N + j, ssx[j]); }
-        }
-    }
+    fd_wg_stat_add<FD_STAT_BWD>(ssum, ssx, red, lanes_c, tid, sr, (long)bm.z * grid_x + bm.x, Cp, c0);
 }
 template <typename T, int K, int S, int MODE, int ACT_IN, int ADD_SG, int N>
 __global__ void __launch_bounds__(256)
@@ -1449,13 +1444,7 @@ fd_dw_bwd1_body(const T *__restrict__ G, const T *__restrict__ Z, const float *_
         }
     }
     float *red = smem;
-    if (fd_wg_sum_by_channel_group(ssum, ssx, red, lanes_c, tid)) {
-        const long blk = (long)bm.z * grid_x + bm.x;
-        if (c0 + tid * N < Cp) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) { fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 0, c0 + tid * N + j, ssum[j]); fd_stat_add<FD_STAT_BWD>(sr, blk, Cp, 1, c0 + tid * N + j, ssx[j]); }
-        }
-    }
+    fd_wg_stat_add<FD_STAT_BWD>(ssum, ssx, red, lanes_c, tid, sr, (long)bm.z * grid_x + bm.x, Cp, c0);
     // the pixel groups' tap sums meet in LDS: red[pg][ky*K + kx][c4] (fixed order -> deterministic); one partial row per tile
     __syncthreads();
     if (worker) {
@@ -1510,7 +1499,7 @@ fd_dw3s2_dgrad_rows(const T *__restrict__ G, const T *__restrict__ Z, const floa
                     const T *__restrict__ Zin, const float *__restrict__ st_in, const T *__restrict__ SG, T *__restrict__ Gin,
                     fd_stat_rows sr, int Hin, int Win, int Ho, int Wo, int C, int TH2)
 {
-    __shared__ float red[4 * 64 * 8];
+    __shared__ float red[4 * 64 * 8 + 2 * 256];             // wave sums + the workgroup's totals (fd_wg_stat_add)
     const int CG = C >> 2;
     const fd_blk3 blk = fd_xcd_image_map();
     const int tid = threadIdx.x;
@@ -1568,11 +1557,7 @@ fd_dw3s2_dgrad_rows(const T *__restrict__ G, const T *__restrict__ Z, const floa
         }
         dA = nA; dB = nB;
     }
-    if (fd_wg_sum_by_channel_group(ssum, ssx, red, CG, tid)) {
-        const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { fd_stat_add<FD_STAT_BWD>(sr, row, C, 0, tid * 4 + j, ssum[j]); fd_stat_add<FD_STAT_BWD>(sr, row, C, 1, tid * 4 + j, ssx[j]); }
-    }
+    fd_wg_stat_add<FD_STAT_BWD>(ssum, ssx, red, CG, tid, sr, ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x, C, 0);
 }
 
 // fd_dw3_wgrad_rows -- dW[c][ky][kx] = sum dz(oy, ox) a_in(S oy - 1 + ky, S ox - 1 + kx): a work-item is q = x_out * (C/4) + c4 and walks down TH

@@ -224,6 +224,27 @@ __device__ __forceinline__ bool fd_wg_sum_by_channel_group(V &a, V &b, float *re
     return true;
 }
 
+// The same sum, handed to the unit's statistics rows: the totals of the workgroup's CB = lanes_c * NV channels [c0, c0 + CB) go through LDS (red + 8 * CB
+// floats ... + 10 * CB) so that CONSECUTIVE lanes add CONSECUTIVE channels -- the memory side serialises atomics per 128-byte line and instruction
+// (~22 ns each, tools/microbench/stat_atomics.hip), so a wave instruction should cover whole lines: 2 * CB * 8 bytes in CB / 8 line operations instead of
+// one line operation per lane and channel (measured: the register-window kernels ran 2 - 4.5x longer with one atomic instruction per channel of a lane).
+template <int DIR, typename V>
+__device__ __forceinline__ void fd_wg_stat_add(V &a, V &b, float *red, int lanes_c, int tid, const fd_stat_rows &sr, long blk, int C, int c0)
+{
+    constexpr int NV = sizeof(V) / sizeof(float);
+    const int CB = lanes_c * NV;
+    float *tot = red + 8 * CB;                                // [2][CB], behind the 4 x lanes_c x 2 x NV floats of the wave sums
+    if (fd_wg_sum_by_channel_group(a, b, red, lanes_c, tid)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { tot[tid * NV + j] = a[j]; tot[CB + tid * NV + j] = b[j]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * CB; t += 256) {
+        const int which = t >= CB ? 1 : 0, ch = t - which * CB;
+        if (c0 + ch < C) fd_stat_add<DIR>(sr, blk, C, which, c0 + ch, tot[t]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Depthwise 3x3, stride S, train mode, register-window variant (fd_dw3_rows' design: no LDS staging, no barrier before the
 // statistics) for the large maps with a power-of-two channel-group count C/4 in 8 ... 64: a work-item is q = x * (C/4) + c4 (one
@@ -238,7 +259,7 @@ __global__ void __launch_bounds__(256)
 fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ w, T *__restrict__ zout,
                   fd_stat_rows sr, int H, int W, int Ho, int Wo, int C, int TH, fd_bn_fin fin)
 {
-    __shared__ float red[4 * 64 * 8];
+    __shared__ float red[4 * 64 * 8 + 2 * 256];              // wave sums + the workgroup's totals (fd_wg_stat_add)
     const int CG = C >> 2;                                   // a power of two, 8 <= CG <= 64 (plan)
     const fd_blk3 blk = fd_xcd_image_map();
     const int tid = threadIdx.x;
@@ -290,11 +311,7 @@ fd_dw3_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, cons
         if (S == 1) { r0l = r1l; r0c = r1c; r0r = r1r; r1l = r2l; r1c = r2c; r1r = r2r; }
         else { r0l = r2l; r0c = r2c; r0r = r2r; }
     }
-    if (fd_wg_sum_by_channel_group(ssum, ssq, red, CG, tid)) {
-        const long row = ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { fd_stat_add<FD_STAT_FWD>(sr, row, C, 0, tid * 4 + j, ssum[j]); fd_stat_add<FD_STAT_FWD>(sr, row, C, 1, tid * 4 + j, ssq[j]); }
-    }
+    fd_wg_stat_add<FD_STAT_FWD>(ssum, ssq, red, CG, tid, sr, ((long)n * gridDim.y + blk.y) * gridDim.x + blk.x, C, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,13 +456,7 @@ fd_dwconv_train(const T *__restrict__ zin, const float *__restrict__ st1, const 
     }
     // workgroup partial statistics: fixed-order sum over the pixel-threads that share a channel group
     FD_DW_PROBE_AT(3);
-    if (fd_wg_sum_by_channel_group(ssum, ssq, reinterpret_cast<float *>(smem_raw), lanes_c, tid)) {
-        const long blk = (long)bm.z * gridDim.x + bm.x;
-        if (c0 + tid * N < C) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) { fd_stat_add<FD_STAT_FWD>(sr, blk, C, 0, c0 + tid * N + j, ssum[j]); fd_stat_add<FD_STAT_FWD>(sr, blk, C, 1, c0 + tid * N + j, ssq[j]); }
-        }
-    }
+    fd_wg_stat_add<FD_STAT_FWD>(ssum, ssq, reinterpret_cast<float *>(smem_raw), lanes_c, tid, sr, (long)bm.z * gridDim.x + bm.x, C, c0);
     FD_DW_PROBE_AT(4);
     FD_DW_PROBE_AT(5);
 }
@@ -586,20 +597,23 @@ fd_head_train(const T *__restrict__ zin, const float *__restrict__ st1, const fl
         __syncthreads();
         tsc = s_tab; tsh = s_tab + FD_HEAD_FIN_MAX;
     }
-    const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    // a workgroup walks pixel groups of 32 (8 lanes per pixel) grid-stride: the plan bounds the grid, so that the head's ONE channel sees at most
+    // ~1024 additions to its statistics rows (12544 workgroups of 32 pixels each cost 47 us of serialised atomics at batch 32)
     const int l8 = threadIdx.x & 7;
-    float s = 0.0f;
-    if (g < npix) {
+    float v = 0.0f, sq = 0.0f;
+    for (long base = (long)blockIdx.x * 32; base < npix; base += (long)gridDim.x * 32) {      // (workgroup-uniform trip count: the shuffles below are wave-wide)
+        const long g = base + (threadIdx.x >> 3);
+        const bool live = g < npix;
+        const long gq = live ? g : npix - 1;
+        float s = 0.0f;
         for (int c = l8 * 4; c < Cin; c += 32) {
-            const fd_f32x4 a = fd_bn_act4<ACT1>(fd_ld4(zin + g * Cin + c), fd_ld4(tsc + c), fd_ld4(tsh + c));
+            const fd_f32x4 a = fd_bn_act4<ACT1>(fd_ld4(zin + gq * Cin + c), fd_ld4(tsc + c), fd_ld4(tsh + c));
             const fd_f32x4 q = fd_ld4(w + c);
             s = fmaf(a.x, q.x, s); s = fmaf(a.y, q.y, s); s = fmaf(a.z, q.z, s); s = fmaf(a.w, q.w, s);
         }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (live && l8 == 0) { zlow[g] = s; v += s; sq = fmaf(s, s, sq); }
     }
-    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-    float v = 0.0f;
-    if (g < npix && l8 == 0) { zlow[g] = s; v = s; }
-    float sq = v * v;
     for (int m = 8; m < 64; m <<= 1) { v += __shfl_xor(v, m); sq += __shfl_xor(sq, m); }   // lanes with l8 != 0 contribute 0
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[wave * 2] = v; red[wave * 2 + 1] = sq; }

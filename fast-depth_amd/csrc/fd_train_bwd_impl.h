@@ -55,13 +55,13 @@ inline size_t dw_bwd_lds(int ph, int pw, int cb, int k, int pstr, int le) { retu
 inline fd_bn_bwd_fin bwd_fin_args(BwdCtx &c, int i, size_t cf_off)
 {
     TLayer &L = c.p->layers[i];
-    return fd_bn_bwd_fin{stat_ptr(c.p, L.sb_off), L.nr_b, (int)cf_off, L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off)};
+    return fd_bn_bwd_fin{stat_ptr(c.p, L.sb_off), L.nr_b, stat_pitch(L.d.cout), (int)cf_off, 1.0 / L.n_stat, tws(c.p, L.st_off), c.grads[i].bn_weight, c.grads[i].bn_bias, tws(c.p, L.coef_off)};
 }
 int bn_bwd_finalize(BwdCtx &c, int i)
 {
     TLayer &L = c.p->layers[i];
     const fd_bn_bwd_fin fa = bwd_fin_args(c, i, 0);
-    FD_LAUNCH(fd_bn_bwd_finalize_rows_f32, dim3((unsigned)ceil_div(L.d.cout, 256)), dim3(256), 0, c.s, fa, L.d.cout);
+    FD_LAUNCH(fd_bn_bwd_finalize_rows_f32, dim3((unsigned)ceil_div(L.d.cout, 16)), dim3(256), 0, c.s, fa, L.d.cout);
     return check_launch("fd_bn_bwd_finalize_rows_f32");
 }
 // unit u's statistics rows are complete (its consumer's backward kernels have been launched): a capable first kernel of u finalises them itself
@@ -69,7 +69,7 @@ int bn_bwd_finalize(BwdCtx &c, int i)
 int finalize_or_defer(BwdCtx &c, int u)
 {
     TLayer &U = c.p->layers[u];
-    if (U.bwd_fin) { U.bwd_fin_rows = U.nr_b; return FD_OK; }
+    if (U.bwd_fin && U.nr_b <= FD_STAT_FIN_MAX_ROWS_BLOCK) { U.bwd_fin_rows = U.nr_b; return FD_OK; }     // (more rows: re-reading them in every workgroup costs more than the launch)
     U.bwd_fin_rows = 0;
     return bn_bwd_finalize(c, u);
 }
@@ -461,7 +461,7 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
                 if (hipMemsetAsync(plan->ws + plan->layers[i].sb_off, 0, stat_rows_bytes(plan->layers[i].nr_cap, plan->layers[i].d.cout), s) != hipSuccess) return fail(FD_ERR_HIP, "hipMemsetAsync(statistics rows) failed");
         }
         plan->bwd_stats_clean = false;
-        const int nb = ceil_div(Hd.M, 256);
+        const int nb = std::min(ceil_div(Hd.M, 256), 512);     // (grid-stride: one addition to the head's single statistics channel per workgroup)
         if (Hd.d.act == FD_ACT_RELU6) FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU6_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_rows(plan, hi, nb), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
         else FD_LAUNCH((fd_head_bwd_reduce_f32<FD_ACT_RELU_>), dim3(nb), dim3(256), 0, s, static_cast<const float *>(dy), tws(plan, Hd.z_off), tws(plan, Hd.st_off), tws(plan, Hd.g_off), bwd_rows(plan, hi, nb), Hd.M, Hd.out_h, Hd.out_w, Hd.d.upsample);
         if ((rc = check_launch("fd_head_bwd_reduce_f32"))) return rc;

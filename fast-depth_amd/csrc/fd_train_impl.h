@@ -82,7 +82,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
     auto fin_of = [&](int u) {
         const TLayer &U = plan->layers[u];
         const fd_layer_params &pq = params[u];
-        return fd_bn_fin{stat_ptr(plan, U.sf_off), U.nr_f, U.n_stat, U.n_unbiased, bn_eps, bn_momentum, pq.bn_weight, pq.bn_bias,
+        return fd_bn_fin{stat_ptr(plan, U.sf_off), U.nr_f, stat_pitch(U.d.cout), U.n_stat, U.n_unbiased, 1.0 / U.n_stat, bn_eps, bn_momentum, pq.bn_weight, pq.bn_bias,
                          const_cast<float *>(pq.bn_mean), const_cast<float *>(pq.bn_var), tws(plan, U.st_off), reinterpret_cast<long long *>(pq.bn_num_batches_tracked)};
     };
     for (int i = 0; i < n_layers; ++i)
@@ -158,7 +158,7 @@ int train_forward_t(fd_train_plan *plan, const fd_layer_params *params, int32_t 
         if (rc) return rc;
         if (L.fin_by_consumer) continue;
         const fd_bn_fin own = fin_of(i);
-        FD_LAUNCH(fd_bn_finalize_rows_f32, dim3((unsigned)ceil_div(d.cout, 256)), dim3(256), 0, s, own, d.cout);
+        FD_LAUNCH(fd_bn_finalize_rows_f32, dim3((unsigned)ceil_div(d.cout, 16)), dim3(256), 0, s, own, d.cout);
         if ((rc = check_launch("fd_bn_finalize_rows_f32"))) return rc;
     }
     const TLayer &Hd = plan->layers.back();
@@ -295,7 +295,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                     L.lds = 0;
                 }
             }
-            if (L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && !(L.rows_th && d.cin > 256)) {
+            if (L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && !(L.rows_th && d.cin > 256) &&
+                p->layers[d.src].nr_f <= (L.rows_th ? FD_STAT_FIN_MAX_ROWS_ALL : FD_STAT_FIN_MAX_ROWS_BLOCK)) {
                 // the producer's BatchNorm is finalised by this kernel's workgroups from the producer's statistics rows (fd_stat_table_block in the LDS-tiled
                 // kernel, which keeps the block's (scale, shift) behind its tap table; the register-window kernel holds all C <= 256 channels in its static LDS)
                 p->layers[d.src].fin_by_consumer = true;
@@ -318,12 +319,12 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.head = true;
                 L.out_h = d.upsample ? L.in_h / 2 : L.in_h;      // stored at the LOW resolution
                 L.out_w = d.upsample ? L.in_w / 2 : L.in_w;
-                L.grid = dim3(ceil_div((long)batch * L.out_h * L.out_w * 8, 256));
+                L.grid = dim3(std::min(ceil_div((long)batch * L.out_h * L.out_w * 8, 256), 512));     // (grid-stride: one addition to the head's single statistics channel per workgroup)
                 L.nblk = (int)L.grid.x;
                 L.wp_elems = (size_t)ceil_div((long)batch * L.out_h * L.out_w, 32 * 16) * d.cin;
                 if (!(tune & FD_TUNE_NO_CONSUMER_FINALIZE)) {
-                    if (d.cin <= FD_HEAD_FIN_MAX) p->layers[d.src].fin_by_consumer = true;     // its producer: finalised in fd_head_train
-                    L.fin_by_consumer = true;                                                   // the head's own 1-channel BatchNorm: in fd_head_apply_f32
+                    if (d.cin <= FD_HEAD_FIN_MAX && p->layers[d.src].nr_f <= FD_STAT_FIN_MAX_ROWS_ALL) p->layers[d.src].fin_by_consumer = true;     // its producer: finalised in fd_head_train
+                    L.fin_by_consumer = FD_STAT_MAX_ROWS <= FD_STAT_FIN_MAX_ROWS_ALL;            // the head's own 1-channel BatchNorm (all 16 rows: one line each) could run in fd_head_apply_f32; with that many rows it keeps its launch
                 }
             } else {
                 if (d.upsample || d.skip >= 0) FD_BAD("layer %d: pointwise after upsample only as the 1-channel head", i);
@@ -358,7 +359,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                     }
                 }
                 // the producer's BatchNorm is finalised by this GEMM's workgroups (fd_stat_table_all into the [2][K] table they keep in LDS anyway)
-                if (!(tune & FD_TUNE_NO_CONSUMER_FINALIZE)) p->layers[d.src].fin_by_consumer = true;
+                if (!(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && p->layers[d.src].nr_f <= FD_STAT_FIN_MAX_ROWS_ALL) p->layers[d.src].fin_by_consumer = true;
                 {   // weight-gradient partials: splits x N x K (same split rule as launch_pw_bwd)
                     const int nt = ceil_div(d.cout, 64), kt = ceil_div(d.cin, 64);
                     int splits = std::max(1, std::min(ceil_div(h16 ? FD_WGRAD_TARGET_WGS_H16 : FD_WGRAD_TARGET_WGS_F32, (long)nt * kt), ceil_div(M, 256)));
@@ -388,8 +389,8 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.coef_off = off; off += align_up((size_t)4 * d.cout * 4, 256);
         // statistics rows: reserved for the row count a producer of M / 64 workgroups per channel would take (the pointwise GEMMs' 64-row tiles: no kernel
         // of either direction has more workgroups per channel), used with the count the actual producer's workgroup number asks for
-        L.nr_cap = stat_nr(ceil_div(L.M, 64));
-        L.nr_f = std::min(L.nr_cap, stat_nr(L.nblk));
+        L.nr_cap = L.head ? FD_STAT_MAX_ROWS : stat_nr(ceil_div(L.M, 64));       // (the head's single channel: one line per row, 512 workgroups)
+        L.nr_f = L.head ? L.nr_cap : std::min(L.nr_cap, stat_nr(L.nblk));
         max_g = std::max(max_g, L.z_elems);
         L.wp_off = off; off += align_up(std::max(L.wp_elems, (size_t)1) * 4, 256);
     }

@@ -44,9 +44,9 @@
 #endif
 #define FD_WGRAD_TARGET_WGS_H16 (FD_WGRAD_TUNE_H16)
 
-namespace {
-
-struct TLayer {
+// (a global name, not the anonymous namespace: fd_train_plan below has external linkage and both train translation units must see ONE class type --
+// an anonymous-namespace member type makes the two definitions of fd_train_plan different classes, an ODR violation)
+struct fd_train_layer {
     fd_layer_desc d;
     int in_h = 0, in_w = 0, out_h = 0, out_w = 0;   // in_* = logical (post-upsample) input size; head: out_* = LOW-res size when upsample
     bool head = false;
@@ -87,8 +87,7 @@ struct TLayer {
     size_t wp_off = 0, wp_elems = 0; // this unit's weight-gradient partial rows (reduced by one launch per backward range)
     int k64 = 0, n64 = 0;
 };
-
-}  // namespace
+typedef fd_train_layer TLayer;
 
 struct fd_train_plan {
     std::vector<TLayer> layers;
@@ -112,7 +111,15 @@ template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reint
 // tools/microbench/stat_atomics.hip), so an address should see at most ~FD_STAT_ADDS_PER_ROW of them during the producer's life; a power of two
 // <= FD_STAT_MAX_ROWS (the consumer adds nr x 3 integers per channel and sum).
 #ifndef FD_STAT_ADDS_PER_ROW
-#define FD_STAT_ADDS_PER_ROW 256
+#define FD_STAT_ADDS_PER_ROW 128
+#endif
+// A consumer (or the unit's own first backward kernel) finalises a BatchNorm in its prologue only when the rows are few: every workgroup reads
+// nr x 3 bins x 2 sums of 8 bytes per channel.  ALL: kernels whose work-items each finalise whole channels (pointwise GEMMs, the register-window and head
+// kernels); BLOCK: kernels that deal a channel's rows to 256 / CB work-items (LDS-tiled depthwise kernels, the 16-bit apply pass).  Units with more rows
+// -- the large maps, whose kernels run 20 ... 160 us -- keep a finalisation launch of their own (fd_bn_finalize_rows_f32: 4 us).
+#ifndef FD_STAT_FIN_MAX_ROWS_ALL
+#define FD_STAT_FIN_MAX_ROWS_ALL 2
+#define FD_STAT_FIN_MAX_ROWS_BLOCK 8
 #endif
 inline int stat_nr(long nblk)
 {
@@ -120,16 +127,17 @@ inline int stat_nr(long nblk)
     while (nr < FD_STAT_MAX_ROWS && (long)nr * FD_STAT_ADDS_PER_ROW < nblk) nr *= 2;
     return nr;
 }
-inline size_t stat_rows_bytes(int nr, int C) { return (size_t)nr * FD_STAT_BINS * 2 * C * sizeof(long long); }
+inline int stat_pitch(int C) { return (C + 15) / 16 * 16; }      // channel pitch of a unit's rows: every [row][bin][sum] slot starts its own 128-byte line
+inline size_t stat_rows_bytes(int nr, int C) { return (size_t)nr * FD_STAT_BINS * 2 * stat_pitch(C) * sizeof(long long); }
 inline long long *stat_ptr(fd_train_plan *p, size_t off) { return reinterpret_cast<long long *>(p->ws + off); }
 // this unit's forward rows as its producer kernel sees them
-inline fd_stat_rows fwd_rows(fd_train_plan *p, const TLayer &L) { return fd_stat_rows{stat_ptr(p, L.sf_off), L.nr_f}; }
+inline fd_stat_rows fwd_rows(fd_train_plan *p, const TLayer &L) { return fd_stat_rows{stat_ptr(p, L.sf_off), L.nr_f, stat_pitch(L.d.cout)}; }
 // unit u's backward rows as the backward-data kernel of its consumer (nblk workgroups per channel) sees them; remembers the row count for u's finalisation
 inline fd_stat_rows bwd_rows(fd_train_plan *p, int u, long nblk)
 {
     const TLayer &U = p->layers[u];
-    U.nr_b = std::min(U.nr_cap, stat_nr(nblk));
-    return fd_stat_rows{stat_ptr(p, U.sb_off), U.nr_b};
+    U.nr_b = U.head ? U.nr_cap : std::min(U.nr_cap, stat_nr(nblk));      // (the head's single channel: every row is a line of its own -- all of them)
+    return fd_stat_rows{stat_ptr(p, U.sb_off), U.nr_b, stat_pitch(U.d.cout)};
 }
 
 // calls fn(fd_int<4>) or -- 16-bit storage types only -- fn(fd_int<8>): the lane width (fd_lane) of the LDS-tiled depthwise kernels

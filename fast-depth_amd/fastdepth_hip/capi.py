@@ -55,8 +55,7 @@ def create_plan(lib, train, descs, n, batch, height, width, fd_dtype, flags, han
     """fd_plan_create / fd_train_plan_create with a combined flags integer: the low 32 bits are the public plan flags, the bits above
     are the private tuning mask (FD_TUNE_*), passed through fd_tuning_next -- which only this thread's next creation consumes."""
     tuning = int(flags) >> _TUNE_SHIFT
-    if tuning:
-        lib.fd_tuning_next(tuning)
+    lib.fd_tuning_next(tuning)         # always, 0 included: a mask an earlier caller left in this thread's slot must not reach an unrelated plan
     fn = lib.fd_train_plan_create if train else lib.fd_plan_create
     return fn(descs, n, batch, height, width, fd_dtype, int(flags) & 0xFFFFFFFF, handle_ref)
 

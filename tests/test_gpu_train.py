@@ -255,13 +255,13 @@ def _product_plan_gradients(m, x, tgt, dtype, flags=0, trace=None):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_in_kernel_batchnorm_finalisations_batch32(dtype):
-    """Round 5: every unit's forward kernel ADDS its BatchNorm partial sums into the unit's statistics rows (64-bit integer atomics, fd_stat_add) and the
-    CONSUMER's workgroups derive (scale, shift) from them in their prologue -- no forward finalisation launch is left (38 fewer); in the bf16 plan the
-    BatchNorm backward of every pointwise unit is finalised inside its apply pass (fd_bn_bwd_apply_fin_h16: 18 launches fewer).  Asserted: the launch
-    census of both plans, and that the step computes what the plan with every finalisation as its own launch (FD_TUNE_NO_CONSUMER_FINALIZE) computes:
-    both read the same integers; a consumer that deals a channel's rows to several work-items adds their doubles in a different order, so the tables
-    agree to the last float bit or the one next to it -- prediction to 1e-4 (fp32) / 2e-2 (bf16: re-rounding noise) of its scale, the 114 gradient
-    tensors to 1e-2 / 1e-1 in norm."""
+    """Round 5: every unit's kernels ADD their BatchNorm partial sums into the unit's statistics rows (64-bit integer atomics, fd_stat_add); where those rows are
+    few (the maps up to 28 x 28 at batch 32: <= 2 rows for a pointwise / register-window / head consumer, <= 8 for an LDS-tiled depthwise consumer or the
+    16-bit apply pass) the CONSUMER's workgroups derive their coefficients from them in their prologue and no finalisation launch exists: 25 of the 38 forward
+    finalisations and, in the bf16 plan, the backward finalisations of the pointwise units on those maps.  Asserted: the launch census of both plans, and that
+    the step computes what the plan with every finalisation as its own launch (FD_TUNE_NO_CONSUMER_FINALIZE) computes: both read the same integers; a consumer
+    that deals a channel's rows to several work-items adds their doubles in a different order, so the tables agree to the last float bit or the one next to
+    it -- prediction to 1e-4 (fp32) / 2e-2 (bf16: re-rounding noise) of its scale, the 114 gradient tensors to 1e-2 / 1e-1 in norm."""
     from fastdepth_hip import capi
     m = _model(seed=25)
     x, tgt = _batch(32, seed=10)
@@ -271,12 +271,14 @@ def test_in_kernel_batchnorm_finalisations_batch32(dtype):
     count = lambda ns, key: sum(1 for k in ns if key in k)
     fwd_sep, bwd_sep = count(names_sep, "fd_bn_finalize_rows_f32"), count(names_sep, "fd_bn_bwd_finalize_rows_f32")
     assert fwd_sep == 38 and bwd_sep == 38 and count(names_sep, "apply_fin") == 0
-    assert count(names, "fd_bn_finalize_rows_f32") == 0
+    # forward: the stem, conv1 ... conv3, conv4.0, decode_conv4, decode_conv5 and the head keep a launch (8 ... 16 statistics rows each)
+    assert 10 <= count(names, "fd_bn_finalize_rows_f32") <= 13
     if dtype == torch.bfloat16:
-        assert count(names, "fd_bn_bwd_apply_fin_h16") == 18 and count(names, "fd_bn_bwd_apply_h16") == 0
-        assert count(names, "fd_bn_bwd_finalize_rows_f32") == 20 and len(names) == len(names_sep) - 38 - 18
+        fin = count(names, "fd_bn_bwd_apply_fin_h16")
+        assert fin >= 12 and fin + count(names, "fd_bn_bwd_apply_h16") == 18 and count(names, "fd_bn_bwd_finalize_rows_f32") == 38 - fin
+        assert len(names) == len(names_sep) - (38 - count(names, "fd_bn_finalize_rows_f32")) - fin
     else:
-        assert count(names, "fd_bn_bwd_finalize_rows_f32") == 38 and len(names) == len(names_sep) - 38
+        assert count(names, "fd_bn_bwd_finalize_rows_f32") == 38 and len(names) == len(names_sep) - (38 - count(names, "fd_bn_finalize_rows_f32"))
         assert count(names, "fd_pw_gemm16_f32") == 9 and count(names_sep, "fd_pw_gemm16_f32") == 9      # conv6.3 ... conv13.3, decode_conv1.1: the fp32 forward GEMMs in train mode
     # (a last-bit difference in ten tables, carried through a train-mode network that amplifies perturbations ~300x and whose ReLU masks can flip:
     # the rigorous statement about these kernels is the layer-local test above, which runs the same default plan)
