@@ -7,7 +7,9 @@ tag, rnd = sys.argv[1], sys.argv[2]
 src, dst = os.path.join("gpurun_out", tag), os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 for name, out in (("profile_summary.txt", "profile_summary.txt"), ("profile_summary.json", "profile_summary.json"),
-                  ("bench.json", "bench_n1.json"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log")):
+                  ("bench.json", "bench_n1.json"), ("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("bf16_grad_probe.txt", "bf16_grad_probe.txt"),
+                  ("bench_driver_protocol_1.json", "bench_driver_protocol_1.json"), ("bench_driver_protocol_2.json", "bench_driver_protocol_2.json"),
+                  ("bench_driver_protocol_3.json", "bench_driver_protocol_3.json")):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, out))
