@@ -203,6 +203,29 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
         assert harness.LAST_SAT6_FRAC > 0.005, harness.LAST_SAT6_FRAC
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_statistics_rows_cover_large_and_small_magnitudes(dtype):
+    """The BatchNorm statistics rows place every fp32 partial sum exactly into one of three integer accumulators chosen by its binary exponent
+    (csrc/fd_device.h: fd_stat_add; forward bins below 2^-8 / below 2^16 / above, backward below 2^-32 / below 2^-8 / above).  Conv weights scaled by
+    1e3 resp. 1e-3 (train-mode BatchNorm removes the scale from everything downstream, and divides that unit's weight gradient by it) push the sums of
+    z, z^2 of alternating units into the highest and the lowest forward bin, and their gradients' sums across the backward bins; the layer-local fp64
+    check must hold exactly as for the unscaled model."""
+    m = small_model(TINY[0], TINY[1], seed=3)
+    # (only units whose maps hold >= 128 values per channel at this test size: with the 8 values per channel of the 2 x 2 maps and no eps to hide
+    # behind -- var >> eps once z is scaled by 1e3 -- the single-pass variance E[z^2] - mean^2 of ANY fp32 implementation loses digits in channels whose
+    # |mean| >> std; that is a property of the small test geometry, not of the accumulation under test)
+    scaled = [n for n, mod in m.named_modules() if isinstance(mod, torch.nn.Conv2d) and n.split(".")[0] in ("conv0", "conv1", "conv2", "conv3", "decode_conv4", "decode_conv5")]
+    assert len(scaled) == 11
+    for k, n in enumerate(scaled):
+        dict(m.named_modules())[n].weight.data.mul_(1e3 if k % 2 == 0 else 1e-3)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    target = 2.0 + torch.rand(2, 1, 64, 64, generator=g)
+    rep = harness.local_train_parity("emu", m, x, target, torch.device("cpu"), dtype=dtype)
+    assert_local_parity(rep, dtype)
+
+
+
 def test_train_plan_dtype_rules():
     m = small_model(TINY[0], TINY[1], seed=1)
     x = torch.rand(1, 3, 64, 64)
