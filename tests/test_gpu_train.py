@@ -398,3 +398,62 @@ def test_library_issued_rccl_exchange_one_rank():
             e.close()
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out, bf16):
+    """One rank of the 2-GPU exchange test: the library-issued route and the torch.distributed route, two steps each on this rank's shard."""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    torch.zeros(1, device=dev)                               # (the compute queue exists before RCCL creates its own: bench.py does the same)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from fastdepth_hip.train import TrainEngine
+        x, tgt = _batch(4, seed=3)
+        base = _model(seed=7)
+        per = x.shape[0] // world
+        xs, ts = x[rank * per:(rank + 1) * per].to(dev), tgt[rank * per:(rank + 1) * per].to(dev)
+        res = {}
+        for route in ("library", "torch"):
+            m = copy.deepcopy(base).to(dev).train()
+            eng = TrainEngine(m, lr=0.01, momentum=0.9, weight_decay=1e-4, process_group=dist.group.WORLD, exchange=route,
+                              grad_exchange_dtype=torch.bfloat16 if bf16 else torch.float32)
+            assert eng.use_comm and (eng.comm is not None) == (route == "library")
+            losses = [float(eng.step(xs, ts)) for _ in range(2)]
+            res[route] = {"state": {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, "grad": eng.flat_grad.cpu().clone(), "losses": losses}
+            eng.close()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the 1-GPU boxes run the one-rank test above and the world-2 CPU test of tests/test_dp_gloo.py)")
+@pytest.mark.parametrize("bf16", [False, True])
+def test_library_issued_rccl_exchange_two_ranks(tmp_path, bf16):
+    """fd_train_backward_allreduce with REAL peers -- two ranks over RCCL, library route vs torch.distributed route on the same shards (bucket
+    slices, the bf16 cast -> sum -> cast back on the communicator's stream, the 1 / world mean, the device-scope event hand-over with peer writes): every
+    rank's parameters and all-reduced gradients agree between the routes (a two-rank sum is commutative: bit for bit in fp32; the bf16 exchange within one
+    bf16 rounding of the vector's scale, should RCCL's reduction order differ) and across ranks, and with a single-process step on the averaged gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "two_rank.pt")
+    mp.spawn(_two_rank_worker, args=(2, port, out, bf16), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    keys = [k for k, _ in _model(seed=7).named_parameters()]
+    for rank in range(2):
+        lib, ref = r[rank]["library"], r[rank]["torch"]
+        assert lib["losses"][0] == ref["losses"][0]                     # the first forward does not depend on the exchange
+        scale = float(ref["grad"].abs().max())
+        assert float((lib["grad"] - ref["grad"]).abs().max()) <= (2.0 ** -7 if bf16 else 1e-6) * scale
+        for k in keys:
+            assert torch.allclose(lib["state"][k], ref["state"][k], rtol=0, atol=(2.0 ** -7 if bf16 else 1e-6) * 0.01 * scale + 1e-7), k
+    assert torch.equal(r[0]["library"]["grad"], r[1]["library"]["grad"])
+    for k in keys:
+        assert torch.equal(r[0]["library"]["state"][k], r[1]["library"]["state"][k]), k
