@@ -348,6 +348,66 @@ template <typename T> struct fd_lane<T, 8> {
     static __device__ __forceinline__ vec lds_round(vec v) { return cvt(fd_pack8v(T{}, v)); }
 };
 
+// ---- pixel-pair arithmetic of the 16-bit 5x5 kernels (fd_kernels_dw5p.h) ---------------------------------------------------------------
+// A "pair" is one 32-bit word holding the SAME channel of two horizontally adjacent pixels (low half = the even pixel) in the storage type.
+// Depthwise taps then run on v_dot2_f32_{f16,bf16}: two 16-bit multiply-accumulates into an fp32 accumulator per VALU slot with no conversion
+// instructions (tools/microbench/valu_rates.hip: the same 3 shader cycles as one v_pk_fma_f32), against 16-bit taps packed the same way.
+#ifdef FD_EMU
+// v_perm_b32: result byte k = byte sel[k] of the 8 bytes {s0 (bytes 4-7), s1 (bytes 0-3)}
+inline unsigned fd_perm(unsigned s0, unsigned s1, unsigned sel)
+{
+    const unsigned long long cat = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) r |= (unsigned)((cat >> (8 * ((sel >> (8 * k)) & 7u))) & 0xffu) << (8 * k);
+    return r;
+}
+inline float fd_h16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+inline float fd_dot2(fd_half, unsigned a, unsigned b, float c)
+{
+    return (float)((double)fd_h16_bits_to_f32((unsigned short)a) * fd_h16_bits_to_f32((unsigned short)b) +
+                   (double)fd_h16_bits_to_f32((unsigned short)(a >> 16)) * fd_h16_bits_to_f32((unsigned short)(b >> 16)) + (double)c);
+}
+inline float fd_dot2(fd_bf16, unsigned a, unsigned b, float c)
+{
+    return (float)((double)fd_bf16_to_f32((unsigned short)a) * fd_bf16_to_f32((unsigned short)b) +
+                   (double)fd_bf16_to_f32((unsigned short)(a >> 16)) * fd_bf16_to_f32((unsigned short)(b >> 16)) + (double)c);
+}
+#else
+__device__ __forceinline__ unsigned fd_perm(unsigned s0, unsigned s1, unsigned sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+__device__ __forceinline__ float fd_dot2(fd_half, unsigned a, unsigned b, float c)
+{
+    typedef _Float16 fd_h2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(fd_h2_hw, a), __builtin_bit_cast(fd_h2_hw, b), c, false);
+}
+__device__ __forceinline__ float fd_dot2(fd_bf16, unsigned a, unsigned b, float c)
+{
+    typedef __bf16 fd_b2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fd_b2_hw, a), __builtin_bit_cast(fd_b2_hw, b), c, false);
+}
+#endif
+#define FD_PERM_LO 0x05040100u     /* fd_perm(b, a, FD_PERM_LO) = (low half of a, low half of b) */
+#define FD_PERM_HI 0x07060302u     /* fd_perm(b, a, FD_PERM_HI) = (high half of a, high half of b) */
+// two fp32 values -> one word of the storage type (low half = a), round to nearest even
+__device__ __forceinline__ unsigned fd_pack2(fd_half, float a, float b)
+{
+    typedef _Float16 fd_h2_ __attribute__((ext_vector_type(2)));
+    const fd_h2_ h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ unsigned fd_pack2(fd_bf16, float a, float b) { return fd_f32x2_to_bf16x2(a, b); }
+// element-wise sum of two words of the storage type, rounded to the storage type (fp16: one v_pk_add_f16 -- the sum of two fp16 values is exact
+// in fp32, so this is "convert, add in fp32, round"; bf16: that sequence spelled out)
+__device__ __forceinline__ unsigned fd_pair_sum(fd_half, unsigned a, unsigned b)
+{
+    typedef _Float16 fd_h2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(fd_h2_, a) + __builtin_bit_cast(fd_h2_, b));
+}
+__device__ __forceinline__ unsigned fd_pair_sum(fd_bf16, unsigned a, unsigned b)
+{
+    return fd_f32x2_to_bf16x2(__builtin_bit_cast(float, a << 16) + __builtin_bit_cast(float, b << 16),
+                              __builtin_bit_cast(float, a & 0xffff0000u) + __builtin_bit_cast(float, b & 0xffff0000u));
+}
+
 // ---- BatchNorm statistics rows (round 5): order-independent, bit-reproducible accumulation of per-workgroup partial sums ----------
 // The train step's BatchNorm reductions -- forward (sum z, sum z^2), backward (sum G, sum G*xhat) -- used to be "one fp32 partial row per
 // workgroup -> a finalisation launch that sums 25 ... 6272 rows -> a table": 76 launches at the per-launch floor per step.  Now every
