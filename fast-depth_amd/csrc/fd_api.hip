@@ -10,6 +10,7 @@
 #include "fd_kernels_h16.h"
 #include "fd_kernels_gemm16_h16.h"
 #include "fd_kernels_dwpw_f32.h"
+#include "fd_kernels_dw5p.h"
 #include "../../include/fastdepth_hip.h"
 #include "fd_tuning.h"
 
@@ -112,6 +113,14 @@ int fd_plan_pack_weights(fd_plan *plan, const fd_layer_params *params, int32_t n
                                reinterpret_cast<float *>(plan->ws + L.w_off), bptr, L.d.cout, inner, transpose, pitch);
         int rc = check_launch("fd_pack_fold");
         if (rc) return rc;
+        if (L.dw5_cl) {                                      // the row-walking 5x5 kernel reads its folded taps as 16-bit pairs
+            const float *wf = reinterpret_cast<const float *>(plan->ws + L.w_off);
+            unsigned *wpk = reinterpret_cast<unsigned *>(plan->ws + L.wpk_off);
+            if (plan->dtype == FD_F16) hipLaunchKernelGGL((fd_pack_dw5_pairs<fd_half>), dim3(ceil_div(30L * L.d.cin, 256)), dim3(256), 0, s, wf, wpk, L.d.cin);
+            else hipLaunchKernelGGL((fd_pack_dw5_pairs<fd_bf16>), dim3(ceil_div(30L * L.d.cin, 256)), dim3(256), 0, s, wf, wpk, L.d.cin);
+            rc = check_launch("fd_pack_dw5_pairs");
+            if (rc) return rc;
+        }
     }
     plan->packed = true;
     return FD_OK;

@@ -20,6 +20,9 @@ template <int N> inline void fd_wait_vmcnt() {}
 #define FD_SCHED_FENCE() ((void)0)
 #define FD_UNIFORM(x) (x)
 #define FD_OPAQUE(x) ((void)0)
+#define FD_SCALAR_PTR(p) ((void)0)
+template <typename P> inline P *fd_uniform_ptr(P *p) { return p; }
+inline void fd_store_u32_sbase(char *base, unsigned off, unsigned v) { memcpy(base + off, &v, 4); }
 inline void fd_block_barrier_lds() { __syncthreads(); }
 inline void fd_block_barrier() { __syncthreads(); }
 inline void fd_wave_lds_fence() { __syncthreads(); }         // the emulator runs a wave's lanes one after the other: a full barrier keeps them in step
@@ -38,12 +41,39 @@ template <int N> __device__ __forceinline__ void fd_wait_vmcnt() { asm volatile(
 // makes the compiler forget what it knows about the integer x: loads addressed through it are not hoisted out of the enclosing loop
 // (used to keep per-channel tables out of registers while they are not needed)
 #define FD_OPAQUE(x) asm volatile("" : "+v"(x))
+// the (wave-uniform) pointer p stays a scalar-register pair the compiler cannot fold lane offsets into: accesses p + (32-bit lane offset) keep the
+// "scalar base + vector offset" addressing form instead of a 64-bit address per lane
+#define FD_SCALAR_PTR(p) asm volatile("" : "+s"(p))
+// 4-byte store to (wave-uniform 64-bit base) + (32-bit lane offset): global_store_dword v_off, v_data, s[base] -- spelled out because the compiler
+// re-associates "uniform row base + lane offset" into one 64-bit address per lane and store (v_lshl_add_u64 chains in the tap kernels' epilogues)
+__device__ __forceinline__ void fd_store_u32_sbase(char *base, unsigned off, unsigned v)
+{
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+// a pointer the caller knows to be wave-uniform, moved into scalar registers (v_readfirstlane of both halves)
+template <typename P> __device__ __forceinline__ P *fd_uniform_ptr(P *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<P *>(((unsigned long long)hi << 32) | lo);
+}
 // a wave's own LDS writes have completed before its following LDS reads are issued (wave-private LDS tiles need no workgroup barrier)
 __device__ __forceinline__ void fd_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // raw s_barrier: unlike __syncthreads() it does not drain vmcnt, so LDS-DMA loads stay in flight across it
 __device__ __forceinline__ void fd_block_barrier() { __builtin_amdgcn_s_barrier(); }
 // the same, after this wave's own LDS writes/reads have completed (lgkmcnt) -- still without draining vector-memory loads
 __device__ __forceinline__ void fd_block_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#endif
+
+// Wave-private LDS / LDS-DMA hand-over inside ONE wave (kernels whose waves share nothing and run different trip counts: no workgroup barrier may be
+// used).  Hardware: the wave's own LDS operations (fd_wave_fence) / vector-memory operations incl. LDS-DMA (fd_wave_dma_wait) have completed.
+// Emulator: a wave-collective rendezvous (its lanes run one after the other; every lane must have issued its part before any lane reads it).
+#ifdef FD_EMU
+inline void fd_wave_fence() { (void)__shfl(0.0f, 0); }
+inline void fd_wave_dma_wait() { (void)__shfl(0.0f, 0); }
+#else
+__device__ __forceinline__ void fd_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void fd_wave_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
 // XCD-aware placement of a (tiles, channel blocks, images) grid: workgroup number b (x fastest) runs on XCD b % 8 and every XCD has its
@@ -108,6 +138,19 @@ __device__ __forceinline__ float fd_act(float v)
     if (ACT == FD_ACT_RELU6_) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);     // one v_med3_f32 (same value for every non-NaN input)
 #endif
     return v;
+}
+// the same on a value that comes out of inline asm (fd_dot2_acc): fmaxf / fmed3 would first canonicalise it (a second v_max_f32 per value)
+template <int ACT>
+__device__ __forceinline__ float fd_act_raw(float v)
+{
+#ifdef FD_EMU
+    return fd_act<ACT>(v);
+#else
+    float r = v;
+    if (ACT == FD_ACT_RELU_) asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    if (ACT == FD_ACT_RELU6_) { const float six = 6.0f; asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(six)); }
+    return r;
+#endif
 }
 template <int ACT>
 __device__ __forceinline__ fd_f32x4 fd_act4(fd_f32x4 v)
@@ -348,6 +391,31 @@ template <typename T> struct fd_lane<T, 8> {
     static __device__ __forceinline__ vec lds_round(vec v) { return cvt(fd_pack8v(T{}, v)); }
 };
 
+// ---- raw buffer access: (128-bit resource = base + byte count) + 32-bit lane offset + scalar offset ----------------------------------------------
+// buffer_load_dword v, v_off, s[rsrc], s_off offen: the addressing form the row-walking kernels want (a lane holds a few 32-bit offsets for its whole
+// band, everything that changes per row is scalar), and the hardware's range check does the horizontal zero padding: a lane offset >= the byte count
+// (FD_BUF_OOB) reads 0 and drops stores.  (Plain pointers were tried first: the compiler re-associates "uniform row base + lane offset" into a
+// 64-bit address per lane and access -- 170 v_lshl_add_u64 per 5 rows and twice the offset registers.)
+#define FD_BUF_OOB 0x80000000u
+#ifdef FD_EMU
+struct fd_bufrsrc { char *base; unsigned bytes; };
+inline fd_bufrsrc fd_make_rsrc(const void *p, unsigned bytes) { fd_bufrsrc r = {const_cast<char *>(static_cast<const char *>(p)), bytes}; return r; }
+inline unsigned fd_buf_ld32(fd_bufrsrc r, unsigned voff, unsigned soff)
+{
+    if (voff >= r.bytes || (unsigned long long)voff + soff + 4 > r.bytes) return 0u;
+    unsigned v; memcpy(&v, r.base + voff + soff, 4); return v;
+}
+inline void fd_buf_st32(fd_bufrsrc r, unsigned voff, unsigned soff, unsigned v)
+{
+    if (voff >= r.bytes || (unsigned long long)voff + soff + 4 > r.bytes) return;
+    memcpy(r.base + voff + soff, &v, 4);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t fd_bufrsrc;
+__device__ __forceinline__ fd_bufrsrc fd_make_rsrc(const void *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ unsigned fd_buf_ld32(fd_bufrsrc r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0); }
+__device__ __forceinline__ void fd_buf_st32(fd_bufrsrc r, unsigned voff, unsigned soff, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)voff, (int)soff, 0); }
+#endif
 // ---- pixel-pair arithmetic of the 16-bit 5x5 kernels (fd_kernels_dw5p.h) ---------------------------------------------------------------
 // A "pair" is one 32-bit word holding the SAME channel of two horizontally adjacent pixels (low half = the even pixel) in the storage type.
 // Depthwise taps then run on v_dot2_f32_{f16,bf16}: two 16-bit multiply-accumulates into an fp32 accumulator per VALU slot with no conversion
@@ -383,6 +451,28 @@ __device__ __forceinline__ float fd_dot2(fd_bf16, unsigned a, unsigned b, float 
 {
     typedef __bf16 fd_b2_hw __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fd_b2_hw, a), __builtin_bit_cast(fd_b2_hw, b), c, false);
+}
+#endif
+// The tap loops of fd_kernels_dw5p.h issue their dot2 in SOURCE order (volatile asm): eight independent accumulation chains interleaved.  Left to
+// itself the compiler runs the chains two at a time (its scheduler minimises live registers; the intrinsic is pure, so sched_barrier does not pin it).
+// fd_dot2_first starts a chain from a third operand (v_dot2_f32_*: no copy of the bias into the accumulator first).
+#ifdef FD_EMU
+template <typename T> inline void fd_dot2_acc(T, unsigned a, unsigned b, float &acc) { acc = fd_dot2(T{}, a, b, acc); }
+template <typename T> inline float fd_dot2_first(T, unsigned a, unsigned b, float c) { return fd_dot2(T{}, a, b, c); }
+#else
+__device__ __forceinline__ void fd_dot2_acc(fd_half, unsigned a, unsigned b, float &acc) { asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void fd_dot2_acc(fd_bf16, unsigned a, unsigned b, float &acc) { asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+__device__ __forceinline__ float fd_dot2_first(fd_half, unsigned a, unsigned b, float c)
+{
+    float r;
+    asm volatile("v_dot2_f32_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fd_dot2_first(fd_bf16, unsigned a, unsigned b, float c)
+{
+    float r;
+    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 #endif
 #define FD_PERM_LO 0x05040100u     /* fd_perm(b, a, FD_PERM_LO) = (low half of a, low half of b) */

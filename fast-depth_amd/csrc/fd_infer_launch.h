@@ -31,8 +31,18 @@ int launch_dw_inst(const Layer &L, const T *in, const T *skip, const float *wp, 
 }
 
 template <typename T, int ACT>
-int launch_dw(const Layer &L, const T *in, const T *skip, const float *wp, const float *bias, T *out, hipStream_t s)
+int launch_dw(const Layer &L, const T *in, const T *skip, const float *wp, const float *bias, T *out, hipStream_t s, const unsigned *wpk = nullptr)
 {
+    if (L.dw5_cl) {                                          // 16-bit plans: 5x5 on up2(low) + skip, row-walking pixel-pair kernel
+        if constexpr (!std::is_same<T, float>::value) {
+            if (L.dw5_cl == 64)
+                FD_LAUNCH((fd_dw5_rows<T, ACT, 64>), L.grid, dim3(FD_DW5R_BLOCK), 0, s, in, skip, wpk, bias, out, L.in_h, L.in_w, L.d.cin, L.dw5_cbs, L.dw5_groups, L.dw5_bh);
+            else
+                FD_LAUNCH((fd_dw5_rows<T, ACT, 32>), L.grid, dim3(FD_DW5R_BLOCK), 0, s, in, skip, wpk, bias, out, L.in_h, L.in_w, L.d.cin, L.dw5_cbs, L.dw5_groups, L.dw5_bh);
+            return check_launch("fd_dw5_rows");
+        }
+        return fail(FD_ERR_INVALID, "fd_dw5_rows is a 16-bit kernel");
+    }
     if (L.dw_rows && L.dw_rows8) {
         if constexpr (!std::is_same<T, float>::value) {
             if (L.d.stride == 1)
@@ -212,7 +222,7 @@ int launch_layer(const fd_plan *p, const Layer &L, const float *x, float *y, hip
     const T *skip = L.d.skip >= 0 ? reinterpret_cast<const T *>(p->ws + p->layers[L.d.skip].out_off) : nullptr;
     switch (L.d.op) {
     case FD_OP_STEM: return launch_stem<T, ACT>(L, x, wpf, bias, out, p->B, s);
-    case FD_OP_DW: return launch_dw<T, ACT>(L, in, skip, wpf, bias, out, s);
+    case FD_OP_DW: return launch_dw<T, ACT>(L, in, skip, wpf, bias, out, s, L.dw5_cl ? reinterpret_cast<const unsigned *>(p->ws + L.wpk_off) : nullptr);
     case FD_OP_PW:
         if (L.head) {
             const int h = L.d.upsample ? L.in_h / 2 : L.in_h, w = L.d.upsample ? L.in_w / 2 : L.in_w;

@@ -69,6 +69,26 @@ int plan_layers(fd_plan *p, const fd_layer_desc *layers, size_t *woff_out)
                 L.w_bytes = (size_t)9 * d.cin * 4; L.w_elems = (size_t)9 * d.cin;
                 break;
             }
+            // 16-bit plans, 5x5 on up2(low) + skip (decode_conv3 / 4 / 5): the row-walking pixel-pair kernel (fd_kernels_dw5p.h).  Measured at batch 32, fp16,
+            // us (tools/microbench/dw5pairs.hip): decode_conv5.0 42.6 -> 34, decode_conv4.0 26.4 -> 21, decode_conv3.0 15.3 -> 13; pruned widths at batch 64:
+            // 81 -> 56, 49 -> 33, 26 -> 20.  Bands of 14 rows (balanced, even) measured best or equal on all three maps; the 128-channel wave form only
+            // where the strip count is odd (7 strips of a 28-pixel row: no half-idle wave)
+            if (dtype != FD_F32 && d.ksize == 5 && d.stride == 1 && L.mode == 2 && d.cin % 8 == 0 && L.out_w % 4 == 0 && L.in_h % 2 == 0 &&
+                (double)L.in_h * L.in_w * d.cin * 2.0 < 2147483648.0 && !(tune & FD_TUNE_NO_DW5_ROWS)) {
+                const int strips = L.out_w / 4;
+                L.dw5_cl = (strips % 2 == 1 && d.cin >= 128) ? 64 : 32;
+                const int cblocks = ceil_div(d.cin, 2 * L.dw5_cl);
+                L.dw5_cbs = ceil_div(ceil_div(d.cin, cblocks), 8) * 8;
+                L.dw5_groups = ceil_div(strips, 64 / L.dw5_cl);
+                const int bands = std::max(1, (L.out_h + 7) / 14);
+                L.dw5_bh = ceil_div(ceil_div(L.out_h, bands), 2) * 2;
+                L.grid = dim3(ceil_div((long)L.dw5_groups * ceil_div(L.out_h, L.dw5_bh), FD_DW5R_BLOCK / 64), cblocks, batch);
+                L.lds = 0;
+                L.w_elems = (size_t)25 * d.cin;
+                L.wpk_off = align_up((size_t)25 * d.cin * 4, 256);      // (relative to w_off; made absolute below)
+                L.w_bytes = L.wpk_off + (size_t)30 * d.cin * 4;
+                break;
+            }
             // 16-bit plans: 8 channels (16 bytes) per work-item and patches kept in the storage type -- a 64-channel block has the LDS footprint
             // (and the instruction count) of the 32-channel fp32 block; FD_TUNE_NO_DW_H8 keeps the 4-channel / fp32-patch form for A/B runs
             // Measured (fp16, batch 32, us, 8-channel vs 4-channel form): decode_conv5.0 46.5 vs 49.4, decode_conv4.0 28.3 vs 29.4 -- but decode_conv3.0
@@ -136,6 +156,7 @@ int plan_layers(fd_plan *p, const fd_layer_desc *layers, size_t *woff_out)
         if ((long)L.in_h * L.in_w >= (1L << 24) || d.cin >= (1 << 24) || d.cout >= (1 << 24) || (double)L.in_h * L.in_w * std::max(d.cin, d.cout) >= 4294967296.0)
             FD_BAD("layer %d: a %dx%d map with %d channels exceeds the kernels' 32-bit within-image addressing", i, L.in_h, L.in_w, std::max(d.cin, d.cout));
         L.w_off = woff; woff += align_up(L.w_bytes, 256);
+        if (L.dw5_cl) L.wpk_off += L.w_off;
         L.b_off = woff; woff += align_up((size_t)d.cout * 4, 256);
         L.out_bytes = align_up((size_t)batch * L.out_h * L.out_w * d.cout * esz, 256);
         L.pw_packed_t = (d.op == FD_OP_PW && !L.head && dtype != FD_F32);
@@ -379,6 +400,9 @@ void plan_describe(fd_plan *p)
                      L.fuse_head >= 0 ? " + the 32->1 head on the accumulators" : "");
         else if (d.op == FD_OP_STEM)
             snprintf(buf, sizeof buf, "stem3x3s2<mfma 32x32x2, LDS-staged rows, 256 px per workgroup> grid=%ux%u lds=%zu", L.grid.x, L.grid.y, L.lds);
+        else if (d.op == FD_OP_DW && L.dw5_cl)
+            snprintf(buf, sizeof buf, "dw5_rows<k5 s1 mode2, pixel pairs + dot2, %d channel lanes per strip> bands of %d rows, %d strip groups, %d channels per block, grid=%ux%ux%u, no LDS",
+                     L.dw5_cl, L.dw5_bh, L.dw5_groups, L.dw5_cbs, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW && L.dw_rows)
             snprintf(buf, sizeof buf, "dw3_rows%s<s%d> rows/item %d grid=%ux%ux%u", L.dw_rows8 ? "8" : "", d.stride, L.th, L.grid.x, L.grid.y, L.grid.z);
         else if (d.op == FD_OP_DW)
@@ -400,6 +424,7 @@ void plan_describe(fd_plan *p)
         if (L.skipped || L.fused_into >= 0) buf[0] = 0;
         else if (L.dwpw) snprintf(buf, sizeof buf, "fd_dwpw_f32<%d, %d, %d, %d, %d, %d, %d, %d, 0>", p->layers[L.fused_dw].d.ksize, p->layers[L.fused_dw].d.stride, p->layers[L.fused_dw].mode, d.act, L.dp_wm, L.dp_nt, L.dp_nld, L.fuse_head >= 0 ? 1 : 0);
         else if (d.op == FD_OP_STEM) snprintf(buf, sizeof buf, "fd_stem3x3s2<%s, %d, %d>", tn, d.act, L.chunk);
+        else if (d.op == FD_OP_DW && L.dw5_cl) snprintf(buf, sizeof buf, "fd_dw5_rows<%s, %d, %d>", tn, d.act, L.dw5_cl);
         else if (d.op == FD_OP_DW && L.dw_rows) snprintf(buf, sizeof buf, "fd_dw3_rows%s<%s, %d, %d>", L.dw_rows8 ? "8" : "", tn, d.stride, d.act);
         else if (d.op == FD_OP_DW) snprintf(buf, sizeof buf, "fd_dwconv<%s, %d, %d, %d, %d, %d>", tn, d.ksize, d.stride, L.mode, d.act, L.dw_n);
         else if (L.head) snprintf(buf, sizeof buf, "fd_head_pw1<%s, %d>", tn, d.act);

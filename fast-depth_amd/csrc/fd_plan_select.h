@@ -61,6 +61,8 @@ struct Layer {
     // dw tiling
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0, mode = 0, pstr = 0;   // pstr: LDS patch row pitch in LDS elements (pick_patch_pitch)
     int dw_n = 4;                // channels per work-item of the LDS-tiled depthwise kernel (8: 16-bit plans, storage-typed patches)
+    int dw5_cl = 0, dw5_cbs = 0, dw5_groups = 0, dw5_bh = 0;   // > 0: the row-walking pixel-pair kernel fd_dw5_rows (16-bit plans, 5x5 on up2 + skip): channel lanes per strip, channels per block, strip groups per row, rows per band
+    size_t wpk_off = 0;          // ... its tap pairs (fd_pack_dw5_pairs), behind the folded fp32 taps
     int csplit = 0;              // concatenating consumer: channels [0, csplit) come from src, the rest from skip
     bool skipped = false;        // depthwise layer executed inside the following pointwise layer's fused kernel
     int fuse_next_dw = -1;       // pointwise layer (fd_pw_gemm16_f32): index of the depthwise consumer evaluated in its epilogue

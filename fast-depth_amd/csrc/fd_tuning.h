@@ -34,7 +34,9 @@
                                              apply pass of a 16-bit pointwise unit with <= 128 partial rows, fd_bn_bwd_apply_fin_h16) */
 #define FD_TUNE_DW_BWD_FINALIZE 524288u    /* train plans: the LDS-tiled depthwise backward launches finalise their unit's BatchNorm backward themselves when its partial
                                              rows are <= 128 (fd_bn_bwd_finalize_block; default: only the apply pass of the 16-bit pointwise units does) */
-#define FD_TUNE_ALL 1048575u
+#define FD_TUNE_NO_DW5_ROWS 1048576u       /* 16-bit plans: the 5x5 up2 + skip units keep the LDS-tiled fd_dwconv (default since round 6: the row-walking pixel-pair
+                                             kernel fd_dw5_rows, fd_kernels_dw5p.h) -- A/B runs and the tests of the older form */
+#define FD_TUNE_ALL 2097151u
 
 #ifdef __cplusplus
 extern "C" {

@@ -49,6 +49,7 @@ FD_TUNE_NO_DW_H8 = 65536 << _TUNE_SHIFT
 FD_TUNE_FORCE_DW_H8 = 131072 << _TUNE_SHIFT
 FD_TUNE_NO_CONSUMER_FINALIZE = 262144 << _TUNE_SHIFT
 FD_TUNE_DW_BWD_FINALIZE = 524288 << _TUNE_SHIFT
+FD_TUNE_NO_DW5_ROWS = 1048576 << _TUNE_SHIFT
 
 
 def create_plan(lib, train, descs, n, batch, height, width, fd_dtype, flags, handle_ref):

@@ -130,8 +130,8 @@ def test_16bit_storage_golden_case(dtype, tol, mtol):
 def test_16bit_default_plan_batch32_vs_oracle(dtype, tol, mtol_d1, mtol_rmse):
     """The plan `bench.py` times as `other_configs` fp16 / bf16 B=32 (unpruned, DEFAULT flags) compared DIRECTLY with the oracle: the fp32 torch
     restatement in 8-frame chunks, as test_full_batch32_vs_oracle_and_properties does for the fp32 plan.  Asserts through plan.info() that the
-    round-3 / round-4 kernels are the ones that ran: fd_pw_gemm16_h16 with fused depthwise epilogues, the head on decode_conv5.1's GEMM tile,
-    the 8-channel register-window 3x3 kernel and the 8-channel storage-typed 5x5 depthwise kernel.  Element-wise bound `tol`; delta1 within
+    round-3 / round-4 / round-6 kernels are the ones that ran: fd_pw_gemm16_h16 with fused depthwise epilogues, the head on decode_conv5.1's GEMM tile,
+    the 8-channel register-window 3x3 kernel and the row-walking pixel-pair 5x5 kernel (fd_dw5_rows) on the three up2 + skip units.  Element-wise bound `tol`; delta1 within
     `mtol_d1` and RMSE within `mtol_rmse` (relative) of the oracle's, per frame against the sample depth map."""
     m, _, _, _ = inputs.golden_case("base_s0")
     x = inputs.batch_variants(inputs.load_sample()[0], 32, seed=0)
@@ -146,7 +146,7 @@ def test_16bit_default_plan_batch32_vs_oracle(dtype, tol, mtol_d1, mtol_rmse):
     assert sum(s.startswith("pw_gemm16") and "fused dw" in s for s in info) >= 6, info
     assert any("head on its output tile" in s for s in info), info
     assert any(s.startswith("dw3_rows8") for s in info), info
-    assert sum(s.startswith("dwconv<k5") and "8 channels per work-item" in s for s in info) >= 2, info     # decode_conv4 / 5: the maps of >= 56 x 56
+    assert sum(s.startswith("dw5_rows<") for s in info) == 3, info     # decode_conv3 / 4 / 5: the row-walking pixel-pair kernel (round 6)
     assert harness.rel_err(y.numpy(), y_ref.numpy()) < tol
     depth = inputs.load_sample()[1].numpy()
     for i in (0, 5, 17, 31):
@@ -169,6 +169,7 @@ def test_pruned_fp16_batch64_config5():
     assert harness.rel_err(y[:6].cpu().numpy(), yo) < 1e-2
     err, per_layer, info = harness.compare_with_oracle("hip", m.cpu(), x[:2], torch.device("cuda"), dtype=torch.float16)
     assert max(per_layer) < 2e-2, [(i, e, info[i]) for i, e in enumerate(per_layer) if e >= 2e-2]
+    assert sum(s.startswith("dw5_rows<") for s in info) == 3, info     # the pruned widths (200 / 120 / 56 channels) run the pixel-pair kernel with ragged channel blocks
 
 
 def test_on_device_metrics_and_eval_harness(tmp_path):

@@ -1,8 +1,9 @@
-// standalone microbench (not product code): the round-6 pixel-pair 5x5 kernel fd_dw5_pairs against fd_dwconv<T, 5, 1, 2, ACT, 8> on the
-// three up2 + skip units of the decoder (B = 32): same inputs, outputs compared, both timed; sweep of the band height.
+// standalone microbench (not product code): the round-6 pixel-pair 5x5 kernel fd_dw5_rows and its two measured alternatives (dw5_variants.h)
+// against fd_dwconv<T, 5, 1, 2, ACT, 8> and a CPU reference on the three up2 + skip units of the decoder (B = 32) and the pruned widths (B = 64):
+// same inputs, outputs compared, all timed; sweep of the band height.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench/dw5pairs.hip -o scratch/dw5pairs
 #include "../../fast-depth_amd/csrc/fd_kernels_f32.h"
-#include "../../fast-depth_amd/csrc/fd_kernels_dw5p.h"
+#include "dw5_variants.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -88,12 +89,47 @@ static void run(int B, int H, int C, const std::vector<int> &bhs)
         printf("%s B=%d %dx%d C=%d  fd_dw5_pairs bh=%d (%d WGs, two=%d cbs=%d): %.1f us = %.2f TB/s | vs old: max|d| %.3g of max %.3g, non-finite %zu | vs CPU %.3g\n", cvt<T>::name(), B, H, W, C, bh,
                (int)(grid.x * grid.y * grid.z), two, cbs, us, bytes / us * 1e-6, maxd, maxv, bad, ref_err(hn));
     }
+    for (int bh : bhs) for (int cl : {32, 64}) {
+        const int spw = 64 / cl, groups = ((W + 3) / 4 + spw - 1) / spw, bands = (H + bh - 1) / bh;
+        const int cblocks = (C + 2 * cl - 1) / (2 * cl), cbs = ((C + cblocks - 1) / cblocks + 7) / 8 * 8;
+        dim3 grid((groups * bands + FD_DW5R_BLOCK / 64 - 1) / (FD_DW5R_BLOCK / 64), cblocks, B);
+        CK(hipMemset(o_new, 0xff, n_hi * 2));
+        const double us = cl == 32 ? time([&]() { hipLaunchKernelGGL((fd_dw5_rows<T, 1, 32>), grid, dim3(FD_DW5R_BLOCK), 0, 0, low, skip, wpk, bias, o_new, H, W, C, cbs, groups, bh); }, 20)
+                                   : time([&]() { hipLaunchKernelGGL((fd_dw5_rows<T, 1, 64>), grid, dim3(FD_DW5R_BLOCK), 0, 0, low, skip, wpk, bias, o_new, H, W, C, cbs, groups, bh); }, 20);
+        CK(hipMemcpy(hn.data(), o_new, n_hi * 2, hipMemcpyDeviceToHost));
+        double maxd = 0; size_t bad = 0;
+        for (size_t i = 0; i < n_hi; ++i) {
+            const double a = cvt<T>::from(ho[i]), b = cvt<T>::from(hn[i]);
+            if (!(std::fabs(b) < 1e30)) { ++bad; continue; }
+            maxd = std::max(maxd, std::fabs(a - b));
+        }
+        printf("%s B=%d %dx%d C=%d  fd_dw5_rows<CL=%d> bh=%d (%d WGs, cbs=%d): %.1f us = %.2f TB/s | vs old: max|d| %.3g, non-finite %zu | vs CPU %.3g\n", cvt<T>::name(), B, H, W, C, cl, bh,
+               (int)(grid.x * grid.y * grid.z), cbs, us, bytes / us * 1e-6, maxd, bad, ref_err(hn));
+    }
+    for (int bh : bhs) {
+        const int groups = (W + 7) / 8, bands = (H + bh - 1) / bh;
+        const int cblocks = (C + 63) / 64, cbs = ((C + cblocks - 1) / cblocks + 7) / 8 * 8;
+        dim3 grid((groups * bands + 3) / 4, cblocks, B);
+        CK(hipMemset(o_new, 0xff, n_hi * 2));
+        const double us = time([&]() { hipLaunchKernelGGL((fd_dw5_dma<T, 1>), grid, dim3(256), 0, 0, low, skip, wpk, bias, o_new, H, W, C, cbs, groups, bh); }, 20);
+        CK(hipMemcpy(hn.data(), o_new, n_hi * 2, hipMemcpyDeviceToHost));
+        double maxd = 0; size_t bad = 0;
+        for (size_t i = 0; i < n_hi; ++i) {
+            const double a = cvt<T>::from(ho[i]), b = cvt<T>::from(hn[i]);
+            if (!(std::fabs(b) < 1e30)) { ++bad; continue; }
+            maxd = std::max(maxd, std::fabs(a - b));
+        }
+        printf("%s B=%d %dx%d C=%d  fd_dw5_dma bh=%d (%d WGs, cbs=%d): %.1f us = %.2f TB/s | vs old: max|d| %.3g, non-finite %zu | vs CPU %.3g\n", cvt<T>::name(), B, H, W, C, bh,
+               (int)(grid.x * grid.y * grid.z), cbs, us, bytes / us * 1e-6, maxd, bad, ref_err(hn));
+    }
     CK(hipFree(low)); CK(hipFree(skip)); CK(hipFree(o_old)); CK(hipFree(o_new)); CK(hipFree(wf)); CK(hipFree(bias)); CK(hipFree(wpk));
 }
 
 int main(int argc, char **)
 {
-    if (argc > 1) { run<fd_half>(32, 112, 64, {20}); run<fd_half>(32, 56, 128, {14}); run<fd_half>(32, 28, 256, {8}); return 0; }   // quick mode (ablation builds)
+    { int nb = 0; CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fd_dw5_rows<fd_half, 1, 32>, FD_DW5R_BLOCK, 0)); printf("occupancy API: fd_dw5_rows<f16, 32> blocks of %d per CU: %d\n", FD_DW5R_BLOCK, nb);
+      CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fd_dw5_pairs<fd_half, 1>, 256, FD_DW5P_LDS)); printf("occupancy API: fd_dw5_pairs<f16> blocks of 256 per CU: %d\n", nb); }
+    if (argc > 1) { run<fd_half>(32, 112, 64, {20}); run<fd_half>(32, 56, 128, {14}); run<fd_half>(32, 28, 256, {8}); run<fd_bf16>(32, 112, 64, {20}); return 0; }   // quick mode (ablation builds)
     run<fd_half>(32, 112, 64, {112, 56, 28, 20, 14, 10});
     run<fd_half>(32, 56, 128, {56, 28, 20, 14, 10, 8});
     run<fd_half>(32, 28, 256, {28, 14, 10, 8, 6, 4});
