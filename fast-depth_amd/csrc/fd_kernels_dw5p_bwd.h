@@ -1,0 +1,386 @@
+// fd_kernels_dw5p_bwd.h -- backward of the depthwise 5x5 units on  up2(a_low) + a_skip  (decode_conv3 / 4 / 5 .0; autograd of reference models.py:61-68
+// behind models.py:723-729) for the bf16 train plans: the row-walking pixel-pair form of fd_kernels_dw5p.h (round 6).
+//
+// Replaces the paired launch fd_dw_bwd<T, 5, 1, 2, ...> on these units (profiles/r05: 150 / 82 / 45 us per step, 143 VALU lane-instructions per output
+// against 25 packed FMAs: LDS-tiled 8 x 16 tiles that stage 1.9 x their outputs, fp32 patches converted on every read).  One launch, two roles dealt by
+// workgroup number; in both a WAVE walks down a band of rows for 2 adjacent channels x 4 adjacent columns per lane, everything it re-uses in registers:
+//   role D (backward-data):  dz = A((G - c1) - (z - mu) c2) is formed once per loaded element, rounded to the storage type and kept as pixel pairs in a
+//     5-row window; d_in = the correlation of that window with the FLIPPED 16-bit tap pairs on v_dot2 (15 per value, fp32 accumulation); the skip
+//     gradient = d_in leaves at full resolution (the gradient of the ACTIVATED skip tensor), the producer's gradient = mask(y_low) * (2 x 2 sum of d_in) at low resolution together
+//     with its BatchNorm-backward sums (sum G, sum G * xhat), which reach the producer's statistics rows once per workgroup;
+//   role W (backward-weights): the forward input  relu(z_low s1 + t1) ^2 + relu6(z_skip s2 + t2)  is re-created on load, rounded, and kept as pixel pairs
+//     in a 5-row window together with the pairs shifted by one pixel (v_perm of neighbouring pairs, formed once per row); dW[ky][kx] accumulates
+//     dot2(dz pair, input pair) -- 2 per tap, row and lane, 12.5 per value -- in 50 registers for the whole band; a workgroup's four waves meet in LDS
+//     at the end and write ONE partial row (fd_reduce_weights_batch_f32 adds the rows).
+// Memory access as in fd_dw5_rows: raw-buffer loads / stores, lane offsets fixed for the band, the horizontal zero padding by the range check (plus a
+// select where the padded quantity is not 0 at zero input: dz).  No LDS and no barrier until the end-of-kernel reductions.
+// Numerics (layer-local test, tests/harness.py): dz and the re-created input are rounded to the storage type (as the 8-channel LDS form did); role D
+// rounds the taps to the storage type as well (fd_train_plan_lds_rounding bit 3); sums and gradients accumulate in fp32.
+#pragma once
+#include "fd_kernels_dw5p.h"
+#include "fd_kernels_bwd.h"
+
+template <typename T> struct fd_dw5_bwd_args {
+    const T *G, *Z, *Zin, *Zskip;      // this unit's dL/dy (after its consumer's mask) and raw output; the raw outputs of the low-resolution producer and of the skip source
+    T *Gin, *SGout;                    // gradient handed to the producer (low resolution) / to the skip source (full resolution)
+    const float *coef, *w, *st_in, *st_skip;   // BN-backward coefficients [4][C] of this unit, live taps [C][25], tables [4][C] of the producer / the skip source
+    fd_stat_rows sr;                   // BatchNorm-backward statistics rows of the PRODUCER
+    float *wpart;                      // weight-gradient partial rows: row = image * wgs_w + workgroup, [25][C]
+    int H, W, C, groups_x;             // full-resolution map, channels, strip pairs per row (W / 8, rounded up)
+    int bh_d, bh_w, wgs_d, wgs_w;      // rows per band and workgroups per image and channel block of the two roles
+};
+
+#ifndef FD_DW5B_WAVES
+#define FD_DW5B_WAVES 2               // waves per SIMD the register allocation is held to (<= 256 VGPRs: both roles keep ~200 live)
+#endif
+#ifdef FD_EMU
+#define FD_DW5B_ATTR
+#else
+#define FD_DW5B_ATTR __attribute__((amdgpu_waves_per_eu(FD_DW5B_WAVES, FD_DW5B_WAVES)))
+#endif
+
+// 16-bit storage -> fp32 of the two channels of a loaded word
+__device__ __forceinline__ float fd_w16_lo(fd_bf16, unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float fd_w16_hi(fd_bf16, unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+__device__ __forceinline__ float fd_w16_lo(fd_half, unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)v); }
+__device__ __forceinline__ float fd_w16_hi(fd_half, unsigned v) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)); }
+
+// ---- role D: backward-data ------------------------------------------------------------------------------------------------------------------------
+template <typename T, int ACT1, int ACT2>
+__device__ __forceinline__ void
+fd_dw5_dgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long stat_blk)
+{
+    const int H = a.H, W = a.W, C = a.C, Hs = H >> 1, Ws = W >> 1;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = wg * 4 + wave;
+    const int band = item / a.groups_x, sg = item - band * a.groups_x;
+    const int cend = c0 + 64 < C ? c0 + 64 : C;
+    const int y0 = band * a.bh_d, y1 = y0 + a.bh_d < H ? y0 + a.bh_d : H;
+    const int l = lane & 31, xs = 4 * (2 * sg + (lane >> 5)), c = c0 + 2 * l;
+    const bool live = y0 < H && c < cend && xs < W;
+    float sg0 = 0.f, sg1 = 0.f, sx0 = 0.f, sx1 = 0.f;       // this lane's sums of the producer's gradient and gradient * xhat, channels c / c + 1
+    if (live) {
+        // flipped taps as 16-bit pairs: d_in[x] = sum_k dz[x + 2 - k] w[k] = sum_k' dz[x - 2 + k'] w[4 - k']
+        unsigned w[5][6][2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float *wc = a.w + (long)(c + ch) * 25;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const float f0 = wc[(4 - ky) * 5 + 4], f1 = wc[(4 - ky) * 5 + 3], f2 = wc[(4 - ky) * 5 + 2], f3 = wc[(4 - ky) * 5 + 1], f4 = wc[(4 - ky) * 5 + 0];
+                w[ky][0][ch] = fd_pack2(T{}, f0, f1); w[ky][1][ch] = fd_pack2(T{}, f2, f3); w[ky][2][ch] = fd_pack2(T{}, f4, 0.f);
+                w[ky][3][ch] = fd_pack2(T{}, 0.f, f0); w[ky][4][ch] = fd_pack2(T{}, f1, f2); w[ky][5][ch] = fd_pack2(T{}, f3, f4);
+            }
+        }
+        float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], m1[2], i1[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch]; m1[ch] = a.st_in[FD_ST_MEAN * C + c + ch]; i1[ch] = a.st_in[FD_ST_INVSTD * C + c + ch];
+        }
+        unsigned so[4];                                      // byte offsets of the strip's four pixel pairs in a full-resolution row (out of range: outside the image)
+        bool pin[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int x = xs - 2 + 2 * p;
+            pin[p] = x >= 0 && x < W;
+            so[p] = pin[p] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned lo0 = (fd_mul24((unsigned)(xs >> 1), (unsigned)C) + (unsigned)c) * 2u;      // the strip's two low-resolution pixels
+        const unsigned rowb = fd_mul24((unsigned)W, (unsigned)C) * 2u, pxb = (unsigned)C * 2u, rowl = rowb >> 1;
+        const fd_bufrsrc r_g = fd_make_rsrc(a.G + (long)n * H * W * C, (unsigned)H * rowb), r_z = fd_make_rsrc(a.Z + (long)n * H * W * C, (unsigned)H * rowb);
+        const fd_bufrsrc r_lo = fd_make_rsrc(a.Zin + (long)n * Hs * Ws * C, (unsigned)Hs * rowl);
+        const fd_bufrsrc r_so = fd_make_rsrc(a.SGout + (long)n * H * W * C, (unsigned)H * rowb), r_gl = fd_make_rsrc(a.Gin + (long)n * Hs * Ws * C, (unsigned)Hs * rowl);
+
+        unsigned ng[2][8], nz[2][8], nlo[2];                 // in flight: G / z of the next step's two dz rows, z_low under the next step's two OUTPUT rows
+        bool nv = false;
+        // step `it`: dz rows r = y0 - 2 + 2 it and r + 1 enter the window, d_in rows r - 2 and r - 1 (it >= 2) leave
+        auto issue = [&](int it) FD_INLINE_LAMBDA {
+            const int r = y0 - 2 + 2 * it;
+            nv = r >= 0 && r < H;
+            if (nv) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const unsigned ro = (unsigned)(r + rr) * rowb;
+                        ng[rr][2 * p] = fd_buf_ld32(r_g, so[p], ro); ng[rr][2 * p + 1] = fd_buf_ld32(r_g, so[p], ro + pxb);
+                        nz[rr][2 * p] = fd_buf_ld32(r_z, so[p], ro); nz[rr][2 * p + 1] = fd_buf_ld32(r_z, so[p], ro + pxb);
+                    }
+            }
+            if (it >= 2) {
+                const int y = r - 2;                         // (even; rows y, y + 1 are inside the band)
+                nlo[0] = fd_buf_ld32(r_lo, lo0, (unsigned)(y >> 1) * rowl); nlo[1] = fd_buf_ld32(r_lo, lo0, (unsigned)(y >> 1) * rowl + pxb);
+            }
+        };
+        unsigned win[5][4][2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { win[q][p][0] = 0u; win[q][p][1] = 0u; }
+        auto convert = [&](unsigned (&dst)[4][2], const unsigned (&g)[8], const unsigned (&z)[8], bool rv) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float d00 = fd_dz(fd_w16_lo(T{}, g[2 * p]), fd_w16_lo(T{}, z[2 * p]), cA[0], c1[0], cM[0], c2[0]);
+                const float d01 = fd_dz(fd_w16_lo(T{}, g[2 * p + 1]), fd_w16_lo(T{}, z[2 * p + 1]), cA[0], c1[0], cM[0], c2[0]);
+                const float d10 = fd_dz(fd_w16_hi(T{}, g[2 * p]), fd_w16_hi(T{}, z[2 * p]), cA[1], c1[1], cM[1], c2[1]);
+                const float d11 = fd_dz(fd_w16_hi(T{}, g[2 * p + 1]), fd_w16_hi(T{}, z[2 * p + 1]), cA[1], c1[1], cM[1], c2[1]);
+                const bool v = rv && pin[p];                 // (dz of a pixel outside the image is 0, not dz(0, 0))
+                dst[p][0] = v ? fd_pack2(T{}, d00, d01) : 0u; dst[p][1] = v ? fd_pack2(T{}, d10, d11) : 0u;
+            }
+        };
+        float lacc[2][2];                                    // 2 x 2 sums of d_in: [low pixel of the strip][channel]
+        unsigned lo_now[2];                                  // z_low under this step's two output rows (the registers it landed in carry the next step's already)
+        auto out_row = [&](auto SB, int y, int rr) FD_INLINE_LAMBDA {
+            constexpr int sb = decltype(SB)::value;
+            float acc[4][2];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const unsigned (&R)[4][2] = win[(sb + ky) % 5];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        if (ky == 0 && k == 0) {
+                            acc[0][ch] = fd_dot2_first(T{}, R[k][ch], w[ky][k][ch], 0.0f);
+                            acc[1][ch] = fd_dot2_first(T{}, R[k][ch], w[ky][3 + k][ch], 0.0f);
+                            acc[2][ch] = fd_dot2_first(T{}, R[k + 1][ch], w[ky][k][ch], 0.0f);
+                            acc[3][ch] = fd_dot2_first(T{}, R[k + 1][ch], w[ky][3 + k][ch], 0.0f);
+                        } else {
+                            fd_dot2_acc(T{}, R[k][ch], w[ky][k][ch], acc[0][ch]);
+                            fd_dot2_acc(T{}, R[k][ch], w[ky][3 + k][ch], acc[1][ch]);
+                            fd_dot2_acc(T{}, R[k + 1][ch], w[ky][k][ch], acc[2][ch]);
+                            fd_dot2_acc(T{}, R[k + 1][ch], w[ky][3 + k][ch], acc[3][ch]);
+                        }
+                    }
+                }
+            }
+            // the gradient of the ACTIVATED skip tensor at full resolution (its source's activation mask is applied by the source's own consumer, which
+            // adds this buffer: ADD_SG); the producer's gradient collects its 2 x 2 block
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fd_buf_st32(r_so, so[1 + (j >> 1)], (unsigned)y * rowb + (unsigned)(j & 1) * pxb, fd_pack2(T{}, acc[j][0], acc[j][1]));
+#pragma unroll
+            for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float s = acc[2 * jl][ch] + acc[2 * jl + 1][ch];
+                    lacc[jl][ch] = rr == 0 ? s : lacc[jl][ch] + s;
+                }
+            if (rr == 1) {
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl) {
+                    const float z0 = fd_w16_lo(T{}, lo_now[jl]), z1 = fd_w16_hi(T{}, lo_now[jl]);
+                    const unsigned packed = fd_pack2(T{}, lacc[jl][0] * fd_actmask<ACT1>(fmaf(z0, s1[0], t1[0])), lacc[jl][1] * fd_actmask<ACT1>(fmaf(z1, s1[1], t1[1])));
+                    fd_buf_st32(r_gl, lo0, (unsigned)(y >> 1) * rowl + (unsigned)jl * pxb, packed);
+                    const float g0 = fd_w16_lo(T{}, packed), g1 = fd_w16_hi(T{}, packed);      // statistics of the stored (rounded) gradient
+                    sg0 += g0; sg1 += g1;
+                    sx0 = fmaf(g0, (z0 - m1[0]) * i1[0], sx0); sx1 = fmaf(g1, (z1 - m1[1]) * i1[1], sx1);
+                }
+            }
+        };
+        const int n_it = (y1 - y0 + 4) >> 1;
+        issue(0);
+        auto step = [&](auto PH, int it) FD_INLINE_LAMBDA {
+            constexpr int ph = decltype(PH)::value;
+            const bool rv = nv;
+            unsigned hold[4][2];                             // row r + 1 takes the slot of row r - 4, which output row r - 2 still reads: its pairs wait here
+            convert(win[(2 * ph) % 5], ng[0], nz[0], rv);
+            convert(hold, ng[1], nz[1], rv);
+            lo_now[0] = nlo[0]; lo_now[1] = nlo[1];
+            if (it + 1 < n_it) issue(it + 1);                // everything the next step reads flies under this step's 240 dot2
+            if (it >= 2) out_row(fd_int<(2 * ph + 1) % 5>{}, y0 - 4 + 2 * it, 0);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { win[(2 * ph + 1) % 5][p][0] = hold[p][0]; win[(2 * ph + 1) % 5][p][1] = hold[p][1]; }
+            if (it >= 2) out_row(fd_int<(2 * ph + 2) % 5>{}, y0 - 3 + 2 * it, 1);
+        };
+        for (int it0 = 0; it0 < n_it; it0 += 5) {
+            step(fd_int<0>{}, it0);
+            if (it0 + 1 < n_it) step(fd_int<1>{}, it0 + 1);
+            if (it0 + 2 < n_it) step(fd_int<2>{}, it0 + 2);
+            if (it0 + 3 < n_it) step(fd_int<3>{}, it0 + 3);
+            if (it0 + 4 < n_it) step(fd_int<4>{}, it0 + 4);
+        }
+    }
+    // ---- the workgroup's BatchNorm-backward sums: the two strips of a wave (lanes l, l + 32), then the four waves through LDS; consecutive lanes add
+    // consecutive channels to the producer's statistics rows
+    sg0 += __shfl_xor(sg0, 32); sg1 += __shfl_xor(sg1, 32); sx0 += __shfl_xor(sx0, 32); sx1 += __shfl_xor(sx1, 32);
+    if (lane < 32) {
+        red[(wave * 2 + 0) * 64 + 2 * l] = sg0; red[(wave * 2 + 0) * 64 + 2 * l + 1] = sg1;
+        red[(wave * 2 + 1) * 64 + 2 * l] = sx0; red[(wave * 2 + 1) * 64 + 2 * l + 1] = sx1;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        if (c0 + ch < cend) {
+            const float v = (red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch]) + (red[(2 * 2 + which) * 64 + ch] + red[(3 * 2 + which) * 64 + ch]);
+            fd_stat_add<FD_STAT_BWD>(a.sr, stat_blk, C, which, c0 + ch, v);
+        }
+    }
+}
+
+// ---- role W: backward-weights ---------------------------------------------------------------------------------------------------------------------
+#define FD_PERM_SHIFT1 0x05040302u    /* fd_perm(next, cur, FD_PERM_SHIFT1) = (high half of cur, low half of next): the pixel pair one pixel to the right */
+template <typename T, int ACT1, int ACT2>
+__device__ __forceinline__ void
+fd_dw5_wgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long row_blk)
+{
+    const int H = a.H, W = a.W, C = a.C, Hs = H >> 1, Ws = W >> 1;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = wg * 4 + wave;
+    const int band = item / a.groups_x, sg = item - band * a.groups_x;
+    const int cend = c0 + 64 < C ? c0 + 64 : C;
+    const int y0 = band * a.bh_w, y1 = y0 + a.bh_w < H ? y0 + a.bh_w : H;
+    const int l = lane & 31, xs = 4 * (2 * sg + (lane >> 5)), c = c0 + 2 * l;
+    const bool live = y0 < H && c < cend && xs < W;
+    float acc[25][2];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
+    if (live) {
+        float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], s2[2], t2[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch];
+            s2[ch] = a.st_skip[FD_ST_SCALE * C + c + ch]; t2[ch] = a.st_skip[FD_ST_SHIFT * C + c + ch];
+        }
+        unsigned so[4], lo_[4];
+        bool pin[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int x = xs - 2 + 2 * p;
+            pin[p] = x >= 0 && x < W;
+            so[p] = pin[p] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+            lo_[p] = pin[p] ? (fd_mul24((unsigned)(x >> 1), (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned rowb = fd_mul24((unsigned)W, (unsigned)C) * 2u, pxb = (unsigned)C * 2u, rowl = rowb >> 1;
+        const fd_bufrsrc r_g = fd_make_rsrc(a.G + (long)n * H * W * C, (unsigned)H * rowb), r_z = fd_make_rsrc(a.Z + (long)n * H * W * C, (unsigned)H * rowb);
+        const fd_bufrsrc r_sk = fd_make_rsrc(a.Zskip + (long)n * H * W * C, (unsigned)H * rowb), r_lo = fd_make_rsrc(a.Zin + (long)n * Hs * Ws * C, (unsigned)Hs * rowl);
+
+        unsigned nsk[2][8], nlo[4], ng[2][4], nz[2][4];      // in flight: the next step's two input rows (z_skip, 8 pixels; their parents) and G / z of its two dz rows (4 pixels)
+        bool nv = false;
+        // step `it`: input rows r = y0 - 2 + 2 it and r + 1 enter the window; dz rows r - 2 and r - 1 (it >= 2) are multiplied with the window
+        auto issue = [&](int it) FD_INLINE_LAMBDA {
+            const int r = y0 - 2 + 2 * it;
+            nv = r >= 0 && r < H;
+            if (nv) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const unsigned ro = (unsigned)(r + rr) * rowb;
+                        nsk[rr][2 * p] = fd_buf_ld32(r_sk, so[p], ro); nsk[rr][2 * p + 1] = fd_buf_ld32(r_sk, so[p], ro + pxb);
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) nlo[p] = fd_buf_ld32(r_lo, lo_[p], (unsigned)(r >> 1) * rowl);
+            }
+            if (it >= 2) {
+                const int y = r - 2;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned ro = (unsigned)(y + rr) * rowb + (unsigned)(j & 1) * pxb;
+                        ng[rr][j] = fd_buf_ld32(r_g, so[1 + (j >> 1)], ro); nz[rr][j] = fd_buf_ld32(r_z, so[1 + (j >> 1)], ro);
+                    }
+            }
+        };
+        unsigned win[5][7][2];                               // input row (y0 - 2 + r) in win[r % 5]: pairs 0..3 as loaded, 4..6 = the pairs shifted right by one pixel
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int p = 0; p < 7; ++p) { win[q][p][0] = 0u; win[q][p][1] = 0u; }
+        auto convert = [&](unsigned (&dst)[7][2], const unsigned (&sk)[8], bool rv) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float l0 = fd_act<ACT1>(fmaf(fd_w16_lo(T{}, nlo[p]), s1[0], t1[0])), l1 = fd_act<ACT1>(fmaf(fd_w16_hi(T{}, nlo[p]), s1[1], t1[1]));
+                const float e0 = fd_act<ACT2>(fmaf(fd_w16_lo(T{}, sk[2 * p]), s2[0], t2[0])) + l0, o0 = fd_act<ACT2>(fmaf(fd_w16_lo(T{}, sk[2 * p + 1]), s2[0], t2[0])) + l0;
+                const float e1 = fd_act<ACT2>(fmaf(fd_w16_hi(T{}, sk[2 * p]), s2[1], t2[1])) + l1, o1 = fd_act<ACT2>(fmaf(fd_w16_hi(T{}, sk[2 * p + 1]), s2[1], t2[1])) + l1;
+                const bool v = rv && pin[p];                 // (zero padding of the ACTIVATED, summed input)
+                dst[p][0] = v ? fd_pack2(T{}, e0, o0) : 0u; dst[p][1] = v ? fd_pack2(T{}, e1, o1) : 0u;
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                dst[4 + p][0] = fd_perm(dst[p + 1][0], dst[p][0], FD_PERM_SHIFT1);
+                dst[4 + p][1] = fd_perm(dst[p + 1][1], dst[p][1], FD_PERM_SHIFT1);
+            }
+        };
+        // the dz pairs of the strip's 4 pixels of one row
+        auto make_dz = [&](unsigned (&dz)[2][2], const unsigned (&g)[4], const unsigned (&z)[4]) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const float d00 = fd_dz(fd_w16_lo(T{}, g[2 * j2]), fd_w16_lo(T{}, z[2 * j2]), cA[0], c1[0], cM[0], c2[0]);
+                const float d01 = fd_dz(fd_w16_lo(T{}, g[2 * j2 + 1]), fd_w16_lo(T{}, z[2 * j2 + 1]), cA[0], c1[0], cM[0], c2[0]);
+                const float d10 = fd_dz(fd_w16_hi(T{}, g[2 * j2]), fd_w16_hi(T{}, z[2 * j2]), cA[1], c1[1], cM[1], c2[1]);
+                const float d11 = fd_dz(fd_w16_hi(T{}, g[2 * j2 + 1]), fd_w16_hi(T{}, z[2 * j2 + 1]), cA[1], c1[1], cM[1], c2[1]);
+                dz[j2][0] = fd_pack2(T{}, d00, d01); dz[j2][1] = fd_pack2(T{}, d10, d11);
+            }
+        };
+        // dz row y (pairs of the strip's 4 pixels) against the window: SB = slot of input row y - 2
+        auto taps = [&](auto SB, const unsigned (&dz)[2][2]) FD_INLINE_LAMBDA {
+            constexpr int sb = decltype(SB)::value;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const unsigned (&R)[7][2] = win[(sb + ky) % 5];
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    // input pixels (x + kx - 2, x + kx - 1) of dz pixels (x, x + 1): even kx -> the loaded pair kx / 2 (+ 1 for the strip's second dz pair),
+                    // odd kx -> the shifted pair (kx - 1) / 2 (+ 1)
+                    const int p0 = (kx & 1) ? 4 + (kx >> 1) : (kx >> 1);
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        fd_dot2_acc(T{}, dz[0][ch], R[p0][ch], acc[ky * 5 + kx][ch]);
+                        fd_dot2_acc(T{}, dz[1][ch], R[p0 + 1][ch], acc[ky * 5 + kx][ch]);
+                    }
+                }
+            }
+        };
+        const int n_it = (y1 - y0 + 4) >> 1;
+        issue(0);
+        auto step = [&](auto PH, int it) FD_INLINE_LAMBDA {
+            constexpr int ph = decltype(PH)::value;
+            const bool rv = nv;
+            unsigned hold[7][2], dza[2][2], dzb[2][2];
+            convert(win[(2 * ph) % 5], nsk[0], rv);
+            convert(hold, nsk[1], rv);                       // (row r + 1 takes the slot of row r - 4, which dz row r - 2 still reads)
+            if (it >= 2) { make_dz(dza, ng[0], nz[0]); make_dz(dzb, ng[1], nz[1]); }
+            if (it + 1 < n_it) issue(it + 1);                // everything the next step reads flies under this step's 200 dot2
+            if (it >= 2) taps(fd_int<(2 * ph + 1) % 5>{}, dza);      // dz row r - 2: input rows r - 4 .. r
+#pragma unroll
+            for (int p = 0; p < 7; ++p) { win[(2 * ph + 1) % 5][p][0] = hold[p][0]; win[(2 * ph + 1) % 5][p][1] = hold[p][1]; }
+            if (it >= 2) taps(fd_int<(2 * ph + 2) % 5>{}, dzb);      // dz row r - 1: input rows r - 3 .. r + 1
+        };
+        for (int it0 = 0; it0 < n_it; it0 += 5) {
+            step(fd_int<0>{}, it0);
+            if (it0 + 1 < n_it) step(fd_int<1>{}, it0 + 1);
+            if (it0 + 2 < n_it) step(fd_int<2>{}, it0 + 2);
+            if (it0 + 3 < n_it) step(fd_int<3>{}, it0 + 3);
+            if (it0 + 4 < n_it) step(fd_int<4>{}, it0 + 4);
+        }
+    }
+    // ---- the workgroup's partial row: the two strips of a wave, then the four waves through LDS [wave][25][64 channels]
+#pragma unroll
+    for (int t = 0; t < 25; ++t) { acc[t][0] += __shfl_xor(acc[t][0], 32); acc[t][1] += __shfl_xor(acc[t][1], 32); }
+    if (lane < 32) {
+#pragma unroll
+        for (int t = 0; t < 25; ++t) { red[(wave * 25 + t) * 64 + 2 * l] = acc[t][0]; red[(wave * 25 + t) * 64 + 2 * l + 1] = acc[t][1]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 25 * 64; i += 256) {
+        const int t = i >> 6, ch = i & 63;
+        if (c0 + ch < cend)
+            a.wpart[(row_blk * 25 + t) * C + c0 + ch] = (red[(0 * 25 + t) * 64 + ch] + red[(1 * 25 + t) * 64 + ch]) + (red[(2 * 25 + t) * 64 + ch] + red[(3 * 25 + t) * 64 + ch]);
+    }
+}
+
+// grid (wgs_d + wgs_w, channel blocks of 64, images) through fd_xcd_image_map; block 256; W % 4 == 0, H even, C % 8 == 0, image bytes < 2^31
+template <typename T, int ACT1, int ACT2>
+__global__ void __launch_bounds__(256) FD_DW5B_ATTR
+fd_dw5_bwd_rows(const fd_dw5_bwd_args<T> a)
+{
+    __shared__ float red[4 * 25 * 64];
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int c0 = blk.y * 64, n = blk.z;
+    if (blk.x < a.wgs_d) fd_dw5_dgrad_rows_body<T, ACT1, ACT2>(a, red, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
+    else fd_dw5_wgrad_rows_body<T, ACT1, ACT2>(a, red, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
+}

@@ -3,6 +3,7 @@
 #include "fd_kernels_train.h"
 #include "fd_kernels_bwd.h"
 #include "fd_kernels_train_h16.h"
+#include "fd_kernels_dw5p_bwd.h"
 #include "../../include/fastdepth_hip.h"
 #include "fd_tuning.h"
 

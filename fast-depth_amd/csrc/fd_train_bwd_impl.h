@@ -205,6 +205,30 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     if (L.bwd_fin_rows) lds += (size_t)4 * cb * 4;          // + the coefficient block of the in-kernel finalisation (fd_bn_bwd_fin::cf_off)
     if (lds > 160 * 1024) return fail(FD_ERR_INVALID, "depthwise backward pair: LDS request %zu exceeds 160 KiB", lds);
     const int kk = K * K;
+    // 16-bit plans, 5x5 on up2 + skip (decode_conv3 / 4 / 5 .0): both gradients on the row-walking pixel-pair kernel (fd_kernels_dw5p_bwd.h) -- one launch,
+    // backward-data workgroups first, then the weight-gradient workgroups of the same image (same XCD: the second role finds G / z in its L2)
+    if constexpr (K == 5 && S == 1 && MODE == 2 && ADD_SG == 0 && !std::is_same<T, float>::value) {
+        if (L.in_w % 4 == 0 && L.in_h % 2 == 0 && L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && !L.bwd_fin_rows &&
+            !(c.p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR))) {
+            fd_dw5_bwd_args<T> b{};
+            b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.Zskip = a.Zskip; b.Gin = a.Gin; b.SGout = a.SGout;
+            b.coef = a.coef; b.w = a.w; b.st_in = a.st_in; b.st_skip = a.st_skip; b.wpart = a.wpart;
+            b.H = L.in_h; b.W = L.in_w; b.C = L.d.cin; b.groups_x = ceil_div(L.in_w, 8);
+            const int bands = std::max(1, (L.in_h + 7) / 14);
+            b.bh_d = b.bh_w = ceil_div(ceil_div(L.in_h, bands), 2) * 2;
+            b.wgs_d = b.wgs_w = ceil_div((long)b.groups_x * ceil_div(L.in_h, b.bh_d), 4);
+            b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs_d * c.p->B);
+            const int wrows = b.wgs_w * c.p->B;
+            if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+            L.lds_rounding = (L.lds_rounding & ~(2 | 8)) | 2 | 8;       // dz and the re-created input rounded to the storage type; the backward-data taps too
+            FD_LAUNCH((fd_dw5_bwd_rows<T, ACT1, ACT2>), dim3((unsigned)(b.wgs_d + b.wgs_w), (unsigned)ceil_div(L.d.cin, 64), (unsigned)c.p->B), dim3(256), 0, c.s, b);
+            int rc5 = check_launch("fd_dw5_bwd_rows");
+            if (rc5) return rc5;
+            *nblk_out = b.wgs_d * c.p->B;
+            return defer_weights(c, b.wpart, wrows, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
+        }
+    }
+    L.lds_rounding &= ~8;
     // The stride-2 3x3 units of the large maps (channel-group count a power of two in 8 ... 64): two register-window kernels without LDS staging
     // (fd_dw3s2_dgrad_rows over input columns, fd_dw3_wgrad_rows over output columns), row strips as high as still leave >= ~1024 workgroups
     {
