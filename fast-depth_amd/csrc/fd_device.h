@@ -456,6 +456,22 @@ __device__ __forceinline__ float fd_dot2(fd_bf16, unsigned a, unsigned b, float 
 // The tap loops of fd_kernels_dw5p.h issue their dot2 in SOURCE order (volatile asm): eight independent accumulation chains interleaved.  Left to
 // itself the compiler runs the chains two at a time (its scheduler minimises live registers; the intrinsic is pure, so sched_barrier does not pin it).
 // fd_dot2_first starts a chain from a third operand (v_dot2_f32_*: no copy of the bias into the accumulator first).
+// HAZARD the compiler cannot see: on gfx90a / gfx940 / gfx950 a register written by a DOT instruction must not be read by a DIFFERENT kind of VALU instruction
+// within 3 wait states (LLVM's GCNHazardRecognizer inserts the s_nop for instructions it knows; inline asm is opaque to it).  Chained dot2 on the same
+// accumulator are fine (the accumulator operand is forwarded); the FIRST other reader is not -- and the compiler is free to schedule that reader right
+// behind the accumulator's last dot2, in between the remaining volatile asm statements.  fd_dot2_done(acc...) is the barrier: a wait of 5 states that every
+// accumulator passes THROUGH (in/out operands of empty volatile asm behind the s_nop), so no reader can be placed before it.  (Measured, round 6:
+// fd_dw5_bwd_rows lost the last tap of one accumulator on hardware -- 4-28 % errors -- while the CPU emulation was exact; tools/microbench/dw5bwd_check.cpp.)
+#ifdef FD_EMU
+template <int N> inline void fd_dot2_done(float (&)[N][2]) {}
+#else
+template <int N> __device__ __forceinline__ void fd_dot2_done(float (&acc)[N][2])
+{
+    asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) { asm volatile("" : "+v"(acc[i][0])); asm volatile("" : "+v"(acc[i][1])); }
+}
+#endif
 #ifdef FD_EMU
 template <typename T> inline void fd_dot2_acc(T, unsigned a, unsigned b, float &acc) { acc = fd_dot2(T{}, a, b, acc); }
 template <typename T> inline float fd_dot2_first(T, unsigned a, unsigned b, float c) { return fd_dot2(T{}, a, b, c); }

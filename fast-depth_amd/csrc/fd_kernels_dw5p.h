@@ -213,6 +213,7 @@ fd_dw5_rows(const T *__restrict__ low, const T *__restrict__ skip, const unsigne
                 }
             }
         }
+        fd_dot2_done(acc);
         if (y < y1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) fd_buf_st32(r_out, oo, (unsigned)y * rowb + (unsigned)j * pxb, fd_dw5_pack_act<T, ACT>(acc[j][0], acc[j][1]));

@@ -155,6 +155,7 @@ fd_dw5_dgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, co
                     }
                 }
             }
+            fd_dot2_done(acc);
             // the gradient of the ACTIVATED skip tensor at full resolution (its source's activation mask is applied by the source's own consumer, which
             // adds this buffer: ADD_SG); the producer's gradient collects its 2 x 2 block
 #pragma unroll
@@ -359,6 +360,7 @@ fd_dw5_wgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, co
         }
     }
     // ---- the workgroup's partial row: the two strips of a wave, then the four waves through LDS [wave][25][64 channels]
+    fd_dot2_done(acc);
 #pragma unroll
     for (int t = 0; t < 25; ++t) { acc[t][0] += __shfl_xor(acc[t][0], 32); acc[t][1] += __shfl_xor(acc[t][1], 32); }
     if (lane < 32) {
@@ -383,4 +385,167 @@ fd_dw5_bwd_rows(const fd_dw5_bwd_args<T> a)
     const int c0 = blk.y * 64, n = blk.z;
     if (blk.x < a.wgs_d) fd_dw5_dgrad_rows_body<T, ACT1, ACT2>(a, red, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
     else fd_dw5_wgrad_rows_body<T, ACT1, ACT2>(a, red, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
+}
+
+// ---- train-mode FORWARD of the same units (replaces fd_dwconv_train<T, 5, 1, 2, ...>: 67 / 43 / 27 us per bf16 step) ---------------------------------
+//   z_out = conv5x5( relu(z_low s1 + t1)^2 + relu6(z_skip s2 + t2) ),  raw (no BatchNorm folded: batch statistics), rounded to the storage type,
+//   + the workgroup's per-channel sums of the ROUNDED values, added to the unit's statistics rows; fin.rows != null: the low-resolution producer's
+//   BatchNorm is finalised here (fd_stat_table_block in the prologue, all four waves; workgroup (0, *, 0) is the writer).
+// fd_dw5_rows with the two BatchNorm + activation transforms on load (once per loaded element; the pair is built by the rounding conversion itself) and
+// the live fp32 taps rounded to 16-bit pairs in the prologue (fd_train_plan_lds_rounding bits 0 and 2).
+// grid (wgs, channel blocks of 64, images) through fd_xcd_image_map; block 256 = 4 independent waves until the end-of-kernel statistics reduction.
+template <typename T, int ACT1, int ACT2>
+__global__ void __launch_bounds__(256) FD_DW5B_ATTR          // (2 waves per SIMD: at 3 the transforms' temporaries spill -- 168 VGPRs + 120 bytes of scratch ran 2.5x longer)
+fd_dw5_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, const T *__restrict__ zskip, const float *__restrict__ st2,
+                  const float *__restrict__ wgt, T *__restrict__ zout, fd_stat_rows sr, int H, int W, int C, int groups_x, int bh, const fd_bn_fin fin)
+{
+    __shared__ double sh[512];
+    __shared__ float s_st[2 * 64];
+    __shared__ float red[4 * 2 * 64];
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int c0 = blk.y * 64, cend = c0 + 64 < C ? c0 + 64 : C, n = blk.z;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = blk.x * 4 + wave;
+    const int band = item / groups_x, sg = item - band * groups_x;
+    const int y0 = band * bh, y1 = y0 + bh < H ? y0 + bh : H;
+    const int l = lane & 31, xs = 4 * (2 * sg + (lane >> 5)), c = c0 + 2 * l;
+    const bool live = y0 < H && c < cend && xs < W;
+    const int Hs = H >> 1, Ws = W >> 1;
+    if (fin.rows) fd_stat_table_block(fin, sh, s_st, c0, 64, C, (int)threadIdx.x, blk.x == 0 && blk.z == 0);
+    float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
+    if (live) {
+        unsigned w[5][6][2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float *wc = wgt + (long)(c + ch) * 25;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const float f0 = wc[ky * 5 + 0], f1 = wc[ky * 5 + 1], f2 = wc[ky * 5 + 2], f3 = wc[ky * 5 + 3], f4 = wc[ky * 5 + 4];
+                w[ky][0][ch] = fd_pack2(T{}, f0, f1); w[ky][1][ch] = fd_pack2(T{}, f2, f3); w[ky][2][ch] = fd_pack2(T{}, f4, 0.f);
+                w[ky][3][ch] = fd_pack2(T{}, 0.f, f0); w[ky][4][ch] = fd_pack2(T{}, f1, f2); w[ky][5][ch] = fd_pack2(T{}, f3, f4);
+            }
+        }
+        float s1[2], t1[2], s2[2], t2[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (fin.rows) { s1[ch] = s_st[2 * l + ch]; t1[ch] = s_st[64 + 2 * l + ch]; }
+            else { s1[ch] = st1[FD_ST_SCALE * C + c + ch]; t1[ch] = st1[FD_ST_SHIFT * C + c + ch]; }
+            s2[ch] = st2[FD_ST_SCALE * C + c + ch]; t2[ch] = st2[FD_ST_SHIFT * C + c + ch];
+        }
+        unsigned so[4], lo_[4];
+        bool pin[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int x = xs - 2 + 2 * p;
+            pin[p] = x >= 0 && x < W;
+            so[p] = pin[p] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+            lo_[p] = pin[p] ? (fd_mul24((unsigned)(x >> 1), (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned rowb = fd_mul24((unsigned)W, (unsigned)C) * 2u, pxb = (unsigned)C * 2u, rowl = rowb >> 1;
+        const fd_bufrsrc r_sk = fd_make_rsrc(zskip + (long)n * H * W * C, (unsigned)H * rowb), r_lo = fd_make_rsrc(zin + (long)n * Hs * Ws * C, (unsigned)Hs * rowl);
+        const fd_bufrsrc r_out = fd_make_rsrc(zout + (long)n * H * W * C, (unsigned)H * rowb);
+        const unsigned oo = (fd_mul24((unsigned)xs, (unsigned)C) + (unsigned)c) * 2u;
+
+        unsigned ns[2][8], nl[4];
+        bool nv = false;
+        auto issue = [&](int it) FD_INLINE_LAMBDA {
+            const int r = y0 - 2 + 2 * it;
+            nv = r >= 0 && r < H;
+            if (!nv) return;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const unsigned ro = (unsigned)(r + rr) * rowb;
+                    ns[rr][2 * p] = fd_buf_ld32(r_sk, so[p], ro); ns[rr][2 * p + 1] = fd_buf_ld32(r_sk, so[p], ro + pxb);
+                }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) nl[p] = fd_buf_ld32(r_lo, lo_[p], (unsigned)(r >> 1) * rowl);
+        };
+        unsigned win[5][4][2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { win[q][p][0] = 0u; win[q][p][1] = 0u; }
+        auto convert = [&](unsigned (&dst)[4][2], const unsigned (&sk)[8], bool rv) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float l0 = fd_act<ACT1>(fmaf(fd_w16_lo(T{}, nl[p]), s1[0], t1[0])), l1 = fd_act<ACT1>(fmaf(fd_w16_hi(T{}, nl[p]), s1[1], t1[1]));
+                const float e0 = fd_act<ACT2>(fmaf(fd_w16_lo(T{}, sk[2 * p]), s2[0], t2[0])) + l0, o0 = fd_act<ACT2>(fmaf(fd_w16_lo(T{}, sk[2 * p + 1]), s2[0], t2[0])) + l0;
+                const float e1 = fd_act<ACT2>(fmaf(fd_w16_hi(T{}, sk[2 * p]), s2[1], t2[1])) + l1, o1 = fd_act<ACT2>(fmaf(fd_w16_hi(T{}, sk[2 * p + 1]), s2[1], t2[1])) + l1;
+                const bool v = rv && pin[p];                 // (zero padding of the ACTIVATED, summed input)
+                dst[p][0] = v ? fd_pack2(T{}, e0, o0) : 0u; dst[p][1] = v ? fd_pack2(T{}, e1, o1) : 0u;
+            }
+        };
+        auto out_row = [&](auto SB, int y) FD_INLINE_LAMBDA {
+            constexpr int sb = decltype(SB)::value;
+            float acc[4][2];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const unsigned (&R)[4][2] = win[(sb + ky) % 5];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        if (ky == 0 && k == 0) {
+                            acc[0][ch] = fd_dot2_first(T{}, R[k][ch], w[ky][k][ch], 0.0f);
+                            acc[1][ch] = fd_dot2_first(T{}, R[k][ch], w[ky][3 + k][ch], 0.0f);
+                            acc[2][ch] = fd_dot2_first(T{}, R[k + 1][ch], w[ky][k][ch], 0.0f);
+                            acc[3][ch] = fd_dot2_first(T{}, R[k + 1][ch], w[ky][3 + k][ch], 0.0f);
+                        } else {
+                            fd_dot2_acc(T{}, R[k][ch], w[ky][k][ch], acc[0][ch]);
+                            fd_dot2_acc(T{}, R[k][ch], w[ky][3 + k][ch], acc[1][ch]);
+                            fd_dot2_acc(T{}, R[k + 1][ch], w[ky][k][ch], acc[2][ch]);
+                            fd_dot2_acc(T{}, R[k + 1][ch], w[ky][3 + k][ch], acc[3][ch]);
+                        }
+                    }
+                }
+            }
+            fd_dot2_done(acc);
+            if (y < y1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned packed = fd_pack2(T{}, acc[j][0], acc[j][1]);
+                    fd_buf_st32(r_out, oo, (unsigned)y * rowb + (unsigned)j * pxb, packed);
+                    const float g0 = fd_w16_lo(T{}, packed), g1 = fd_w16_hi(T{}, packed);      // statistics of the stored (rounded) output
+                    ssum0 += g0; ssum1 += g1; ssq0 = fmaf(g0, g0, ssq0); ssq1 = fmaf(g1, g1, ssq1);
+                }
+            }
+        };
+        const int n_it = (y1 - y0 + 4) >> 1;
+        issue(0);
+        auto step = [&](auto PH, int it) FD_INLINE_LAMBDA {
+            constexpr int ph = decltype(PH)::value;
+            const bool rv = nv;
+            unsigned hold[4][2];
+            convert(win[(2 * ph) % 5], ns[0], rv);
+            convert(hold, ns[1], rv);
+            if (it + 1 < n_it) issue(it + 1);
+            if (it >= 2) out_row(fd_int<(2 * ph + 1) % 5>{}, y0 - 4 + 2 * it);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { win[(2 * ph + 1) % 5][p][0] = hold[p][0]; win[(2 * ph + 1) % 5][p][1] = hold[p][1]; }
+            if (it >= 2) out_row(fd_int<(2 * ph + 2) % 5>{}, y0 - 3 + 2 * it);
+        };
+        for (int it0 = 0; it0 < n_it; it0 += 5) {
+            step(fd_int<0>{}, it0);
+            if (it0 + 1 < n_it) step(fd_int<1>{}, it0 + 1);
+            if (it0 + 2 < n_it) step(fd_int<2>{}, it0 + 2);
+            if (it0 + 3 < n_it) step(fd_int<3>{}, it0 + 3);
+            if (it0 + 4 < n_it) step(fd_int<4>{}, it0 + 4);
+        }
+    }
+    ssum0 += __shfl_xor(ssum0, 32); ssum1 += __shfl_xor(ssum1, 32); ssq0 += __shfl_xor(ssq0, 32); ssq1 += __shfl_xor(ssq1, 32);
+    if (lane < 32) {
+        red[(wave * 2 + 0) * 64 + 2 * l] = ssum0; red[(wave * 2 + 0) * 64 + 2 * l + 1] = ssum1;
+        red[(wave * 2 + 1) * 64 + 2 * l] = ssq0; red[(wave * 2 + 1) * 64 + 2 * l + 1] = ssq1;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        if (c0 + ch < cend) {
+            const float v = (red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch]) + (red[(2 * 2 + which) * 64 + ch] + red[(3 * 2 + which) * 64 + ch]);
+            fd_stat_add<FD_STAT_FWD>(sr, (long)n * gridDim.x + blk.x, C, which, c0 + ch, v);
+        }
+    }
 }

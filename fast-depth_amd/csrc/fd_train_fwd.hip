@@ -4,6 +4,7 @@
 #include "fd_kernels_train.h"
 #include "fd_kernels_gemm16_f32.h"
 #include "fd_kernels_train_h16.h"
+#include "fd_kernels_dw5p_bwd.h"
 #include "fd_kernels_io.h"
 #include "../../include/fastdepth_hip.h"
 #include "fd_tuning.h"

@@ -8,7 +8,14 @@ template <typename T, int ACT1, int ACT2>
 int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zskip, const float *st2, const float *w,
                     T *zout, fd_stat_rows part, hipStream_t s, int batch, const fd_bn_fin &fin)
 {
-    L.lds_rounding = (L.lds_rounding & ~1) | ((!L.rows_th && L.dw_n == 8) ? 1 : 0);
+    L.lds_rounding = (L.lds_rounding & ~(1 | 4)) | ((!L.rows_th && L.dw_n == 8) ? 1 : 0);
+    if (L.dw5_groups) {                                       // 16-bit plans, 5x5 on up2 + skip: row-walking pixel-pair kernel (input AND taps rounded to the storage type)
+        if constexpr (!std::is_same<T, float>::value) {
+            L.lds_rounding |= 1 | 4;
+            FD_LAUNCH((fd_dw5_rows_train<T, ACT1, ACT2>), L.grid, dim3(256), 0, s, zin, st1, zskip, st2, w, zout, part, L.in_h, L.in_w, L.d.cin, L.dw5_groups, L.dw5_bh, fin);
+            return check_launch("fd_dw5_rows_train");
+        }
+    }
     if (L.rows_th) {                                          // register-window kernel (3x3, plain input, large maps)
         if (L.d.stride == 1) FD_LAUNCH((fd_dw3_rows_train<T, 1, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th, fin);
         else FD_LAUNCH((fd_dw3_rows_train<T, 2, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th, fin);
@@ -295,12 +302,23 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                     L.lds = 0;
                 }
             }
+            // 16-bit plans, 5x5 on up2 + skip (decode_conv3 / 4 / 5 .0): the row-walking pixel-pair kernel (fd_kernels_dw5p_bwd.h: fd_dw5_rows_train); bands of ~14 rows
+            if (h16 && k5 && d.stride == 1 && L.mode == 2 && L.out_w % 4 == 0 && L.in_h % 2 == 0 && d.cin % 8 == 0 && (double)L.in_h * L.in_w * d.cin * 2.0 < 2147483648.0 &&
+                !(tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_FORCE_DW_H8))) {
+                L.dw5_groups = ceil_div(L.out_w, 8);
+                const int bands = std::max(1, (L.out_h + 7) / 14);
+                L.dw5_bh = ceil_div(ceil_div(L.out_h, bands), 2) * 2;
+                const int wgs = ceil_div((long)L.dw5_groups * ceil_div(L.out_h, L.dw5_bh), 4);
+                L.grid = dim3(wgs, ceil_div(d.cin, 64), batch);
+                L.nblk = wgs * batch;
+                L.lds = 0;
+            }
             if (L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && !(L.rows_th && d.cin > 256) &&
                 p->layers[d.src].nr_f <= (L.rows_th ? FD_STAT_FIN_MAX_ROWS_ALL : FD_STAT_FIN_MAX_ROWS_BLOCK)) {
                 // the producer's BatchNorm is finalised by this kernel's workgroups from the producer's statistics rows (fd_stat_table_block in the LDS-tiled
                 // kernel, which keeps the block's (scale, shift) behind its tap table; the register-window kernel holds all C <= 256 channels in its static LDS)
                 p->layers[d.src].fin_by_consumer = true;
-                if (!L.rows_th) L.lds += (size_t)2 * cb * 4;
+                if (!L.rows_th && !L.dw5_groups) L.lds += (size_t)2 * cb * 4;
             }
             const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x

@@ -57,6 +57,7 @@ struct fd_train_layer {
     mutable int lds_rounding = 0;                             // fd_train_plan_lds_rounding: set by the launches of the last forward / backward
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
     int rows_th = 0;                                          // > 0: the forward runs on fd_dw3_rows_train with row strips of this height
+    int dw5_groups = 0, dw5_bh = 0;                           // > 0: the forward runs on fd_dw5_rows_train (16-bit plans, 5x5 on up2 + skip): strip pairs per row, rows per band
     int stem_band = 0;                                        // floats of the stem kernels' input band in LDS
     int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels
     int chunk = 0;                                            // stem

@@ -46,7 +46,7 @@ void fd_tuning_next(uint32_t mask);
 /* Test hook of the layer-local train parity (tests/harness.py: the fp64 single-unit reference rounds exactly where the kernels round): which
  * kernels of depthwise unit `layer` kept their LDS patches in the 16-bit storage type during the LAST forward / backward of this plan --
  * bit 0: the forward kernel rounded its (activated, upsampled, skip-added) conv input; bit 1: the backward kernels rounded dz and the
- * re-created conv input; bit 3: the backward-data kernel rounded its taps as well (fd_dw5_bwd_rows).  0 for fp32 plans, the 4-channel form and the
+ * re-created conv input; bit 2 / bit 3: the forward / the backward-data kernel rounded its taps as well (fd_dw5_rows_train / fd_dw5_bwd_rows).  0 for fp32 plans, the 4-channel form and the
  * register-window kernels.  -1: bad arguments. */
 struct fd_train_plan;
 int fd_train_plan_lds_rounding(const struct fd_train_plan *plan, int32_t layer);

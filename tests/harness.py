@@ -296,14 +296,14 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
     ST = [tp.tensor(i, 2).double()[0, :, :, 0].t() for i in range(n)]
     G = [tp.tensor(i, 1).double() for i in range(n)]
     # which depthwise kernels kept their LDS patches in the 16-bit storage type (private test hook, csrc/fd_tuning.h): bit 0 forward, bit 1 backward,
-    # bit 3: the backward-data kernel also rounds its taps (fd_dw5_bwd_rows)
+    # bit 2 / bit 3: the forward / the backward-data kernel also rounds its taps (fd_dw5_rows_train / fd_dw5_bwd_rows)
     tp.lib.fd_train_plan_lds_rounding.restype = ctypes.c_int
     tp.lib.fd_train_plan_lds_rounding.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lds_round = [max(tp.lib.fd_train_plan_lds_rounding(tp.h, i), 0) for i in range(n)]
     tp.lib.fd_train_plan_unit_kernels.restype = ctypes.c_int
     tp.lib.fd_train_plan_unit_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     forms = [max(tp.lib.fd_train_plan_unit_kernels(tp.h, i), 0) for i in range(n)]
-    rep_info = {"dw_units_with_16bit_lds_patches": sum(1 for v in lds_round if (v & 3) and not (v & 8)), "dw_units_on_dw5_bwd_rows": sum(1 for v in lds_round if v & 8), "pw_units_on_gemm16": sum(1 for v in forms if v & 1),
+    rep_info = {"dw_units_with_16bit_lds_patches": sum(1 for v in lds_round if (v & 3) and not (v & (4 | 8))), "dw_units_on_dw5_bwd_rows": sum(1 for v in lds_round if v & 8), "dw_units_on_dw5_rows_train": sum(1 for v in lds_round if v & 4), "pw_units_on_gemm16": sum(1 for v in forms if v & 1),
                 "units_finalised_by_consumer": sum(1 for v in forms if v & 2), "units_finalising_their_own_backward": sum(1 for v in forms if v & 4)}
     consumers = {}
     for i in range(n):
@@ -360,9 +360,9 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
         # 16-bit LDS patches (fd_lane<T, 8> depthwise kernels): the conv input is rounded to the storage type on its way into LDS -- straight-through
         # for autograd, so that the gradient below flows to `a` / `ask` as the kernels compute it
         st_round = lambda t: t + (rnd(t.detach()) - t.detach())
-        zr = F.conv2d(st_round(inp) if (lds_round[i] & 1) else inp, w, None, d.stride, d.ksize // 2, 1, groups)
+        zr = F.conv2d(st_round(inp) if (lds_round[i] & 1) else inp, st_round(w) if (lds_round[i] & 4) else w, None, d.stride, d.ksize // 2, 1, groups)
         note("z", relmax(Z[i], zr.detach()), i)
-        if (lds_round[i] & 1) != ((lds_round[i] >> 1) & 1) or (lds_round[i] & 8):     # the backward kernels stage the input their own way
+        if (lds_round[i] & 1) != ((lds_round[i] >> 1) & 1) or (lds_round[i] & (4 | 8)):     # the backward kernels stage the input their own way
             # (bit 3: the backward-DATA kernel rounds its taps to the storage type -- straight-through, so that w.grad below is the correlation of dz
             # with the input as the weight-gradient kernel computes it, and a.grad flows through the rounded taps)
             zr = F.conv2d(st_round(inp) if (lds_round[i] & 2) else inp, st_round(w) if (lds_round[i] & 8) else w, None, d.stride, d.ksize // 2, 1, groups)
