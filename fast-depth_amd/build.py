@@ -23,11 +23,13 @@ def _deps():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "_obj") + [os.path.join(HERE, "..", "include", "fastdepth_hip.h")]
 
 
-def source_hash():
-    """First 16 hex digits of the SHA-256 over the library's sources (file names + contents, sorted): compiled into the binary as FD_SOURCE_HASH and
-    reported by fd_version(), so that whoever loads the .so can tell whether it was built from the sources next to it."""
+def source_hash(extra=()):
+    """First 16 hex digits of the SHA-256 over the library's sources (file names + contents, sorted) AND the compiler flags (CFLAGS + `extra`:
+    a build with other -D switches is another library -- ADVICE r05): compiled into the binary as FD_SOURCE_HASH and reported by fd_version(),
+    so that whoever loads the .so can tell whether it was built from the sources next to it."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(CFLAGS + list(extra)).encode() + b"\0")
     for d in _deps():
         h.update(os.path.basename(d).encode() + b"\0")
         with open(d, "rb") as f:
@@ -46,10 +48,10 @@ def built_hash():
         return ""
 
 
-def _stale():
+def _stale(extra=()):
     if not os.path.exists(OUT):
         return True
-    return built_hash() != source_hash()       # content, not mtimes: a checkout or a copy must neither force nor hide a rebuild
+    return built_hash() != source_hash(extra)       # content, not mtimes: a checkout or a copy must neither force nor hide a rebuild
 
 
 def compile_and_link(out, extra=(), tag=""):
@@ -59,7 +61,7 @@ def compile_and_link(out, extra=(), tag=""):
     for src in SOURCES:
         obj = os.path.join(OBJ, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
         objs.append(obj)
-        procs.append((src, subprocess.Popen([HIPCC] + CFLAGS + ['-DFD_SOURCE_HASH="%s"' % source_hash()] + list(extra) + ["-c", src, "-o", obj])))
+        procs.append((src, subprocess.Popen([HIPCC] + CFLAGS + ['-DFD_SOURCE_HASH="%s"' % source_hash(extra)] + list(extra) + ["-c", src, "-o", obj])))
     failed = [src for src, p in procs if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
@@ -73,10 +75,10 @@ LAST_BUILD_MODE = ""
 def build(force=False, extra=()):
     """Returns the library path; LAST_BUILD_MODE says what happened ("compiled" / "reused: stamp == source hash")."""
     global LAST_BUILD_MODE
-    if not force and not _stale():
-        LAST_BUILD_MODE = "reused (stamp %s == hash of the sources in the tree)" % built_hash()
+    if not force and not _stale(extra):
+        LAST_BUILD_MODE = "reused (stamp %s == hash of the sources + flags in the tree)" % built_hash()
         return OUT
-    LAST_BUILD_MODE = "compiled (sources %s)" % source_hash()
+    LAST_BUILD_MODE = "compiled (sources + flags %s)" % source_hash(extra)
     return compile_and_link(OUT, extra)
 
 

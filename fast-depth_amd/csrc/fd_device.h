@@ -535,6 +535,7 @@ __device__ __forceinline__ unsigned fd_pair_sum(fd_bf16, unsigned a, unsigned b)
 // Layout of a unit's rows: int64 [nr][FD_STAT_BINS][2][cs]  (2 = first / second sum; cs = channel pitch >= C, a multiple of 16: the memory side
 // serialises atomics per 128-byte LINE and instruction, so no two (row, bin, sum) slots share a line).  The plan zeroes all rows of a step with one memset.
 #define FD_STAT_BINS 3
+#define FD_STAT_POISON (1LL << 62)      /* added to the highest bin by an Inf / NaN partial */
 #define FD_STAT_MAX_ROWS 16
 #define FD_STAT_FWD 0
 #define FD_STAT_BWD 1
@@ -559,6 +560,10 @@ __device__ __forceinline__ void fd_stat_add(const fd_stat_rows &d, long blk, int
     const unsigned u = __builtin_bit_cast(unsigned, v);
     int e = (int)((u >> 23) & 255u) - 127;
     if (e == -127) return;                                  // +-0 and denormals: nothing to add
+    if (e == 128) {                                         // Inf / NaN partial (a diverged step): POISON the column -- fd_stat_total returns NaN, as nn.BatchNorm2d's
+        fd_atomic_add_i64(d.rows + ((((long)(blk & (d.nr - 1)) * FD_STAT_BINS + 2) * 2 + which) * d.cs + c), FD_STAT_POISON);   // statistics would be
+        return;
+    }
     const int bin = e < F::lo ? 0 : (e < F::hi ? 1 : 2);
     const int frac = bin == 0 ? F::f0 : (bin == 1 ? F::f1 : F::f2);
     if (e > 47 - frac) e = 47 - frac;                       // (saturation, highest bin only: |partial| >= 2^40 forward / 2^16 backward)
@@ -579,6 +584,8 @@ __device__ __forceinline__ double fd_stat_total(const long long *__restrict__ ro
         const long long *p = rows + (((long)r * FD_STAT_BINS) * 2 + which) * C + c;
         a0 += p[0]; a1 += p[2 * (long)C]; a2 += p[4 * (long)C];
     }
+    // (a poisoned column: the highest bin holds at most 2^14 partials below 2^48 in magnitude, i.e. |a2| < 2^62 unless FD_STAT_POISON = 2^62 was added)
+    if (a2 >= FD_STAT_POISON / 2 || a2 <= -(FD_STAT_POISON / 2)) return __builtin_nan("");
     return ldexp((double)a0, -F::f0) + ldexp((double)a1, -F::f1) + ldexp((double)a2, -F::f2);
 }
 

@@ -549,3 +549,264 @@ fd_dw5_rows_train(const T *__restrict__ zin, const float *__restrict__ st1, cons
         }
     }
 }
+
+// ======================================================================================================================================================
+// Backward of the depthwise 3x3 stride-1 units on plain inputs (conv1.0 / conv3.0 / conv5.0 ...; autograd of reference imagenet/mobilenet.py:31-33) for the
+// 16-bit train plans: the same row-walking wave, fp32 window.  Replaces the paired launch fd_dw_bwd<T, 3, 1, 0, ...> there (47 / 51 / 31 us per bf16 step).
+// With 9 taps the arithmetic is cheaper as plain fp32 FMA (2 issue cycles each on gfx950: 18 cycles per value) than as dot2 on pixel pairs (6 x 4 cycles
+// plus the pair packing), and a 3-row window of fp32 values is only 36 registers for a lane's 2 channels x 6 columns -- so nothing is rounded here: dz,
+// the re-created input and the taps stay fp32 (fd_train_plan_lds_rounding reports 0 for these units).
+//   role D: dz rows (G, z: 6 columns x 2 channels per lane) -> d_in = correlation with the flipped taps -> G_in = mask(y_in) * d_in, stored rounded, and its
+//           BatchNorm-backward sums; role W: the input relu6(z_in s + t) re-created on load (6 columns), dz of the lane's 4 columns, 9 x 2 accumulators.
+// One output row per step, the walk unrolled over the 3-row window's period.  Any even W (columns beyond the row: out-of-range loads, predicated stores).
+// ======================================================================================================================================================
+template <typename T> struct fd_dw3_bwd_args {
+    const T *G, *Z, *Zin;              // this unit's dL/dy and raw output; the raw output of its producer
+    T *Gin;                            // gradient handed to the producer
+    const float *coef, *w, *st_in;     // BN-backward coefficients [4][C] of this unit, live taps [C][9], table [4][C] of the producer
+    fd_stat_rows sr;                   // BatchNorm-backward statistics rows of the producer
+    float *wpart;                      // weight-gradient partial rows: row = image * wgs_w + workgroup, [9][C]
+    int H, W, C, groups_x;             // map, channels, strip groups per row (ceil(W / (4 * strips per wave)))
+    int bh_d, bh_w, wgs_d, wgs_w;      // rows per band and workgroups per image and channel block of the two roles
+};
+
+template <typename T, int ACT1, int CL>      // CL = channel lanes per strip: 32 (a wave = 2 strips x 64 channels) or 16 (4 strips x 32 channels: conv1.0)
+__device__ __forceinline__ void
+fd_dw3_dgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long stat_blk)
+{
+    const int H = a.H, W = a.W, C = a.C;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = wg * 4 + wave;
+    const int band = item / a.groups_x, sg = item - band * a.groups_x;
+    constexpr int CB = 2 * CL, SPW = 64 / CL;
+    const int cend = c0 + CB < C ? c0 + CB : C;
+    const int y0 = band * a.bh_d, y1 = y0 + a.bh_d < H ? y0 + a.bh_d : H;
+    const int l = lane % CL, xs = 4 * (SPW * sg + lane / CL), c = c0 + 2 * l;
+    const bool live = y0 < H && c < cend && xs < W;
+    float sg0 = 0.f, sg1 = 0.f, sx0 = 0.f, sx1 = 0.f;
+    if (live) {
+        float wf[3][3][2];                                   // flipped taps: d_in[y][x] = sum dz[y - 1 + ky][x - 1 + kx] * w[2 - ky][2 - kx]
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wf[t / 3][t % 3][ch] = a.w[(long)(c + ch) * 9 + (8 - t)];
+        float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], m1[2], i1[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch]; m1[ch] = a.st_in[FD_ST_MEAN * C + c + ch]; i1[ch] = a.st_in[FD_ST_INVSTD * C + c + ch];
+        }
+        unsigned so[6];                                      // byte offsets of columns xs - 1 ... xs + 4 in a row (out of range: outside the image)
+        bool pin[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int x = xs - 1 + i;
+            pin[i] = x >= 0 && x < W;
+            so[i] = pin[i] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned rowb = fd_mul24((unsigned)W, (unsigned)C) * 2u;
+        const fd_bufrsrc r_g = fd_make_rsrc(a.G + (long)n * H * W * C, (unsigned)H * rowb), r_z = fd_make_rsrc(a.Z + (long)n * H * W * C, (unsigned)H * rowb);
+        const fd_bufrsrc r_zi = fd_make_rsrc(a.Zin + (long)n * H * W * C, (unsigned)H * rowb), r_gi = fd_make_rsrc(a.Gin + (long)n * H * W * C, (unsigned)H * rowb);
+        unsigned ng[6], nz[6], nzi[4];                        // in flight: G / z of the next step's dz row, z_in under the next step's output row
+        bool nv = false;
+        // step `it`: dz row r = y0 - 1 + it enters the window, d_in row r - 1 (it >= 2) leaves
+        auto issue = [&](int it) FD_INLINE_LAMBDA {
+            const int r = y0 - 1 + it;
+            nv = r >= 0 && r < H;
+            if (nv) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { ng[i] = fd_buf_ld32(r_g, so[i], (unsigned)r * rowb); nz[i] = fd_buf_ld32(r_z, so[i], (unsigned)r * rowb); }
+            }
+            if (it >= 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nzi[j] = fd_buf_ld32(r_zi, so[1 + j], (unsigned)(r - 1) * rowb);
+            }
+        };
+        float win[3][6][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { win[q][i][0] = 0.f; win[q][i][1] = 0.f; }
+        const int n_it = (y1 - y0) + 2;
+        issue(0);
+        auto step = [&](auto PH, int it) FD_INLINE_LAMBDA {
+            constexpr int ph = decltype(PH)::value;                 // row r lives in win[it % 3]
+            const bool rv = nv;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool v = rv && pin[i];                 // (dz of a pixel outside the image is 0, not dz(0, 0))
+                const float d0 = fd_dz(fd_w16_lo(T{}, ng[i]), fd_w16_lo(T{}, nz[i]), cA[0], c1[0], cM[0], c2[0]);
+                const float d1 = fd_dz(fd_w16_hi(T{}, ng[i]), fd_w16_hi(T{}, nz[i]), cA[1], c1[1], cM[1], c2[1]);
+                win[ph][i][0] = v ? d0 : 0.f; win[ph][i][1] = v ? d1 : 0.f;
+            }
+            unsigned zi[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zi[j] = nzi[j];
+            if (it + 1 < n_it) issue(it + 1);
+            if (it >= 2) {
+                const int y = y0 + it - 2;                   // rows y - 1, y, y + 1 = slots (ph + 1) % 3, (ph + 2) % 3, ph
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            d0 = fmaf(win[(ph + 1 + ky) % 3][j + kx][0], wf[ky][kx][0], d0);
+                            d1 = fmaf(win[(ph + 1 + ky) % 3][j + kx][1], wf[ky][kx][1], d1);
+                        }
+                    const float z0 = fd_w16_lo(T{}, zi[j]), z1 = fd_w16_hi(T{}, zi[j]);
+                    const unsigned packed = fd_pack2(T{}, d0 * fd_actmask<ACT1>(fmaf(z0, s1[0], t1[0])), d1 * fd_actmask<ACT1>(fmaf(z1, s1[1], t1[1])));
+                    if (xs + j < W) {
+                        fd_buf_st32(r_gi, so[1 + j], (unsigned)y * rowb, packed);
+                        const float g0 = fd_w16_lo(T{}, packed), g1 = fd_w16_hi(T{}, packed);
+                        sg0 += g0; sg1 += g1;
+                        sx0 = fmaf(g0, (z0 - m1[0]) * i1[0], sx0); sx1 = fmaf(g1, (z1 - m1[1]) * i1[1], sx1);
+                    }
+                }
+            }
+        };
+        for (int it0 = 0; it0 < n_it; it0 += 3) {
+            step(fd_int<0>{}, it0);
+            if (it0 + 1 < n_it) step(fd_int<1>{}, it0 + 1);
+            if (it0 + 2 < n_it) step(fd_int<2>{}, it0 + 2);
+        }
+    }
+#pragma unroll
+    for (int m = CL; m < 64; m <<= 1) { sg0 += __shfl_xor(sg0, m); sg1 += __shfl_xor(sg1, m); sx0 += __shfl_xor(sx0, m); sx1 += __shfl_xor(sx1, m); }
+    if (lane < CL) {
+        red[(wave * 2 + 0) * CB + 2 * l] = sg0; red[(wave * 2 + 0) * CB + 2 * l + 1] = sg1;
+        red[(wave * 2 + 1) * CB + 2 * l] = sx0; red[(wave * 2 + 1) * CB + 2 * l + 1] = sx1;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 2 * CB) {
+        const int which = tid / CB, ch = tid % CB;
+        if (c0 + ch < cend) {
+            const float v = (red[(0 * 2 + which) * CB + ch] + red[(1 * 2 + which) * CB + ch]) + (red[(2 * 2 + which) * CB + ch] + red[(3 * 2 + which) * CB + ch]);
+            fd_stat_add<FD_STAT_BWD>(a.sr, stat_blk, C, which, c0 + ch, v);
+        }
+    }
+}
+
+template <typename T, int ACT1, int CL>
+__device__ __forceinline__ void
+fd_dw3_wgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long row_blk)
+{
+    const int H = a.H, W = a.W, C = a.C;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = wg * 4 + wave;
+    const int band = item / a.groups_x, sg = item - band * a.groups_x;
+    constexpr int CB = 2 * CL, SPW = 64 / CL;
+    const int cend = c0 + CB < C ? c0 + CB : C;
+    const int y0 = band * a.bh_w, y1 = y0 + a.bh_w < H ? y0 + a.bh_w : H;
+    const int l = lane % CL, xs = 4 * (SPW * sg + lane / CL), c = c0 + 2 * l;
+    const bool live = y0 < H && c < cend && xs < W;
+    float acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
+    if (live) {
+        float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch];
+        }
+        unsigned so[6];
+        bool pin[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int x = xs - 1 + i;
+            pin[i] = x >= 0 && x < W;
+            so[i] = pin[i] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned rowb = fd_mul24((unsigned)W, (unsigned)C) * 2u;
+        const fd_bufrsrc r_g = fd_make_rsrc(a.G + (long)n * H * W * C, (unsigned)H * rowb), r_z = fd_make_rsrc(a.Z + (long)n * H * W * C, (unsigned)H * rowb);
+        const fd_bufrsrc r_zi = fd_make_rsrc(a.Zin + (long)n * H * W * C, (unsigned)H * rowb);
+        unsigned nzi[6], ng[4], nz[4];                        // in flight: the next step's input row (6 columns), G / z of its dz row (4 columns)
+        bool nv = false;
+        // step `it`: input row r = y0 - 1 + it enters the window; dz row r - 1 (it >= 2) is multiplied with rows r - 2 ... r
+        auto issue = [&](int it) FD_INLINE_LAMBDA {
+            const int r = y0 - 1 + it;
+            nv = r >= 0 && r < H;
+            if (nv) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nzi[i] = fd_buf_ld32(r_zi, so[i], (unsigned)r * rowb);
+            }
+            if (it >= 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ng[j] = fd_buf_ld32(r_g, so[1 + j], (unsigned)(r - 1) * rowb); nz[j] = fd_buf_ld32(r_z, so[1 + j], (unsigned)(r - 1) * rowb); }
+            }
+        };
+        float win[3][6][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { win[q][i][0] = 0.f; win[q][i][1] = 0.f; }
+        const int n_it = (y1 - y0) + 2;
+        issue(0);
+        auto step = [&](auto PH, int it) FD_INLINE_LAMBDA {
+            constexpr int ph = decltype(PH)::value;
+            const bool rv = nv;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool v = rv && pin[i];                 // (zero padding of the ACTIVATED input)
+                const float a0 = fd_act<ACT1>(fmaf(fd_w16_lo(T{}, nzi[i]), s1[0], t1[0])), a1 = fd_act<ACT1>(fmaf(fd_w16_hi(T{}, nzi[i]), s1[1], t1[1]));
+                win[ph][i][0] = v ? a0 : 0.f; win[ph][i][1] = v ? a1 : 0.f;
+            }
+            float dz[4][2];
+            if (it >= 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool v = xs + j < W;
+                    const float d0 = fd_dz(fd_w16_lo(T{}, ng[j]), fd_w16_lo(T{}, nz[j]), cA[0], c1[0], cM[0], c2[0]);
+                    const float d1 = fd_dz(fd_w16_hi(T{}, ng[j]), fd_w16_hi(T{}, nz[j]), cA[1], c1[1], cM[1], c2[1]);
+                    dz[j][0] = v ? d0 : 0.f; dz[j][1] = v ? d1 : 0.f;
+                }
+            }
+            if (it + 1 < n_it) issue(it + 1);
+            if (it >= 2) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[ky * 3 + kx][0] = fmaf(dz[j][0], win[(ph + 1 + ky) % 3][j + kx][0], acc[ky * 3 + kx][0]);
+                            acc[ky * 3 + kx][1] = fmaf(dz[j][1], win[(ph + 1 + ky) % 3][j + kx][1], acc[ky * 3 + kx][1]);
+                        }
+            }
+        };
+        for (int it0 = 0; it0 < n_it; it0 += 3) {
+            step(fd_int<0>{}, it0);
+            if (it0 + 1 < n_it) step(fd_int<1>{}, it0 + 1);
+            if (it0 + 2 < n_it) step(fd_int<2>{}, it0 + 2);
+        }
+    }
+#pragma unroll
+    for (int m = CL; m < 64; m <<= 1)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { acc[t][0] += __shfl_xor(acc[t][0], m); acc[t][1] += __shfl_xor(acc[t][1], m); }
+    if (lane < CL) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { red[(wave * 9 + t) * CB + 2 * l] = acc[t][0]; red[(wave * 9 + t) * CB + 2 * l + 1] = acc[t][1]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * CB; i += 256) {
+        const int t = i / CB, ch = i % CB;
+        if (c0 + ch < cend)
+            a.wpart[(row_blk * 9 + t) * C + c0 + ch] = (red[(0 * 9 + t) * CB + ch] + red[(1 * 9 + t) * CB + ch]) + (red[(2 * 9 + t) * CB + ch] + red[(3 * 9 + t) * CB + ch]);
+    }
+}
+
+// grid (wgs_d + wgs_w, channel blocks of 2 * CL, images) through fd_xcd_image_map; block 256
+template <typename T, int ACT1, int CL>
+__global__ void __launch_bounds__(256)
+fd_dw3_bwd_rows(const fd_dw3_bwd_args<T> a)
+{
+    __shared__ float red[4 * 9 * 2 * CL];
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int c0 = blk.y * 2 * CL, n = blk.z;
+    if (blk.x < a.wgs_d) fd_dw3_dgrad_rows_body<T, ACT1, CL>(a, red, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
+    else fd_dw3_wgrad_rows_body<T, ACT1, CL>(a, red, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
+}

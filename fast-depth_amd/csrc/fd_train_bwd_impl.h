@@ -81,6 +81,7 @@ int launch_dw_dgrad(BwdCtx &c, int i, int *nblk_out)
     TLayer &P = c.p->layers[L.d.src];
     const int cb = L.dw_n << L.cbq, le = L.dw_n == 8 ? 2 : 4;
     L.lds_rounding = (L.lds_rounding & ~2) | (L.dw_n == 8 ? 2 : 0);
+    L.bwd_rows = 0;
     const int TH = dw_dgrad_rows(c.p, L), TW = dw_dgrad_cols(L);
     const int tiles_x = ceil_div(L.in_w, TW), tiles_y = ceil_div(L.in_h, TH);
     const int ph = dw_dz_patch(TH, K, S), pw = dw_dz_patch(TW, K, S);
@@ -171,6 +172,12 @@ int launch_dw_wgrad(BwdCtx &c, int i)
 
 // Both backward kernels of a depthwise unit in ONE launch (fd_dw_bwd); returns FD_OK with *paired = false when this unit's combination of
 // kernel size / stride / input composition / activations has no paired instance (the caller then launches the two kernels one after the other).
+#ifndef FD_DW3_ROWS_SMALL_BAND
+#define FD_DW3_ROWS_SMALL_BAND 7
+#endif
+#ifndef FD_DW3_ROWS_MIN_PIXELS
+#define FD_DW3_ROWS_MIN_PIXELS 0      // maps below this many pixels keep the paired LDS-tiled launch (tools/build_variant.py A/B switch)
+#endif
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG>
 int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
 {
@@ -221,6 +228,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             const int wrows = b.wgs_w * c.p->B;
             if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
             L.lds_rounding = (L.lds_rounding & ~(2 | 8)) | 2 | 8;       // dz and the re-created input rounded to the storage type; the backward-data taps too
+            L.bwd_rows = 1;
             FD_LAUNCH((fd_dw5_bwd_rows<T, ACT1, ACT2>), dim3((unsigned)(b.wgs_d + b.wgs_w), (unsigned)ceil_div(L.d.cin, 64), (unsigned)c.p->B), dim3(256), 0, c.s, b);
             int rc5 = check_launch("fd_dw5_bwd_rows");
             if (rc5) return rc5;
@@ -229,6 +237,33 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
         }
     }
     L.lds_rounding &= ~8;
+    // 16-bit plans, 3x3 stride 1 on plain inputs (conv1.0 / conv3.0 / conv5.0 / the 14x14 units ...): both gradients on the row-walking fp32-window kernel
+    // (fd_kernels_dw5p_bwd.h: fd_dw3_bwd_rows); nothing is rounded there, so the unit reports no LDS rounding
+    if constexpr (K == 3 && S == 1 && MODE == 0 && ADD_SG == 0 && !std::is_same<T, float>::value) {
+        if (L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && !L.bwd_fin_rows && (long)L.in_h * L.in_w >= FD_DW3_ROWS_MIN_PIXELS &&
+            !(c.p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR | FD_TUNE_FORCE_DW_H8))) {
+            fd_dw3_bwd_args<T> b{};
+            b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.Gin = a.Gin; b.coef = a.coef; b.w = a.w; b.st_in = a.st_in; b.wpart = a.wpart;
+            const int cl = L.d.cin <= 32 ? 16 : 32;          // channel lanes per strip: a 32-channel unit (conv1.0) would leave half of every wave idle at 32
+            b.H = L.in_h; b.W = L.in_w; b.C = L.d.cin; b.groups_x = ceil_div(L.in_w, 4 * (64 / cl));
+            // bands of ~14 rows on the large maps; the 14x14 / 7x7 maps take bands of 7 (twice the waves: their launches are latency-, not issue-bound)
+            const int bands = L.in_h <= 14 ? ceil_div(L.in_h, FD_DW3_ROWS_SMALL_BAND) : std::max(1, (L.in_h + 7) / 14);
+            b.bh_d = b.bh_w = ceil_div(L.in_h, bands);
+            b.wgs_d = b.wgs_w = ceil_div((long)b.groups_x * ceil_div(L.in_h, b.bh_d), 4);
+            b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs_d * c.p->B);
+            const int wrows = b.wgs_w * c.p->B;
+            if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+            L.lds_rounding &= ~2;
+            L.bwd_rows = 1;
+            const dim3 g3((unsigned)(b.wgs_d + b.wgs_w), (unsigned)ceil_div(L.d.cin, 2 * cl), (unsigned)c.p->B);
+            if (cl == 16) FD_LAUNCH((fd_dw3_bwd_rows<T, ACT1, 16>), g3, dim3(256), 0, c.s, b);
+            else FD_LAUNCH((fd_dw3_bwd_rows<T, ACT1, 32>), g3, dim3(256), 0, c.s, b);
+            int rc3 = check_launch("fd_dw3_bwd_rows");
+            if (rc3) return rc3;
+            *nblk_out = b.wgs_d * c.p->B;
+            return defer_weights(c, b.wpart, wrows, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
+        }
+    }
     // The stride-2 3x3 units of the large maps (channel-group count a power of two in 8 ... 64): two register-window kernels without LDS staging
     // (fd_dw3s2_dgrad_rows over input columns, fd_dw3_wgrad_rows over output columns), row strips as high as still leave >= ~1024 workgroups
     {
@@ -650,6 +685,14 @@ int fd_comm_bind_library(const char *path)
 {
     if (!path || !*path) return fail(FD_ERR_INVALID, "fd_comm_bind_library: empty path");
     if (!rccl_path().empty() && rccl_path() != path) return fail(FD_ERR_STATE, "fd_comm_bind_library: already bound to %s", rccl_path().c_str());
+    if (rccl_path().empty()) {
+        // the candidate is opened and checked BEFORE the path is committed: a library that cannot be loaded (or lacks an entry point) must not leave the
+        // process bound to it for good -- the one-time binding below would then never try librccl.so.1 or another path again
+        void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(FD_ERR_STATE, "fd_comm_bind_library: %s cannot be loaded (%s)", path, dlerror());
+        for (const char *sym : {"ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy"})
+            if (!dlsym(h, sym)) { dlclose(h); return fail(FD_ERR_STATE, "fd_comm_bind_library: %s does not provide %s", path, sym); }
+    }
     rccl_path() = path;
     if (!rccl().ok) return fail(FD_ERR_STATE, "fd_comm_bind_library: %s does not provide ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy (or the binding was made before this call)", path);
     return FD_OK;

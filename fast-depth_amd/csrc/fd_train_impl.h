@@ -395,6 +395,9 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         if ((long)L.in_h * L.in_w >= (1L << 24) || d.cin >= (1 << 24) || d.cout >= (1 << 24) || (double)L.in_h * L.in_w * std::max(d.cin, d.cout) >= 4294967296.0)
             FD_BAD("layer %d: a %dx%d map with %d channels exceeds the kernels' 32-bit within-image addressing", i, L.in_h, L.in_w, std::max(d.cin, d.cout));
         L.M = (long)batch * L.out_h * L.out_w;
+        // statistics rows (fd_device.h): a 64-bit bin holds 2^14 partials of < 2^48 each with room to spare and a unit adds at most one partial per 64 stored
+        // pixels and channel -- larger batches would let the cross-row total wrap silently: rejected instead
+        if (ceil_div(L.M, 64) > (1L << 14) * FD_STAT_MAX_ROWS) FD_BAD("layer %d: %ld stored pixels per channel exceed the statistics rows' headroom (%d rows x 2^14 partials of 64 pixels)", i, L.M, FD_STAT_MAX_ROWS);
         L.z_elems = (size_t)L.M * d.cout;
         L.n_stat = (double)L.M;
         L.n_unbiased = (L.head && d.upsample) ? 4.0 * (double)L.M : (double)L.M;
@@ -437,6 +440,12 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
         L.sb_off = off; off += align_up(stat_rows_bytes(L.nr_cap, L.d.cout), 256);
     }
     p->stat_bytes = off - p->stat_off;
+    // a unit whose BatchNorm is finalised inside its src-consumer's kernel publishes its table only when that kernel runs: a SKIP consumer that comes earlier in the
+    // layer list would read the table before it is written (FastDepth's graph never does; the C ABI accepts arbitrary descriptors -- ADVICE r05)
+    for (int i = 0; i < n_layers; ++i) {
+        TLayer &U = p->layers[i];
+        if (U.fin_by_consumer && U.skip_consumer >= 0 && U.skip_consumer < U.consumer) U.fin_by_consumer = false;
+    }
     for (int i = 0; i < n_layers; ++i) p->layers[i].bwd_fin = bwd_fin_candidate(p, i);
     p->ws_bytes = off;
     *out_plan = p;
@@ -476,7 +485,7 @@ int fd_train_plan_unit_kernels(const fd_train_plan *plan, int32_t layer)
 {
     if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return -1;
     const TLayer &L = plan->layers[layer];
-    return (L.pw16_tm ? 1 : 0) | (L.fin_by_consumer ? 2 : 0) | (L.bwd_fin_rows > 0 ? 4 : 0);
+    return (L.pw16_tm ? 1 : 0) | (L.fin_by_consumer ? 2 : 0) | (L.bwd_fin_rows > 0 ? 4 : 0) | (L.bwd_rows ? 8 : 0) | (L.dw5_groups ? 16 : 0);
 }
 
 int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n, int32_t *h,

@@ -55,6 +55,7 @@ struct fd_train_layer {
     int cbq = 0, th = 0, tw = 0, tiles_x = 0, tiles_y = 0;   // dw tiling (forward kernel)
     int dw_n = 4;                                             // channels per work-item of the LDS-tiled depthwise kernels (8: bf16 plans, storage-typed LDS patches; fd_lane)
     mutable int lds_rounding = 0;                             // fd_train_plan_lds_rounding: set by the launches of the last forward / backward
+    mutable int bwd_rows = 0;                                 // the LAST backward of this depthwise unit ran on a row-walking kernel (fd_dw5_bwd_rows / fd_dw3_bwd_rows)
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
     int rows_th = 0;                                          // > 0: the forward runs on fd_dw3_rows_train with row strips of this height
     int dw5_groups = 0, dw5_bh = 0;                           // > 0: the forward runs on fd_dw5_rows_train (16-bit plans, 5x5 on up2 + skip): strip pairs per row, rows per band
