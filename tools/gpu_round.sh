@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: smoke, gpu tests, bench, then ONE rocprofv3 invocation per configuration (kernel trace + stats) and the PMC passes.
 # Usage: gpurun --timeout 2400 -- bash tools/gpu_round.sh [tag] [skip-tests]
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
