@@ -810,3 +810,211 @@ fd_dw3_bwd_rows(const fd_dw3_bwd_args<T> a)
     if (blk.x < a.wgs_d) fd_dw3_dgrad_rows_body<T, ACT1, CL>(a, red, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
     else fd_dw3_wgrad_rows_body<T, ACT1, CL>(a, red, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
 }
+
+// ======================================================================================================================================================
+// Backward of the depthwise 3x3 STRIDE-2 units (conv2.0 / conv4.0 / conv6.0 / conv12.0; autograd of reference imagenet/mobilenet.py:31-33) for the 16-bit train
+// plans: ONE role -- a wave produces BOTH gradients from one pass over its operands (fd_dw3s2_bwd_rows).  These units move bytes, not flops (2.25 taps per input
+// value for the data gradient, 9 per OUTPUT value for the weight gradient): the register-window pair fd_dw3s2_dgrad_rows + fd_dw3_wgrad_rows read the saved input
+// z_in twice and G / z twice (49 + 17 us on conv2.0 for ~180 MB).  Here a lane owns 2 channels x 4 OUTPUT columns (8 input columns + 1 halo column) and walks down
+// output rows: per step it takes in input rows 2oy, 2oy + 1 (activated once, fp32, kept with row 2oy - 1 in a 3-row window), the dz row oy + 1 (5 columns, kept
+// with row oy), the skip gradient of the two input rows, and emits
+//   d_in(2oy, x), d_in(2oy + 1, x)  for its 8 input columns (x even: one tap column, x odd: two; row 2oy: filter row 1, row 2oy + 1: filter rows 2 and 0),
+//   G_in = mask(y_in) * (d_in + skip gradient), rounded, + its BatchNorm-backward sums,   dW[ky][kx] += dz(oy, ox) * a_in(2oy - 1 + ky, 2ox - 1 + kx).
+// Nothing is rounded before the stores (fp32 window, fp32 taps).  End-of-kernel reductions as in fd_dw3_bwd_rows.
+// ======================================================================================================================================================
+template <typename T> struct fd_dw3s2_bwd_args {
+    const T *G, *Z, *Zin, *SG;         // this unit's dL/dy and raw output (OUTPUT resolution); the producer's raw output and (ADD_SG) the decoder's skip gradient (INPUT resolution)
+    T *Gin;
+    const float *coef, *w, *st_in;
+    fd_stat_rows sr;
+    float *wpart;                      // [9][C] per workgroup
+    int Ho, Wo, C, groups_x;           // OUTPUT map (the input map is 2 Ho x 2 Wo), channels, strip pairs per output row (ceil(Wo / 8))
+    int bh, wgs;                       // output rows per band, workgroups per image and channel block
+};
+
+template <typename T, int ACT1, int ADD_SG>
+__global__ void __launch_bounds__(256) FD_DW5B_ATTR
+fd_dw3s2_bwd_rows(const fd_dw3s2_bwd_args<T> a)
+{
+    __shared__ float red[4 * 9 * 64];
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int c0 = blk.y * 64, n = blk.z;
+    const int Ho = a.Ho, Wo = a.Wo, C = a.C, H = 2 * Ho, W = 2 * Wo;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = blk.x * 4 + wave;
+    const int band = item / a.groups_x, sg = item - band * a.groups_x;
+    const int cend = c0 + 64 < C ? c0 + 64 : C;
+    const int oy0 = band * a.bh, oy1 = oy0 + a.bh < Ho ? oy0 + a.bh : Ho;
+    const int l = lane & 31, ox0 = 4 * (2 * sg + (lane >> 5)), c = c0 + 2 * l;
+    const bool live = oy0 < Ho && c < cend && ox0 < Wo;
+    float acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
+    float sg0 = 0.f, sg1 = 0.f, sx0 = 0.f, sx1 = 0.f;
+    if (live) {
+        float wt[3][3][2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wt[t / 3][t % 3][ch] = a.w[(long)(c + ch) * 9 + t];
+        float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], m1[2], i1[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch]; m1[ch] = a.st_in[FD_ST_MEAN * C + c + ch]; i1[ch] = a.st_in[FD_ST_INVSTD * C + c + ch];
+        }
+        unsigned si[9], sd[5];                               // byte offsets: input columns 2 ox0 - 1 ... 2 ox0 + 7 in an input row; dz columns ox0 ... ox0 + 4 in an output row
+        bool pi[9], pd[5];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int x = 2 * ox0 - 1 + i;
+            pi[i] = x >= 0 && x < W;
+            si[i] = pi[i] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int x = ox0 + i;
+            pd[i] = x < Wo;
+            sd[i] = pd[i] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned rowi = fd_mul24((unsigned)W, (unsigned)C) * 2u, rowo = fd_mul24((unsigned)Wo, (unsigned)C) * 2u;
+        const fd_bufrsrc r_g = fd_make_rsrc(a.G + (long)n * Ho * Wo * C, (unsigned)Ho * rowo), r_z = fd_make_rsrc(a.Z + (long)n * Ho * Wo * C, (unsigned)Ho * rowo);
+        const fd_bufrsrc r_zi = fd_make_rsrc(a.Zin + (long)n * H * W * C, (unsigned)H * rowi), r_gi = fd_make_rsrc(a.Gin + (long)n * H * W * C, (unsigned)H * rowi);
+        const fd_bufrsrc r_sg = fd_make_rsrc(ADD_SG ? a.SG + (long)n * H * W * C : a.Zin, (unsigned)H * rowi);
+
+        unsigned nzi[2][9], nsg[2][8], ng[5], nz[5];          // in flight for the next step: input rows 2oy, 2oy + 1 (9 columns), their skip gradient (8), G / z of dz row oy + 1 (5)
+        bool nvd = false;                                    // dz row oy + 1 exists
+        auto issue = [&](int oy) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const unsigned ro = (unsigned)(2 * oy + rr) * rowi;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) nzi[rr][i] = fd_buf_ld32(r_zi, si[i], ro);
+                if (ADD_SG) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) nsg[rr][i] = fd_buf_ld32(r_sg, si[1 + i], ro);
+                }
+            }
+            nvd = oy + 1 < Ho;
+            if (nvd) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { ng[i] = fd_buf_ld32(r_g, sd[i], (unsigned)(oy + 1) * rowo); nz[i] = fd_buf_ld32(r_z, sd[i], (unsigned)(oy + 1) * rowo); }
+            }
+        };
+        auto make_dz = [&](float (&dst)[5][2], const unsigned (&g)[5], const unsigned (&z)[5], bool rv) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const bool v = rv && pd[i];
+                const float d0 = fd_dz(fd_w16_lo(T{}, g[i]), fd_w16_lo(T{}, z[i]), cA[0], c1[0], cM[0], c2[0]);
+                const float d1 = fd_dz(fd_w16_hi(T{}, g[i]), fd_w16_hi(T{}, z[i]), cA[1], c1[1], cM[1], c2[1]);
+                dst[i][0] = v ? d0 : 0.f; dst[i][1] = v ? d1 : 0.f;
+            }
+        };
+        float inw[3][9][2];                                  // activated input rows 2oy - 1, 2oy, 2oy + 1: slot 0 = the row kept from the previous step
+        float dzw[2][5][2];                                  // dz rows oy (slot 0) and oy + 1 (slot 1)
+        // prologue: input row 2 oy0 - 1 (zero above the image) and dz row oy0
+        {
+            const int r = 2 * oy0 - 1;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                unsigned v = 0u;
+                if (r >= 0) v = fd_buf_ld32(r_zi, si[i], (unsigned)r * rowi);
+                const bool ok = r >= 0 && pi[i];
+                inw[0][i][0] = ok ? fd_act<ACT1>(fmaf(fd_w16_lo(T{}, v), s1[0], t1[0])) : 0.f;
+                inw[0][i][1] = ok ? fd_act<ACT1>(fmaf(fd_w16_hi(T{}, v), s1[1], t1[1])) : 0.f;
+            }
+            unsigned g0[5], z0[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { g0[i] = fd_buf_ld32(r_g, sd[i], (unsigned)oy0 * rowo); z0[i] = fd_buf_ld32(r_z, sd[i], (unsigned)oy0 * rowo); }
+            make_dz(dzw[0], g0, z0, true);
+        }
+        issue(oy0);
+        for (int oy = oy0; oy < oy1; ++oy) {
+            // this step's operands leave the in-flight registers: the two new input rows (activated; the raw words stay for xhat), dz row oy + 1, the skip gradient
+            unsigned zraw[2][8], sgr[2][8];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    inw[1 + rr][i][0] = pi[i] ? fd_act<ACT1>(fmaf(fd_w16_lo(T{}, nzi[rr][i]), s1[0], t1[0])) : 0.f;
+                    inw[1 + rr][i][1] = pi[i] ? fd_act<ACT1>(fmaf(fd_w16_hi(T{}, nzi[rr][i]), s1[1], t1[1])) : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { zraw[rr][i] = nzi[rr][1 + i]; sgr[rr][i] = ADD_SG ? nsg[rr][i] : 0u; }
+            }
+            make_dz(dzw[1], ng, nz, nvd);
+            if (oy + 1 < oy1) issue(oy + 1);                   // everything the next step reads flies under this step's arithmetic
+            // ---- weight gradient: dz(oy, ox0 + j) * a_in(2oy - 1 + ky, 2(ox0 + j) - 1 + kx): window column 2 j + kx
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[ky * 3 + kx][0] = fmaf(dzw[0][j][0], inw[ky][2 * j + kx][0], acc[ky * 3 + kx][0]);
+                        acc[ky * 3 + kx][1] = fmaf(dzw[0][j][1], inw[ky][2 * j + kx][1], acc[ky * 3 + kx][1]);
+                    }
+            // ---- data gradient of input rows 2oy (filter row 1 of dz row oy) and 2oy + 1 (filter row 2 of dz row oy + filter row 0 of dz row oy + 1);
+            // input column 2 m (window column 1 + 2 (m - ox0)): tap column 1 of dz column m; column 2 m + 1: tap column 2 of dz column m + tap column 0 of dz column m + 1
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = i >> 1;
+                    float d[2];
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        if ((i & 1) == 0) {
+                            d[ch] = rr == 0 ? dzw[0][m][ch] * wt[1][1][ch] : fmaf(dzw[0][m][ch], wt[2][1][ch], dzw[1][m][ch] * wt[0][1][ch]);
+                        } else {
+                            const float e = rr == 0 ? fmaf(dzw[0][m][ch], wt[1][2][ch], dzw[0][m + 1][ch] * wt[1][0][ch])
+                                                    : fmaf(dzw[0][m][ch], wt[2][2][ch], fmaf(dzw[0][m + 1][ch], wt[2][0][ch], fmaf(dzw[1][m][ch], wt[0][2][ch], dzw[1][m + 1][ch] * wt[0][0][ch])));
+                            d[ch] = e;
+                        }
+                    }
+                    if (ADD_SG) { d[0] += fd_w16_lo(T{}, sgr[rr][i]); d[1] += fd_w16_hi(T{}, sgr[rr][i]); }
+                    const float z0 = fd_w16_lo(T{}, zraw[rr][i]), z1 = fd_w16_hi(T{}, zraw[rr][i]);
+                    const unsigned packed = fd_pack2(T{}, d[0] * fd_actmask<ACT1>(fmaf(z0, s1[0], t1[0])), d[1] * fd_actmask<ACT1>(fmaf(z1, s1[1], t1[1])));
+                    if (ox0 + m < Wo) {
+                        fd_buf_st32(r_gi, si[1 + i], (unsigned)(2 * oy + rr) * rowi, packed);
+                        const float g0 = fd_w16_lo(T{}, packed), g1 = fd_w16_hi(T{}, packed);
+                        sg0 += g0; sg1 += g1;
+                        sx0 = fmaf(g0, (z0 - m1[0]) * i1[0], sx0); sx1 = fmaf(g1, (z1 - m1[1]) * i1[1], sx1);
+                    }
+                }
+            // ---- the windows move on: input row 2oy + 1 becomes the next step's row 2(oy + 1) - 1, dz row oy + 1 its row oy
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { inw[0][i][0] = inw[2][i][0]; inw[0][i][1] = inw[2][i][1]; }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { dzw[0][i][0] = dzw[1][i][0]; dzw[0][i][1] = dzw[1][i][1]; }
+        }
+    }
+    // ---- end of kernel: the workgroup's BatchNorm-backward sums and its weight-gradient partial row
+    sg0 += __shfl_xor(sg0, 32); sg1 += __shfl_xor(sg1, 32); sx0 += __shfl_xor(sx0, 32); sx1 += __shfl_xor(sx1, 32);
+    if (lane < 32) {
+        red[(wave * 2 + 0) * 64 + 2 * l] = sg0; red[(wave * 2 + 0) * 64 + 2 * l + 1] = sg1;
+        red[(wave * 2 + 1) * 64 + 2 * l] = sx0; red[(wave * 2 + 1) * 64 + 2 * l + 1] = sx1;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        if (c0 + ch < cend) {
+            const float v = (red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch]) + (red[(2 * 2 + which) * 64 + ch] + red[(3 * 2 + which) * 64 + ch]);
+            fd_stat_add<FD_STAT_BWD>(a.sr, (long)n * a.wgs + blk.x, C, which, c0 + ch, v);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc[t][0] += __shfl_xor(acc[t][0], 32); acc[t][1] += __shfl_xor(acc[t][1], 32); }
+    if (lane < 32) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { red[(wave * 9 + t) * 64 + 2 * l] = acc[t][0]; red[(wave * 9 + t) * 64 + 2 * l + 1] = acc[t][1]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * 64; i += 256) {
+        const int t = i >> 6, ch = i & 63;
+        if (c0 + ch < cend)
+            a.wpart[(((long)n * a.wgs + blk.x) * 9 + t) * C + c0 + ch] = (red[(0 * 9 + t) * 64 + ch] + red[(1 * 9 + t) * 64 + ch]) + (red[(2 * 9 + t) * 64 + ch] + red[(3 * 9 + t) * 64 + ch]);
+    }
+}

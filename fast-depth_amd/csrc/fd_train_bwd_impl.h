@@ -264,6 +264,29 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             return defer_weights(c, b.wpart, wrows, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
         }
     }
+    // 16-bit plans, 3x3 stride 2 (conv2.0 / conv4.0 / conv6.0 / conv12.0): ONE row-walking kernel produces both gradients from one pass over z_in, G, z and the
+    // skip gradient (fd_kernels_dw5p_bwd.h: fd_dw3s2_bwd_rows); these units are byte-bound and the paired forms read their operands twice
+    if constexpr (K == 3 && S == 2 && MODE == 0 && !std::is_same<T, float>::value) {
+        if (L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && !L.bwd_fin_rows &&
+            !(c.p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR | FD_TUNE_FORCE_DW_H8 | FD_TUNE_DW_FORCE_ROWS | FD_TUNE_DW_NO_ROWS))) {
+            fd_dw3s2_bwd_args<T> b{};
+            b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.SG = a.SG; b.Gin = a.Gin; b.coef = a.coef; b.w = a.w; b.st_in = a.st_in; b.wpart = a.wpart;
+            b.Ho = L.out_h; b.Wo = L.out_w; b.C = L.d.cin; b.groups_x = ceil_div(L.out_w, 8);
+            const int bands = L.out_h <= 14 ? ceil_div(L.out_h, 4) : std::max(1, (L.out_h + 3) / 7);     // ~7 output rows (14 input rows) per band; the small maps take 4
+            b.bh = ceil_div(L.out_h, bands);
+            b.wgs = ceil_div((long)b.groups_x * ceil_div(L.out_h, b.bh), 4);
+            b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs * c.p->B);
+            const int wrows = b.wgs * c.p->B;
+            if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
+            L.lds_rounding &= ~2;
+            L.bwd_rows = 1;
+            FD_LAUNCH((fd_dw3s2_bwd_rows<T, ACT1, ADD_SG>), dim3((unsigned)b.wgs, (unsigned)ceil_div(L.d.cin, 64), (unsigned)c.p->B), dim3(256), 0, c.s, b);
+            int rc2 = check_launch("fd_dw3s2_bwd_rows");
+            if (rc2) return rc2;
+            *nblk_out = b.wgs * c.p->B;
+            return defer_weights(c, b.wpart, wrows, kk * L.d.cin, kk, L.d.cin, c.grads[i].conv_weight);
+        }
+    }
     // The stride-2 3x3 units of the large maps (channel-group count a power of two in 8 ... 64): two register-window kernels without LDS staging
     // (fd_dw3s2_dgrad_rows over input columns, fd_dw3_wgrad_rows over output columns), row strips as high as still leave >= ~1024 workgroups
     {

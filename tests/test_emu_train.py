@@ -190,8 +190,8 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     # asks for one of the LDS-tiled forms (or for the in-kernel BatchNorm-backward finalisation, which only those carry)
     lds_forms = capi.FD_TUNE_DW_BWD1 | capi.FD_TUNE_DW_BWD_PAIR | capi.FD_TUNE_DW_BWD_FINALIZE | capi.FD_TUNE_NO_DW5_ROWS | capi.FD_PLAN_NO_BWD_PAIRING
     assert info["dw_units_on_dw5_bwd_rows"] == (3 if dtype == torch.bfloat16 and not flags & lds_forms else 0), info
-    # ... and every 3x3 stride-1 unit on a plain input (9 of the encoder's 13 depthwise units) on fd_dw3_bwd_rows
-    assert info["dw_units_backward_on_row_kernels"] == (12 if dtype == torch.bfloat16 and not flags & (lds_forms | capi.FD_TUNE_FORCE_DW_H8) else 0), info
+    # ... and every 3x3 unit of the encoder on fd_dw3_bwd_rows (stride 1: 9 units) / fd_dw3s2_bwd_rows (stride 2: 4 units)
+    assert info["dw_units_backward_on_row_kernels"] == (16 if dtype == torch.bfloat16 and not flags & (lds_forms | capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_FORCE_ROWS) else 0), info
     assert info["dw_units_on_dw5_rows_train"] == (3 if dtype == torch.bfloat16 and not flags & (capi.FD_TUNE_NO_DW5_ROWS | capi.FD_TUNE_FORCE_DW_H8) else 0), info
     # the forms the flags ask for did run: gemm16 train GEMMs (every pointwise unit but the head), in-kernel finalisations forward / backward
     assert info["pw_units_on_gemm16"] == (18 if name.startswith("g16") else 0)
