@@ -28,6 +28,7 @@ template <typename T> struct fd_dw5_bwd_args {
     float *wpart;                      // weight-gradient partial rows: row = image * wgs_w + workgroup, [25][C]
     int H, W, C, groups_x;             // full-resolution map, channels, strip pairs per row (W / 8, rounded up)
     int bh_d, bh_w, wgs_d, wgs_w;      // rows per band and workgroups per image and channel block of the two roles
+    fd_bn_bwd_fin fin;                 // rows != null: this unit's BatchNorm backward is finalised in the kernel's prologue (few statistics rows: fd_bstat_table_block)
 };
 
 #ifndef FD_DW5B_WAVES
@@ -39,6 +40,14 @@ template <typename T> struct fd_dw5_bwd_args {
 #define FD_DW5B_ATTR __attribute__((amdgpu_waves_per_eu(FD_DW5B_WAVES, FD_DW5B_WAVES)))
 #endif
 
+// a lane's BatchNorm-backward coefficients of channel c + ch: from the table a finalisation launch wrote, or (fin.rows != null) from the block the kernel's own
+// prologue derived into LDS (s_cf: [4][CBF] for the workgroup's channel block, local channel 2 l + ch)
+#define FD_DW_ROWS_COEF(ch)                                                                                                                         \
+    do {                                                                                                                                            \
+        if (a.fin.rows) { cA[ch] = s_cf[FD_CF_A * CBF + 2 * l + ch]; c1[ch] = s_cf[FD_CF_C1 * CBF + 2 * l + ch]; cM[ch] = s_cf[FD_CF_MU * CBF + 2 * l + ch]; c2[ch] = s_cf[FD_CF_C2 * CBF + 2 * l + ch]; } \
+        else { cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch]; }                     \
+    } while (0)
+
 // 16-bit storage -> fp32 of the two channels of a loaded word
 __device__ __forceinline__ float fd_w16_lo(fd_bf16, unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float fd_w16_hi(fd_bf16, unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
@@ -48,8 +57,9 @@ __device__ __forceinline__ float fd_w16_hi(fd_half, unsigned v) { return (float)
 // ---- role D: backward-data ------------------------------------------------------------------------------------------------------------------------
 template <typename T, int ACT1, int ACT2>
 __device__ __forceinline__ void
-fd_dw5_dgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long stat_blk)
+fd_dw5_dgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const float *s_cf, const int wg, const int c0, const int n, const long stat_blk)
 {
+    constexpr int CBF = 64;
     const int H = a.H, W = a.W, C = a.C, Hs = H >> 1, Ws = W >> 1;
     const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int item = wg * 4 + wave;
@@ -75,7 +85,7 @@ fd_dw5_dgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, co
         float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], m1[2], i1[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            FD_DW_ROWS_COEF(ch);
             s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch]; m1[ch] = a.st_in[FD_ST_MEAN * C + c + ch]; i1[ch] = a.st_in[FD_ST_INVSTD * C + c + ch];
         }
         unsigned so[4];                                      // byte offsets of the strip's four pixel pairs in a full-resolution row (out of range: outside the image)
@@ -224,8 +234,9 @@ fd_dw5_dgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, co
 #define FD_PERM_SHIFT1 0x05040302u    /* fd_perm(next, cur, FD_PERM_SHIFT1) = (high half of cur, low half of next): the pixel pair one pixel to the right */
 template <typename T, int ACT1, int ACT2>
 __device__ __forceinline__ void
-fd_dw5_wgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long row_blk)
+fd_dw5_wgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const float *s_cf, const int wg, const int c0, const int n, const long row_blk)
 {
+    constexpr int CBF = 64;
     const int H = a.H, W = a.W, C = a.C, Hs = H >> 1, Ws = W >> 1;
     const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int item = wg * 4 + wave;
@@ -241,7 +252,7 @@ fd_dw5_wgrad_rows_body(const fd_dw5_bwd_args<T> &a, float *red, const int wg, co
         float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], s2[2], t2[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            FD_DW_ROWS_COEF(ch);
             s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch];
             s2[ch] = a.st_skip[FD_ST_SCALE * C + c + ch]; t2[ch] = a.st_skip[FD_ST_SHIFT * C + c + ch];
         }
@@ -381,10 +392,13 @@ __global__ void __launch_bounds__(256) FD_DW5B_ATTR
 fd_dw5_bwd_rows(const fd_dw5_bwd_args<T> a)
 {
     __shared__ float red[4 * 25 * 64];
+    __shared__ double sh[512];
+    __shared__ float s_cf[4 * 64];
     const fd_blk3 blk = fd_xcd_image_map();
     const int c0 = blk.y * 64, n = blk.z;
-    if (blk.x < a.wgs_d) fd_dw5_dgrad_rows_body<T, ACT1, ACT2>(a, red, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
-    else fd_dw5_wgrad_rows_body<T, ACT1, ACT2>(a, red, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
+    if (a.fin.rows) fd_bstat_table_block(a.fin, sh, s_cf, c0, 64, a.C, (int)threadIdx.x, blk.x == 0 && n == 0);
+    if (blk.x < a.wgs_d) fd_dw5_dgrad_rows_body<T, ACT1, ACT2>(a, red, s_cf, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
+    else fd_dw5_wgrad_rows_body<T, ACT1, ACT2>(a, red, s_cf, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
 }
 
 // ---- train-mode FORWARD of the same units (replaces fd_dwconv_train<T, 5, 1, 2, ...>: 67 / 43 / 27 us per bf16 step) ---------------------------------
@@ -568,12 +582,14 @@ template <typename T> struct fd_dw3_bwd_args {
     float *wpart;                      // weight-gradient partial rows: row = image * wgs_w + workgroup, [9][C]
     int H, W, C, groups_x;             // map, channels, strip groups per row (ceil(W / (4 * strips per wave)))
     int bh_d, bh_w, wgs_d, wgs_w;      // rows per band and workgroups per image and channel block of the two roles
+    fd_bn_bwd_fin fin;                 // rows != null: finalised in the prologue
 };
 
 template <typename T, int ACT1, int CL>      // CL = channel lanes per strip: 32 (a wave = 2 strips x 64 channels) or 16 (4 strips x 32 channels: conv1.0)
 __device__ __forceinline__ void
-fd_dw3_dgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long stat_blk)
+fd_dw3_dgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const float *s_cf, const int wg, const int c0, const int n, const long stat_blk)
 {
+    constexpr int CBF = 2 * CL;
     const int H = a.H, W = a.W, C = a.C;
     const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int item = wg * 4 + wave;
@@ -593,7 +609,7 @@ fd_dw3_dgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, co
         float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], m1[2], i1[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            FD_DW_ROWS_COEF(ch);
             s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch]; m1[ch] = a.st_in[FD_ST_MEAN * C + c + ch]; i1[ch] = a.st_in[FD_ST_INVSTD * C + c + ch];
         }
         unsigned so[6];                                      // byte offsets of columns xs - 1 ... xs + 4 in a row (out of range: outside the image)
@@ -691,8 +707,9 @@ fd_dw3_dgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, co
 
 template <typename T, int ACT1, int CL>
 __device__ __forceinline__ void
-fd_dw3_wgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, const int c0, const int n, const long row_blk)
+fd_dw3_wgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const float *s_cf, const int wg, const int c0, const int n, const long row_blk)
 {
+    constexpr int CBF = 2 * CL;
     const int H = a.H, W = a.W, C = a.C;
     const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int item = wg * 4 + wave;
@@ -709,7 +726,7 @@ fd_dw3_wgrad_rows_body(const fd_dw3_bwd_args<T> &a, float *red, const int wg, co
         float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            FD_DW_ROWS_COEF(ch);
             s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch];
         }
         unsigned so[6];
@@ -805,10 +822,13 @@ __global__ void __launch_bounds__(256)
 fd_dw3_bwd_rows(const fd_dw3_bwd_args<T> a)
 {
     __shared__ float red[4 * 9 * 2 * CL];
+    __shared__ double sh[512];
+    __shared__ float s_cf[4 * 2 * CL];
     const fd_blk3 blk = fd_xcd_image_map();
     const int c0 = blk.y * 2 * CL, n = blk.z;
-    if (blk.x < a.wgs_d) fd_dw3_dgrad_rows_body<T, ACT1, CL>(a, red, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
-    else fd_dw3_wgrad_rows_body<T, ACT1, CL>(a, red, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
+    if (a.fin.rows) fd_bstat_table_block(a.fin, sh, s_cf, c0, 2 * CL, a.C, (int)threadIdx.x, blk.x == 0 && n == 0);
+    if (blk.x < a.wgs_d) fd_dw3_dgrad_rows_body<T, ACT1, CL>(a, red, s_cf, blk.x, c0, n, (long)n * a.wgs_d + blk.x);
+    else fd_dw3_wgrad_rows_body<T, ACT1, CL>(a, red, s_cf, blk.x - a.wgs_d, c0, n, (long)n * a.wgs_w + (blk.x - a.wgs_d));
 }
 
 // ======================================================================================================================================================
@@ -830,6 +850,7 @@ template <typename T> struct fd_dw3s2_bwd_args {
     float *wpart;                      // [9][C] per workgroup
     int Ho, Wo, C, groups_x;           // OUTPUT map (the input map is 2 Ho x 2 Wo), channels, strip pairs per output row (ceil(Wo / 8))
     int bh, wgs;                       // output rows per band, workgroups per image and channel block
+    fd_bn_bwd_fin fin;                 // rows != null: finalised in the prologue
 };
 
 template <typename T, int ACT1, int ADD_SG>
@@ -837,9 +858,13 @@ __global__ void __launch_bounds__(256) FD_DW5B_ATTR
 fd_dw3s2_bwd_rows(const fd_dw3s2_bwd_args<T> a)
 {
     __shared__ float red[4 * 9 * 64];
+    __shared__ double sh[512];
+    __shared__ float s_cf[4 * 64];
+    constexpr int CBF = 64;
     const fd_blk3 blk = fd_xcd_image_map();
     const int c0 = blk.y * 64, n = blk.z;
     const int Ho = a.Ho, Wo = a.Wo, C = a.C, H = 2 * Ho, W = 2 * Wo;
+    if (a.fin.rows) fd_bstat_table_block(a.fin, sh, s_cf, c0, 64, C, (int)threadIdx.x, blk.x == 0 && n == 0);
     const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int item = blk.x * 4 + wave;
     const int band = item / a.groups_x, sg = item - band * a.groups_x;
@@ -860,7 +885,7 @@ fd_dw3s2_bwd_rows(const fd_dw3s2_bwd_args<T> a)
         float cA[2], c1[2], cM[2], c2[2], s1[2], t1[2], m1[2], i1[2];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            cA[ch] = a.coef[FD_CF_A * C + c + ch]; c1[ch] = a.coef[FD_CF_C1 * C + c + ch]; cM[ch] = a.coef[FD_CF_MU * C + c + ch]; c2[ch] = a.coef[FD_CF_C2 * C + c + ch];
+            FD_DW_ROWS_COEF(ch);
             s1[ch] = a.st_in[FD_ST_SCALE * C + c + ch]; t1[ch] = a.st_in[FD_ST_SHIFT * C + c + ch]; m1[ch] = a.st_in[FD_ST_MEAN * C + c + ch]; i1[ch] = a.st_in[FD_ST_INVSTD * C + c + ch];
         }
         unsigned si[9], sd[5];                               // byte offsets: input columns 2 ox0 - 1 ... 2 ox0 + 7 in an input row; dz columns ox0 ... ox0 + 4 in an output row

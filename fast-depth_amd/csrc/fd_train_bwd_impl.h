@@ -175,9 +175,6 @@ int launch_dw_wgrad(BwdCtx &c, int i)
 #ifndef FD_DW3_ROWS_SMALL_BAND
 #define FD_DW3_ROWS_SMALL_BAND 7
 #endif
-#ifndef FD_DW3_ROWS_MIN_PIXELS
-#define FD_DW3_ROWS_MIN_PIXELS 0      // maps below this many pixels keep the paired LDS-tiled launch (tools/build_variant.py A/B switch)
-#endif
 template <typename T, int K, int S, int MODE, int ACT1, int ACT2, int ADD_SG>
 int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
 {
@@ -215,7 +212,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     // 16-bit plans, 5x5 on up2 + skip (decode_conv3 / 4 / 5 .0): both gradients on the row-walking pixel-pair kernel (fd_kernels_dw5p_bwd.h) -- one launch,
     // backward-data workgroups first, then the weight-gradient workgroups of the same image (same XCD: the second role finds G / z in its L2)
     if constexpr (K == 5 && S == 1 && MODE == 2 && ADD_SG == 0 && !std::is_same<T, float>::value) {
-        if (L.in_w % 4 == 0 && L.in_h % 2 == 0 && L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && !L.bwd_fin_rows &&
+        if (L.in_w % 4 == 0 && L.in_h % 2 == 0 && L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 &&
             !(c.p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR))) {
             fd_dw5_bwd_args<T> b{};
             b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.Zskip = a.Zskip; b.Gin = a.Gin; b.SGout = a.SGout;
@@ -225,6 +222,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             b.bh_d = b.bh_w = ceil_div(ceil_div(L.in_h, bands), 2) * 2;
             b.wgs_d = b.wgs_w = ceil_div((long)b.groups_x * ceil_div(L.in_h, b.bh_d), 4);
             b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs_d * c.p->B);
+            if (L.bwd_fin_rows) b.fin = bwd_fin_args(c, i, 0);
             const int wrows = b.wgs_w * c.p->B;
             if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
             L.lds_rounding = (L.lds_rounding & ~(2 | 8)) | 2 | 8;       // dz and the re-created input rounded to the storage type; the backward-data taps too
@@ -240,7 +238,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     // 16-bit plans, 3x3 stride 1 on plain inputs (conv1.0 / conv3.0 / conv5.0 / the 14x14 units ...): both gradients on the row-walking fp32-window kernel
     // (fd_kernels_dw5p_bwd.h: fd_dw3_bwd_rows); nothing is rounded there, so the unit reports no LDS rounding
     if constexpr (K == 3 && S == 1 && MODE == 0 && ADD_SG == 0 && !std::is_same<T, float>::value) {
-        if (L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && !L.bwd_fin_rows && (long)L.in_h * L.in_w >= FD_DW3_ROWS_MIN_PIXELS &&
+        if (L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && (long)L.in_h * L.in_w >= FD_DW3_ROWS_MIN_PIXELS &&
             !(c.p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR | FD_TUNE_FORCE_DW_H8))) {
             fd_dw3_bwd_args<T> b{};
             b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.Gin = a.Gin; b.coef = a.coef; b.w = a.w; b.st_in = a.st_in; b.wpart = a.wpart;
@@ -251,6 +249,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             b.bh_d = b.bh_w = ceil_div(L.in_h, bands);
             b.wgs_d = b.wgs_w = ceil_div((long)b.groups_x * ceil_div(L.in_h, b.bh_d), 4);
             b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs_d * c.p->B);
+            if (L.bwd_fin_rows) b.fin = bwd_fin_args(c, i, 0);
             const int wrows = b.wgs_w * c.p->B;
             if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
             L.lds_rounding &= ~2;
@@ -267,7 +266,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
     // 16-bit plans, 3x3 stride 2 (conv2.0 / conv4.0 / conv6.0 / conv12.0): ONE row-walking kernel produces both gradients from one pass over z_in, G, z and the
     // skip gradient (fd_kernels_dw5p_bwd.h: fd_dw3s2_bwd_rows); these units are byte-bound and the paired forms read their operands twice
     if constexpr (K == 3 && S == 2 && MODE == 0 && !std::is_same<T, float>::value) {
-        if (L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 && !L.bwd_fin_rows &&
+        if (L.d.cin % 8 == 0 && (double)L.in_h * L.in_w * L.d.cin * 2.0 < 2147483648.0 &&
             !(c.p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR | FD_TUNE_FORCE_DW_H8 | FD_TUNE_DW_FORCE_ROWS | FD_TUNE_DW_NO_ROWS))) {
             fd_dw3s2_bwd_args<T> b{};
             b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.SG = a.SG; b.Gin = a.Gin; b.coef = a.coef; b.w = a.w; b.st_in = a.st_in; b.wpart = a.wpart;
@@ -276,6 +275,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             b.bh = ceil_div(L.out_h, bands);
             b.wgs = ceil_div((long)b.groups_x * ceil_div(L.out_h, b.bh), 4);
             b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs * c.p->B);
+            if (L.bwd_fin_rows) b.fin = bwd_fin_args(c, i, 0);
             const int wrows = b.wgs * c.p->B;
             if ((size_t)wrows * kk * L.d.cin > L.wp_elems) return fail(FD_ERR_STATE, "depthwise weight-gradient partial region too small");
             L.lds_rounding &= ~2;

@@ -174,6 +174,25 @@ inline bool dw_bwd_on_rows(const fd_train_plan *p, const TLayer &L)
                          (((long)L.out_h * L.out_w >= 28 * 28 && p->esz == 2) || (p->tune & FD_TUNE_DW_FORCE_ROWS));
     return rows_ok && !(p->tune & (FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_BWD_PAIR | FD_TUNE_DW_BWD1));
 }
+#ifndef FD_DW_ROWS_FIN
+#define FD_DW_ROWS_FIN 1               // the row-walking backward kernels finalise their unit's BatchNorm backward in the prologue (0: the separate launch; A/B switch)
+#endif
+#ifndef FD_DW3_ROWS_MIN_PIXELS
+#define FD_DW3_ROWS_MIN_PIXELS 0      // maps below this many pixels keep the paired LDS-tiled launch (tools/build_variant.py A/B switch)
+#endif
+// the unit's backward runs on a row-walking kernel of fd_kernels_dw5p_bwd.h (the launch-time conditions of launch_dw_bwd_pair, fd_train_bwd_impl.h)
+inline bool dw_bwd_row_kernel(const fd_train_plan *p, int i)
+{
+    const TLayer &L = p->layers[i];
+    if (p->esz != 2 || L.d.op != FD_OP_DW || L.d.cin % 8 || (double)L.in_h * L.in_w * L.d.cin * 2.0 >= 2147483648.0 || (p->flags & FD_PLAN_NO_BWD_PAIRING) || !dw_bwd_has_pair(p, i)) return false;
+    if (p->tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_DW_BWD1 | FD_TUNE_DW_BWD_PAIR)) return false;
+    const bool add = p->layers[L.d.src].skip_consumer >= 0 && L.mode == 0;
+    if (L.d.ksize == 5 && L.d.stride == 1 && L.mode == 2) return L.in_w % 4 == 0 && L.in_h % 2 == 0;
+    if (p->tune & FD_TUNE_FORCE_DW_H8) return false;
+    if (L.d.ksize == 3 && L.d.stride == 1 && L.mode == 0) return !add && (long)L.in_h * L.in_w >= FD_DW3_ROWS_MIN_PIXELS;
+    if (L.d.ksize == 3 && L.d.stride == 2 && L.mode == 0) return !(p->tune & (FD_TUNE_DW_FORCE_ROWS | FD_TUNE_DW_NO_ROWS));
+    return false;
+}
 // plan-time half of TLayer::bwd_fin: the unit's first backward kernel CAN finalise its BatchNorm backward (the LDS-tiled depthwise launches, the
 // apply pass of the 16-bit pointwise units); whether it does is decided per step by the number of partial rows its consumer left (finalize_or_defer)
 inline bool bwd_fin_candidate(const fd_train_plan *p, int i)
@@ -183,6 +202,7 @@ inline bool bwd_fin_candidate(const fd_train_plan *p, int i)
     if (L.d.op == FD_OP_PW) return p->esz == 2;           // (16-bit plans: the apply pass fd_bn_bwd_apply_fin_h16; any row count now that the rows are few)
     // (depthwise units: built and measured in round 4 with up to 128 fp32 partial rows, off by default -- bf16 step: the 10 launches it removed were 43 us, the
     // paired kernels got 40 us slower (163 VGPRs + 36 bytes of scratch in the 3x3 instance); fp32 step +26 us.  FD_TUNE_DW_BWD_FINALIZE turns it on: tests, A/B)
+    if (L.d.op == FD_OP_DW && FD_DW_ROWS_FIN && dw_bwd_row_kernel(p, i)) return true;     // (round 6: the row-walking kernels derive the coefficients in their prologue -- no registers carried through the walk)
     if (L.d.op == FD_OP_DW) return (p->tune & FD_TUNE_DW_BWD_FINALIZE) && !(p->flags & FD_PLAN_NO_BWD_PAIRING) && dw_bwd_has_pair(p, i) && !dw_bwd_on_rows(p, L);
     return false;
 }

@@ -187,11 +187,13 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     info = harness.LAST_LOCAL_INFO
     assert (info["dw_units_with_16bit_lds_patches"] > 0) == bool(flags & capi.FD_TUNE_FORCE_DW_H8)
     # round 6: in a bf16 plan the three 5x5 units on up2 + skip run their backward on the row-walking pixel-pair kernel (fd_dw5_bwd_rows) unless a flag
-    # asks for one of the LDS-tiled forms (or for the in-kernel BatchNorm-backward finalisation, which only those carry)
+    # asks for one of the LDS-tiled forms
     lds_forms = capi.FD_TUNE_DW_BWD1 | capi.FD_TUNE_DW_BWD_PAIR | capi.FD_TUNE_DW_BWD_FINALIZE | capi.FD_TUNE_NO_DW5_ROWS | capi.FD_PLAN_NO_BWD_PAIRING
     assert info["dw_units_on_dw5_bwd_rows"] == (3 if dtype == torch.bfloat16 and not flags & lds_forms else 0), info
     # ... and every 3x3 unit of the encoder on fd_dw3_bwd_rows (stride 1: 9 units) / fd_dw3s2_bwd_rows (stride 2: 4 units)
-    assert info["dw_units_backward_on_row_kernels"] == (16 if dtype == torch.bfloat16 and not flags & (lds_forms | capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_FORCE_ROWS) else 0), info
+    # (FD_TUNE_DW_FORCE_ROWS keeps the stride-2 units on the older two register-window kernels)
+    on_rows = 0 if dtype != torch.bfloat16 or flags & (lds_forms | capi.FD_TUNE_FORCE_DW_H8) else (12 if flags & capi.FD_TUNE_DW_FORCE_ROWS else 16)
+    assert info["dw_units_backward_on_row_kernels"] == on_rows, info
     assert info["dw_units_on_dw5_rows_train"] == (3 if dtype == torch.bfloat16 and not flags & (capi.FD_TUNE_NO_DW5_ROWS | capi.FD_TUNE_FORCE_DW_H8) else 0), info
     # the forms the flags ask for did run: gemm16 train GEMMs (every pointwise unit but the head), in-kernel finalisations forward / backward
     assert info["pw_units_on_gemm16"] == (18 if name.startswith("g16") else 0)
@@ -201,7 +203,8 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     elif flags & capi.FD_TUNE_DW_BWD_FINALIZE:
         assert info["units_finalising_their_own_backward"] >= (12 if dtype == torch.float32 else 24)      # depthwise units (+ the 16-bit pointwise ones)
     elif dtype == torch.bfloat16:
-        assert info["units_finalising_their_own_backward"] >= 10                                              # the apply pass of the 16-bit pointwise units
+        # the apply pass of the 16-bit pointwise units; + the depthwise units whose backward is a row-walking kernel (prologue: fd_bstat_table_block)
+        assert info["units_finalising_their_own_backward"] >= (20 if info["dw_units_backward_on_row_kernels"] else 10), info
     else:
         assert info["units_finalising_their_own_backward"] == 0
     if dtype == torch.bfloat16:
