@@ -1043,3 +1043,185 @@ fd_dw3s2_bwd_rows(const fd_dw3s2_bwd_args<T> a)
             a.wpart[(((long)n * a.wgs + blk.x) * 9 + t) * C + c0 + ch] = (red[(0 * 9 + t) * 64 + ch] + red[(1 * 9 + t) * 64 + ch]) + (red[(2 * 9 + t) * 64 + ch] + red[(3 * 9 + t) * 64 + ch]);
     }
 }
+
+// ======================================================================================================================================================
+// Train-mode FORWARD of the depthwise 3x3 units on plain inputs (every encoder unit; reference imagenet/mobilenet.py:31-33) for the 16-bit train plans:
+//   z_out = conv3x3_stride_S( act(z_in s + t) ),  raw, rounded to the storage type, + the workgroup's per-channel sums of the ROUNDED values added to the
+//   unit's statistics rows; fin.rows != null: the producer's BatchNorm is finalised in the prologue (fd_stat_table_block; workgroup (0, *, 0) writes).
+// The row-walking wave of fd_dw3_bwd_rows / fd_dw3s2_bwd_rows: a lane owns 2 adjacent channels x 4 adjacent OUTPUT columns, the activated input rows live
+// in an fp32 register window (nothing but the stored output is rounded), the taps are fp32 (v_fmac_f32: 2 issue cycles), no LDS staging, no barrier before
+// the end-of-kernel reduction.  S = 1: 6 input columns, one input row in / one output row out per step (3-row window).  S = 2: 9 input columns, two input
+// rows in per output row; the lower one is carried to the next step as its top row.
+// Replaces fd_dw3_rows_train (4 channels x 1 column per work-item, 3 x 3 loads per output) on the large maps and the LDS-tiled fd_dwconv_train on the small.
+// grid (wgs, channel blocks of 2 CL, images) through fd_xcd_image_map; block 256 = 4 independent waves; C % 8 == 0; S = 2: H, W even.
+// ======================================================================================================================================================
+template <typename T, int S, int ACT1, int CL>
+__global__ void __launch_bounds__(256)
+fd_dw3_rows_fwd(const T *__restrict__ zin, const float *__restrict__ st1, const float *__restrict__ wgt, T *__restrict__ zout, fd_stat_rows sr,
+                int H, int W, int Ho, int Wo, int C, int groups_x, int bh, const fd_bn_fin fin)
+{
+    constexpr int CB = 2 * CL, SPW = 64 / CL, NI = S == 1 ? 6 : 9;
+    __shared__ double sh[512];
+    __shared__ float s_st[2 * CB];
+    __shared__ float red[4 * 2 * CB];
+    const fd_blk3 blk = fd_xcd_image_map();
+    const int c0 = blk.y * CB, cend = c0 + CB < C ? c0 + CB : C, n = blk.z;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = blk.x * 4 + wave;
+    const int band = item / groups_x, sg = item - band * groups_x;
+    const int y0 = band * bh, y1 = y0 + bh < Ho ? y0 + bh : Ho;
+    const int l = lane % CL, xs = 4 * (SPW * sg + lane / CL), c = c0 + 2 * l;
+    const bool live = y0 < Ho && c < cend && xs < Wo;
+    if (fin.rows) fd_stat_table_block(fin, sh, s_st, c0, CB, C, (int)threadIdx.x, blk.x == 0 && blk.z == 0);
+    float ssum0 = 0.f, ssum1 = 0.f, ssq0 = 0.f, ssq1 = 0.f;
+    if (live) {
+        float w[3][3][2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[t / 3][t % 3][ch] = wgt[(long)(c + ch) * 9 + t];
+        float s1[2], t1[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (fin.rows) { s1[ch] = s_st[2 * l + ch]; t1[ch] = s_st[CB + 2 * l + ch]; }
+            else { s1[ch] = st1[FD_ST_SCALE * C + c + ch]; t1[ch] = st1[FD_ST_SHIFT * C + c + ch]; }
+        }
+        unsigned so[NI];                                     // byte offsets of the lane's input columns S xs - 1 ... in a row (outside the image: out of range)
+        bool pin[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int x = S * xs - 1 + i;
+            pin[i] = x >= 0 && x < W;
+            so[i] = pin[i] ? (fd_mul24((unsigned)x, (unsigned)C) + (unsigned)c) * 2u : FD_BUF_OOB;
+        }
+        const unsigned rowb = fd_mul24((unsigned)W, (unsigned)C) * 2u, rowo = fd_mul24((unsigned)Wo, (unsigned)C) * 2u, pxb = (unsigned)C * 2u;
+        const fd_bufrsrc r_in = fd_make_rsrc(zin + (long)n * H * W * C, (unsigned)H * rowb), r_out = fd_make_rsrc(zout + (long)n * Ho * Wo * C, (unsigned)Ho * rowo);
+        const unsigned oo = (fd_mul24((unsigned)xs, (unsigned)C) + (unsigned)c) * 2u;
+        // a loaded row -> activated fp32 values (zero padding of the ACTIVATED input: act(t) != 0 in general)
+        auto convert = [&](float (&dst)[NI][2], const unsigned (&src)[NI], bool rv) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const bool v = rv && pin[i];
+                const float a0 = fd_act<ACT1>(fmaf(fd_w16_lo(T{}, src[i]), s1[0], t1[0])), a1 = fd_act<ACT1>(fmaf(fd_w16_hi(T{}, src[i]), s1[1], t1[1]));
+                dst[i][0] = v ? a0 : 0.f; dst[i][1] = v ? a1 : 0.f;
+            }
+        };
+        auto emit = [&](const float (&acc)[4][2], int y) FD_INLINE_LAMBDA {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned packed = fd_pack2(T{}, acc[j][0], acc[j][1]);
+                if (xs + j < Wo) {
+                    fd_buf_st32(r_out, oo, (unsigned)y * rowo + (unsigned)j * pxb, packed);
+                    const float g0 = fd_w16_lo(T{}, packed), g1 = fd_w16_hi(T{}, packed);          // statistics of the stored (rounded) output
+                    ssum0 += g0; ssum1 += g1; ssq0 = fmaf(g0, g0, ssq0); ssq1 = fmaf(g1, g1, ssq1);
+                }
+            }
+        };
+        if constexpr (S == 1) {
+            // two rows in flight: at one or two waves per SIMD (the small maps) a step's load latency is not covered by the other waves
+            unsigned nx[2][NI];
+            bool nv[2] = {false, false};
+            auto issue = [&](auto B, int it) FD_INLINE_LAMBDA {  // step `it`: input row r = y0 - 1 + it enters, output row r - 1 (it >= 2) leaves
+                constexpr int b = decltype(B)::value;
+                const int r = y0 - 1 + it;
+                nv[b] = r >= 0 && r < H;
+                if (nv[b]) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) nx[b][i] = fd_buf_ld32(r_in, so[i], (unsigned)r * rowb);
+                }
+            };
+            float win[3][NI][2];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) { win[q][i][0] = 0.f; win[q][i][1] = 0.f; }
+            const int n_it = (y1 - y0) + 2;                      // >= 3
+            issue(fd_int<0>{}, 0);
+            issue(fd_int<1>{}, 1);
+            auto step = [&](auto PH, int it) FD_INLINE_LAMBDA {
+                constexpr int ph = decltype(PH)::value % 3, b = decltype(PH)::value % 2;
+                convert(win[ph], nx[b], nv[b]);
+                if (it + 2 < n_it) issue(fd_int<b>{}, it + 2);
+                if (it >= 2) {                                   // rows y - 1, y, y + 1 = slots (ph + 1) % 3, (ph + 2) % 3, ph
+                    float acc[4][2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                d0 = fmaf(win[(ph + 1 + ky) % 3][j + kx][0], w[ky][kx][0], d0);
+                                d1 = fmaf(win[(ph + 1 + ky) % 3][j + kx][1], w[ky][kx][1], d1);
+                            }
+                        acc[j][0] = d0; acc[j][1] = d1;
+                    }
+                    emit(acc, y0 + it - 2);
+                }
+            };
+            for (int it0 = 0; it0 < n_it; it0 += 6) {
+                step(fd_int<0>{}, it0);
+                if (it0 + 1 < n_it) step(fd_int<1>{}, it0 + 1);
+                if (it0 + 2 < n_it) step(fd_int<2>{}, it0 + 2);
+                if (it0 + 3 < n_it) step(fd_int<3>{}, it0 + 3);
+                if (it0 + 4 < n_it) step(fd_int<4>{}, it0 + 4);
+                if (it0 + 5 < n_it) step(fd_int<5>{}, it0 + 5);
+            }
+        } else {
+            unsigned nb[2][NI], nc[2][NI];                       // in flight: input rows 2 oy and 2 oy + 1 of the next TWO steps
+            auto issue = [&](auto B, int oy) FD_INLINE_LAMBDA {
+                constexpr int b = decltype(B)::value;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) { nb[b][i] = fd_buf_ld32(r_in, so[i], (unsigned)(2 * oy) * rowb); nc[b][i] = fd_buf_ld32(r_in, so[i], (unsigned)(2 * oy + 1) * rowb); }
+            };
+            float top[2][NI][2], mid[NI][2];                     // top[ph]: row 2 oy - 1 of this step; the step's row 2 oy + 1 lands in top[1 - ph]
+            {
+                const bool tv = y0 > 0;
+                unsigned tx[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) tx[i] = tv ? fd_buf_ld32(r_in, so[i], (unsigned)(2 * y0 - 1) * rowb) : 0u;
+                issue(fd_int<0>{}, y0);
+                if (y0 + 1 < y1) issue(fd_int<1>{}, y0 + 1);
+                convert(top[0], tx, tv);
+            }
+            auto step = [&](auto PH, int oy) FD_INLINE_LAMBDA {
+                constexpr int ph = decltype(PH)::value;
+                convert(mid, nb[ph], true);
+                convert(top[1 - ph], nc[ph], true);
+                if (oy + 2 < y1) issue(fd_int<ph>{}, oy + 2);
+                float acc[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        d0 = fmaf(top[ph][2 * j + kx][0], w[0][kx][0], d0); d1 = fmaf(top[ph][2 * j + kx][1], w[0][kx][1], d1);
+                        d0 = fmaf(mid[2 * j + kx][0], w[1][kx][0], d0); d1 = fmaf(mid[2 * j + kx][1], w[1][kx][1], d1);
+                        d0 = fmaf(top[1 - ph][2 * j + kx][0], w[2][kx][0], d0); d1 = fmaf(top[1 - ph][2 * j + kx][1], w[2][kx][1], d1);
+                    }
+                    acc[j][0] = d0; acc[j][1] = d1;
+                }
+                emit(acc, oy);
+            };
+            for (int oy = y0; oy < y1; oy += 2) {
+                step(fd_int<0>{}, oy);
+                if (oy + 1 < y1) step(fd_int<1>{}, oy + 1);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = CL; m < 64; m <<= 1) { ssum0 += __shfl_xor(ssum0, m); ssum1 += __shfl_xor(ssum1, m); ssq0 += __shfl_xor(ssq0, m); ssq1 += __shfl_xor(ssq1, m); }
+    if (lane < CL) {
+        red[(wave * 2 + 0) * CB + 2 * l] = ssum0; red[(wave * 2 + 0) * CB + 2 * l + 1] = ssum1;
+        red[(wave * 2 + 1) * CB + 2 * l] = ssq0; red[(wave * 2 + 1) * CB + 2 * l + 1] = ssq1;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 2 * CB) {
+        const int which = tid / CB, ch = tid % CB;
+        if (c0 + ch < cend) {
+            const float v = (red[(0 * 2 + which) * CB + ch] + red[(1 * 2 + which) * CB + ch]) + (red[(2 * 2 + which) * CB + ch] + red[(3 * 2 + which) * CB + ch]);
+            fd_stat_add<FD_STAT_FWD>(sr, (long)n * gridDim.x + blk.x, C, which, c0 + ch, v);
+        }
+    }
+}

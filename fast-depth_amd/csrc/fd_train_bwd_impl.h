@@ -245,7 +245,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             const int cl = L.d.cin <= 32 ? 16 : 32;          // channel lanes per strip: a 32-channel unit (conv1.0) would leave half of every wave idle at 32
             b.H = L.in_h; b.W = L.in_w; b.C = L.d.cin; b.groups_x = ceil_div(L.in_w, 4 * (64 / cl));
             // bands of ~14 rows on the large maps; the 14x14 / 7x7 maps take bands of 7 (twice the waves: their launches are latency-, not issue-bound)
-            const int bands = L.in_h <= 14 ? ceil_div(L.in_h, FD_DW3_ROWS_SMALL_BAND) : std::max(1, (L.in_h + 7) / 14);
+            const int bands = L.in_h <= 7 ? ceil_div(L.in_h, 4) : L.in_h <= 14 ? ceil_div(L.in_h, FD_DW3_ROWS_SMALL_BAND) : std::max(1, (L.in_h + 7) / 14);     // (7x7: 512 -> 1024 waves, -2.7 us)
             b.bh_d = b.bh_w = ceil_div(L.in_h, bands);
             b.wgs_d = b.wgs_w = ceil_div((long)b.groups_x * ceil_div(L.in_h, b.bh_d), 4);
             b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs_d * c.p->B);
@@ -271,7 +271,7 @@ int launch_dw_bwd_pair(BwdCtx &c, int i, int *nblk_out)
             fd_dw3s2_bwd_args<T> b{};
             b.G = a.G; b.Z = a.Z; b.Zin = a.Zin; b.SG = a.SG; b.Gin = a.Gin; b.coef = a.coef; b.w = a.w; b.st_in = a.st_in; b.wpart = a.wpart;
             b.Ho = L.out_h; b.Wo = L.out_w; b.C = L.d.cin; b.groups_x = ceil_div(L.out_w, 8);
-            const int bands = L.out_h <= 14 ? ceil_div(L.out_h, 4) : std::max(1, (L.out_h + 3) / 7);     // ~7 output rows (14 input rows) per band; the small maps take 4
+            const int bands = L.out_h <= 7 ? ceil_div(L.out_h, 2) : L.out_h <= 14 ? ceil_div(L.out_h, 4) : std::max(1, (L.out_h + 3) / 7);     // ~7 output rows (14 input rows) per band; the small maps take 4 / 2
             b.bh = ceil_div(L.out_h, bands);
             b.wgs = ceil_div((long)b.groups_x * ceil_div(L.out_h, b.bh), 4);
             b.sr = bwd_rows(c.p, L.d.src, (long)b.wgs * c.p->B);

@@ -16,6 +16,21 @@ int launch_dw_train(const TLayer &L, const T *zin, const float *st1, const T *zs
             return check_launch("fd_dw5_rows_train");
         }
     }
+    if (L.dw3_cl) {                                           // 16-bit plans, 3x3 on a plain input: row-walking fp32-window kernel (nothing rounded but the stored output)
+        if constexpr (!std::is_same<T, float>::value) {
+            const int key3 = L.d.stride * 100 + L.dw3_cl;
+#define FD_DW3F(S_, CL_)                                                                                                                                   \
+    case S_ * 100 + CL_:                                                                                                                                  \
+        FD_LAUNCH((fd_dw3_rows_fwd<T, S_, ACT1, CL_>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.dw3_groups, L.dw3_bh, fin); \
+        break;
+            switch (key3) {
+                FD_DW3F(1, 16) FD_DW3F(1, 32) FD_DW3F(2, 16) FD_DW3F(2, 32)
+            default: return fail(FD_ERR_STATE, "train: fd_dw3_rows_fwd has no instance for stride %d, %d channel lanes", L.d.stride, L.dw3_cl);
+            }
+#undef FD_DW3F
+            return check_launch("fd_dw3_rows_fwd");
+        }
+    }
     if (L.rows_th) {                                          // register-window kernel (3x3, plain input, large maps)
         if (L.d.stride == 1) FD_LAUNCH((fd_dw3_rows_train<T, 1, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th, fin);
         else FD_LAUNCH((fd_dw3_rows_train<T, 2, ACT1>), L.grid, dim3(256), 0, s, zin, st1, w, zout, part, L.in_h, L.in_w, L.out_h, L.out_w, L.d.cin, L.rows_th, fin);
@@ -313,12 +328,28 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.nblk = wgs * batch;
                 L.lds = 0;
             }
+            // 16-bit plans, 3x3 on a plain input (every encoder unit): the row-walking fp32-window kernel (fd_kernels_dw5p_bwd.h: fd_dw3_rows_fwd) -- bands of ~14 output
+            // rows at stride 1, ~7 at stride 2 (14 input rows); the 14x14 maps take 7, the 7x7 maps 4 (twice the waves: those launches are latency-bound)
+            if (h16 && d.ksize == 3 && L.mode == 0 && d.cin % 8 == 0 && (d.stride == 1 || (L.in_h % 2 == 0 && L.in_w % 2 == 0)) &&
+                (double)L.in_h * L.in_w * d.cin * 2.0 < 2147483648.0 &&
+                !(tune & (FD_TUNE_NO_DW5_ROWS | FD_TUNE_FORCE_DW_H8 | FD_TUNE_DW_NO_ROWS | FD_TUNE_DW_FORCE_ROWS))) {
+                L.rows_th = 0;
+                L.dw3_cl = d.cin <= 32 ? 16 : 32;                // (a 32-channel unit would leave half of every wave idle at 32 lanes per strip)
+                L.dw3_groups = ceil_div(L.out_w, 4 * (64 / L.dw3_cl));
+                const int tall = L.out_h <= 7 ? 4 : (L.out_h <= 14 ? 7 : (d.stride == 1 ? 14 : 7));
+                const int bands = std::max(1, (L.out_h + tall / 2) / tall);
+                L.dw3_bh = ceil_div(L.out_h, bands);
+                const int wgs = ceil_div((long)L.dw3_groups * ceil_div(L.out_h, L.dw3_bh), 4);
+                L.grid = dim3(wgs, ceil_div(d.cin, 2 * L.dw3_cl), batch);
+                L.nblk = wgs * batch;
+                L.lds = 0;
+            }
             if (L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && !(L.rows_th && d.cin > 256) &&
                 p->layers[d.src].nr_f <= (L.rows_th ? FD_STAT_FIN_MAX_ROWS_ALL : FD_STAT_FIN_MAX_ROWS_BLOCK)) {
                 // the producer's BatchNorm is finalised by this kernel's workgroups from the producer's statistics rows (fd_stat_table_block in the LDS-tiled
                 // kernel, which keeps the block's (scale, shift) behind its tap table; the register-window kernel holds all C <= 256 channels in its static LDS)
                 p->layers[d.src].fin_by_consumer = true;
-                if (!L.rows_th && !L.dw5_groups) L.lds += (size_t)2 * cb * 4;
+                if (!L.rows_th && !L.dw5_groups && !L.dw3_cl) L.lds += (size_t)2 * cb * 4;
             }
             const int fwd_tiles = ceil_div(L.out_w, L.btw) * ceil_div(L.out_h, L.bth) * batch;      // (tiles of the separate backward-weights kernel)
             {   // weight-gradient partial rows: one per forward tile (separate kernels) or one per INPUT-space backward tile (fd_dw_bwd1: 16 columns x
@@ -485,7 +516,7 @@ int fd_train_plan_unit_kernels(const fd_train_plan *plan, int32_t layer)
 {
     if (!plan || layer < 0 || layer >= (int)plan->layers.size()) return -1;
     const TLayer &L = plan->layers[layer];
-    return (L.pw16_tm ? 1 : 0) | (L.fin_by_consumer ? 2 : 0) | (L.bwd_fin_rows > 0 ? 4 : 0) | (L.bwd_rows ? 8 : 0) | (L.dw5_groups ? 16 : 0);
+    return (L.pw16_tm ? 1 : 0) | (L.fin_by_consumer ? 2 : 0) | (L.bwd_fin_rows > 0 ? 4 : 0) | (L.bwd_rows ? 8 : 0) | (L.dw5_groups ? 16 : 0) | (L.dw3_cl ? 32 : 0);
 }
 
 int fd_train_layer_tensor(const fd_train_plan *plan, int32_t layer, int32_t which, const void **device_ptr, int32_t *n, int32_t *h,

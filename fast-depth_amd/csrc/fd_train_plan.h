@@ -58,6 +58,7 @@ struct fd_train_layer {
     mutable int bwd_rows = 0;                                 // the LAST backward of this depthwise unit ran on a row-walking kernel (fd_dw5_bwd_rows / fd_dw3_bwd_rows)
     int bth = 0, btw = 0;                                     // output-space tile of the backward-weights kernel
     int rows_th = 0;                                          // > 0: the forward runs on fd_dw3_rows_train with row strips of this height
+    int dw3_cl = 0, dw3_groups = 0, dw3_bh = 0;               // dw3_cl > 0: the forward runs on fd_dw3_rows_fwd (16-bit plans, 3x3 on a plain input): channel lanes per strip, strip groups per row, output rows per band
     int dw5_groups = 0, dw5_bh = 0;                           // > 0: the forward runs on fd_dw5_rows_train (16-bit plans, 5x5 on up2 + skip): strip pairs per row, rows per band
     int stem_band = 0;                                        // floats of the stem kernels' input band in LDS
     int pstr = 0, bpstr = 0;                                  // LDS patch pitch (floats) of the forward / the backward depthwise kernels

@@ -53,8 +53,8 @@ int fd_train_plan_lds_rounding(const struct fd_train_plan *plan, int32_t layer);
 /* Test hook: which of the selectable forms unit `layer` of a train plan runs on -- bit 0: its forward pointwise GEMM is fd_pw_gemm16_f32 in train mode
  * (fp32 plans, one round of workgroups); bit 1: its BatchNorm statistics are finalised inside the consuming depthwise kernel (fd_bn_finalize_block);
  * bit 2: in the LAST backward its BatchNorm backward was finalised inside its own first backward kernel (fd_bn_bwd_apply_fin_h16 /
- * fd_bn_bwd_finalize_block); bit 3: its LAST backward ran on a row-walking depthwise kernel (fd_dw5_bwd_rows / fd_dw3_bwd_rows); bit 4: its forward runs on
- * fd_dw5_rows_train.  -1: bad arguments. */
+ * fd_bn_bwd_finalize_block); bit 3: its LAST backward ran on a row-walking depthwise kernel (fd_dw5_bwd_rows / fd_dw3_bwd_rows / fd_dw3s2_bwd_rows); bit 4: its forward runs on
+ * fd_dw5_rows_train; bit 5: on fd_dw3_rows_fwd.  -1: bad arguments. */
 int fd_train_plan_unit_kernels(const struct fd_train_plan *plan, int32_t layer);
 /* Measurement hook (tools/gpu_round.sh, bench.py with FD_BENCH_FORCE_DIST=2): fd_train_backward_allreduce runs everything -- bucket ranges, event
  * hand-over to the communicator's stream, casts, the wait of the compute stream -- EXCEPT the ncclAllReduce calls.  On one rank this separates the

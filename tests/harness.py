@@ -304,7 +304,7 @@ def local_train_parity(kind, model, x, target, device, dtype=torch.float32, flag
     tp.lib.fd_train_plan_unit_kernels.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     forms = [max(tp.lib.fd_train_plan_unit_kernels(tp.h, i), 0) for i in range(n)]
     rep_info = {"dw_units_with_16bit_lds_patches": sum(1 for v in lds_round if (v & 3) and not (v & (4 | 8))), "dw_units_on_dw5_bwd_rows": sum(1 for v in lds_round if v & 8), "dw_units_on_dw5_rows_train": sum(1 for v in lds_round if v & 4), "pw_units_on_gemm16": sum(1 for v in forms if v & 1),
-                "dw_units_backward_on_row_kernels": sum(1 for v in forms if v & 8), "units_finalised_by_consumer": sum(1 for v in forms if v & 2), "units_finalising_their_own_backward": sum(1 for v in forms if v & 4)}
+                "dw_units_backward_on_row_kernels": sum(1 for v in forms if v & 8), "dw_units_on_dw3_rows_fwd": sum(1 for v in forms if v & 32), "units_finalised_by_consumer": sum(1 for v in forms if v & 2), "units_finalising_their_own_backward": sum(1 for v in forms if v & 4)}
     consumers = {}
     for i in range(n):
         if L[i].desc.src >= 0:

@@ -194,6 +194,8 @@ def test_emulated_train_step_layer_local(name, plan, dtype, flags):
     # (FD_TUNE_DW_FORCE_ROWS keeps the stride-2 units on the older two register-window kernels)
     on_rows = 0 if dtype != torch.bfloat16 or flags & (lds_forms | capi.FD_TUNE_FORCE_DW_H8) else (12 if flags & capi.FD_TUNE_DW_FORCE_ROWS else 16)
     assert info["dw_units_backward_on_row_kernels"] == on_rows, info
+    # ... and the forward of all 13 encoder units on fd_dw3_rows_fwd
+    assert info["dw_units_on_dw3_rows_fwd"] == (13 if dtype == torch.bfloat16 and not flags & (capi.FD_TUNE_NO_DW5_ROWS | capi.FD_TUNE_FORCE_DW_H8 | capi.FD_TUNE_DW_FORCE_ROWS | capi.FD_TUNE_DW_NO_ROWS) else 0), info
     assert info["dw_units_on_dw5_rows_train"] == (3 if dtype == torch.bfloat16 and not flags & (capi.FD_TUNE_NO_DW5_ROWS | capi.FD_TUNE_FORCE_DW_H8) else 0), info
     # the forms the flags ask for did run: gemm16 train GEMMs (every pointwise unit but the head), in-kernel finalisations forward / backward
     assert info["pw_units_on_gemm16"] == (18 if name.startswith("g16") else 0)
