@@ -75,6 +75,14 @@ LAST_BUILD_MODE = ""
 def build(force=False, extra=()):
     """Returns the library path; LAST_BUILD_MODE says what happened ("compiled" / "reused: stamp == source hash")."""
     global LAST_BUILD_MODE
+    import fcntl
+    with open(os.path.join(os.path.dirname(OUT), ".build.lock"), "w") as lk:      # concurrent callers (parallel test workers): one compiles, the others wait and reuse
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build_locked(force, extra)
+
+
+def _build_locked(force, extra):
+    global LAST_BUILD_MODE
     if not force and not _stale(extra):
         LAST_BUILD_MODE = "reused (stamp %s == hash of the sources + flags in the tree)" % built_hash()
         return OUT

@@ -69,7 +69,7 @@ int bn_bwd_finalize(BwdCtx &c, int i)
 int finalize_or_defer(BwdCtx &c, int u)
 {
     TLayer &U = c.p->layers[u];
-    if (U.bwd_fin && U.nr_b <= FD_STAT_FIN_MAX_ROWS_BLOCK) { U.bwd_fin_rows = U.nr_b; return FD_OK; }     // (more rows: re-reading them in every workgroup costs more than the launch)
+    if (U.bwd_fin && U.nr_b <= (dw_bwd_row_kernel(c.p, u) ? FD_STAT_FIN_MAX_ROWS_ROWK : FD_STAT_FIN_MAX_ROWS_BLOCK)) { U.bwd_fin_rows = U.nr_b; return FD_OK; }     // (more rows: re-reading them in every workgroup costs more than the launch)
     U.bwd_fin_rows = 0;
     return bn_bwd_finalize(c, u);
 }

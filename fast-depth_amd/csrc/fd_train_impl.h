@@ -345,7 +345,7 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.lds = 0;
             }
             if (L.mode != 3 && !(tune & FD_TUNE_NO_CONSUMER_FINALIZE) && !(L.rows_th && d.cin > 256) &&
-                p->layers[d.src].nr_f <= (L.rows_th ? FD_STAT_FIN_MAX_ROWS_ALL : FD_STAT_FIN_MAX_ROWS_BLOCK)) {
+                p->layers[d.src].nr_f <= (L.rows_th ? FD_STAT_FIN_MAX_ROWS_ALL : ((L.dw3_cl || L.dw5_groups) ? FD_STAT_FIN_MAX_ROWS_ROWK : FD_STAT_FIN_MAX_ROWS_BLOCK))) {
                 // the producer's BatchNorm is finalised by this kernel's workgroups from the producer's statistics rows (fd_stat_table_block in the LDS-tiled
                 // kernel, which keeps the block's (scale, shift) behind its tap table; the register-window kernel holds all C <= 256 channels in its static LDS)
                 p->layers[d.src].fin_by_consumer = true;

@@ -124,6 +124,9 @@ template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reint
 #define FD_STAT_FIN_MAX_ROWS_ALL 2
 #define FD_STAT_FIN_MAX_ROWS_BLOCK 8
 #endif
+#ifndef FD_STAT_FIN_MAX_ROWS_ROWK
+#define FD_STAT_FIN_MAX_ROWS_ROWK 8       // ... the row-walking depthwise kernels (a few hundred fat workgroups per launch; 16 measured slower: DESIGN Appendix A)
+#endif
 inline int stat_nr(long nblk)
 {
     int nr = 1;

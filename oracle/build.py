@@ -10,6 +10,13 @@ LIB = os.path.join(OUT_DIR, "libfd_oracle.so")
 
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(OUT_DIR, ".lock"), "w") as lk:      # parallel test workers: one builds, the others wait and reuse
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
         return LIB
     cmd = ["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c99", "-Wall", SRC, "-o", LIB, "-lm"]

@@ -13,6 +13,13 @@ CLANG = os.environ.get("FD_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(OUT_DIR, ".lock"), "w") as lk:      # parallel test workers (pytest -n): one builds, the others wait and reuse
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "_obj"] + [os.path.join(HERE, "hipemu.h"),
                                                                 os.path.join(REPO, "include", "fastdepth_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
