@@ -209,7 +209,7 @@ def inference_profile(eng, x, steps, mfma_peak_tflops, cfg="infer"):
 # kernel families of the train step whose launches move a unit's activations once (fwd 1x + bwd 2x the inference bytes);
 # everything else (BatchNorm finalisation, partial reductions, operand packing) is overhead with no algorithmic traffic of its own
 _TRAIN_MAJOR = ("gemm_train", "fd_pw_gemm16_f32", "dwconv_train", "dw3_rows_train", "dw5_rows_train", "stem_train", "head_train", "dgrad", "wgrad", "head_bwd<", "fd_dw_bwd<", "fd_dw_bwd1<",
-                "fd_dw5_bwd_rows<", "fd_dw3_bwd_rows<", "fd_dw3s2_bwd_rows<", "dw3_rows_fwd", "fd_pw_bwd_")
+                "fd_dw5_bwd_rows<", "fd_dw3_bwd_rows<", "fd_dw3s2_bwd_rows<", "dw3_rows_fwd", "fd_pw_bwd_")       # ("wgrad" also matches fd_stem_wgrad_rows)
 _TRAIN_PAIRED = ("head_bwd<", "fd_dw_bwd<", "fd_dw_bwd1<", "fd_dw5_bwd_rows<", "fd_dw3_bwd_rows<", "fd_dw3s2_bwd_rows<", "fd_pw_bwd_")       # one launch = a unit's backward-data AND backward-weights pass
 
 

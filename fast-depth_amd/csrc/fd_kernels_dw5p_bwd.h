@@ -1225,3 +1225,102 @@ fd_dw3_rows_fwd(const T *__restrict__ zin, const float *__restrict__ st1, const 
         }
     }
 }
+
+// ======================================================================================================================================================
+// Stem backward-weights for the 16-bit train plans (conv_bn(3, 32, 2): imagenet/mobilenet.py:22-27; autograd of the dense 3x3 stride-2 convolution):
+//   dW[co][c][ky][kx] = sum over output pixels of dz[px][co] * x[c][2 oy - 1 + ky][2 ox - 1 + kx],   dz = A((G - c1) - (z - mu) c2) formed on load.
+// 864 MACs per output pixel, 0.35 GMAC per step at B = 32: nothing for the VALU (4 us of fp32 FMA issue) -- the MFMA kernel it replaces (fd_stem_wgrad: 256-pixel
+// blocks, 27 scalar stride-2 gathers per work-item into LDS, dz staged in LDS, two barriers per block) ran 55 us for 70 MB.  Here the row-walking wave again:
+// a lane owns 4 adjacent output channels (two 16-bit words of G / z) x 4 adjacent output columns and walks down a band of output rows; per row and input plane
+// it loads the 3 x 9 input values its 4 pixels touch (two aligned 16-byte loads + one scalar per input row; the 8 channel lanes of a column group read the same
+// addresses -- with 2 channels per lane and 16 lanes per group the texture path, not the VALU, was the bound: 32 us) and adds 4 x 9 x 4 products into its 27 x 4 accumulators.  No LDS, no barrier until the end-of-kernel reduction (column groups
+// by shuffle, waves through LDS); one partial row [Cout][27] per workgroup, reduced by fd_reduce_weights_batch_f32.
+// grid (wgs, images); block 256 = 4 independent waves (16 channel lanes x 4 column groups); Cout == 32, Wo % 16 == 0 is NOT required (Wo % 4 == 0 is), H = 2 Ho.
+// ======================================================================================================================================================
+// (200 VGPRs, two waves per SIMD: the compiler keeps all three planes' loads of a row in flight.  Held to three waves (168) it spills 140 bytes;
+// with 4 channels per lane -- half the redundant input loads -- the 108 accumulators leave one wave per SIMD: both measured slower or not at all)
+template <typename T, int CL, int CPL>  // CPL channels per lane (2 or 4), CL = Cout / CPL channel lanes; a wave = CL channel lanes x 64 / CL column groups of 4 output columns
+__global__ void __launch_bounds__(256)
+fd_stem_wgrad_rows(const float *__restrict__ x, const T *__restrict__ G, const T *__restrict__ Z, const float *__restrict__ coef, float *__restrict__ wpart,
+                   int H, int W, int groups_x, int bh)
+{
+    constexpr int C = CPL * CL, GPW = 64 / CL, NA = 27 * CPL, WPL = CPL / 2;
+    __shared__ float red[4 * NA * CL];
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int n = blockIdx.y;
+    const int wave = FD_UNIFORM((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    const int band = item / groups_x, sg = item - band * groups_x;
+    const int y0 = band * bh, y1 = y0 + bh < Ho ? y0 + bh : Ho;
+    const int l = lane % CL, ox0 = 4 * (GPW * sg + lane / CL), c = CPL * l;
+    const bool live = y0 < Ho && ox0 < Wo;
+    float acc[27][CPL];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int ch = 0; ch < CPL; ++ch) acc[t][ch] = 0.f;
+    if (live) {
+        float cA[CPL], c1[CPL], cM[CPL], c2[CPL];
+#pragma unroll
+        for (int ch = 0; ch < CPL; ++ch) { cA[ch] = coef[FD_CF_A * C + c + ch]; c1[ch] = coef[FD_CF_C1 * C + c + ch]; cM[ch] = coef[FD_CF_MU * C + c + ch]; c2[ch] = coef[FD_CF_C2 * C + c + ch]; }
+        const float *xn = x + (long)n * 3 * H * W + 2 * ox0;                  // column 2 ox0 of plane 0, row 0 (16-byte aligned: ox0 % 4 == 0)
+        const unsigned *gw = reinterpret_cast<const unsigned *>(G) + (((long)n * Ho * Wo + ox0) * C + c) / 2;
+        const unsigned *zw = reinterpret_cast<const unsigned *>(Z) + (((long)n * Ho * Wo + ox0) * C + c) / 2;
+        const bool left = ox0 > 0;
+        for (int oy = y0; oy < y1; ++oy) {
+            float dz[4][CPL];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long o = ((long)oy * Wo + j) * (C / 2);
+#pragma unroll
+                for (int q = 0; q < WPL; ++q) {
+                    const unsigned g = gw[o + q], z = zw[o + q];
+                    dz[j][2 * q] = fd_dz(fd_w16_lo(T{}, g), fd_w16_lo(T{}, z), cA[2 * q], c1[2 * q], cM[2 * q], c2[2 * q]);
+                    dz[j][2 * q + 1] = fd_dz(fd_w16_hi(T{}, g), fd_w16_hi(T{}, z), cA[2 * q + 1], c1[2 * q + 1], cM[2 * q + 1], c2[2 * q + 1]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float xw[3][9];                                               // input rows 2 oy - 1 ... 2 oy + 1, columns 2 ox0 - 1 ... 2 ox0 + 7 of plane p
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = 2 * oy - 1 + ky;
+                    const bool rv = iy >= 0;                                  // (iy <= 2 Ho - 1 = H - 1 always)
+                    const float *row = xn + ((long)p * H + (rv ? iy : 0)) * W;
+                    const fd_f32x4 a = fd_ld4(row), b = fd_ld4(row + 4);
+                    const float e = left ? row[-1] : 0.0f;
+                    xw[ky][0] = rv ? e : 0.f;
+                    xw[ky][1] = rv ? a.x : 0.f; xw[ky][2] = rv ? a.y : 0.f; xw[ky][3] = rv ? a.z : 0.f; xw[ky][4] = rv ? a.w : 0.f;
+                    xw[ky][5] = rv ? b.x : 0.f; xw[ky][6] = rv ? b.y : 0.f; xw[ky][7] = rv ? b.z : 0.f; xw[ky][8] = rv ? b.w : 0.f;
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int ch = 0; ch < CPL; ++ch)
+                                acc[(p * 3 + ky) * 3 + kx][ch] = fmaf(dz[j][ch], xw[ky][2 * j + kx], acc[(p * 3 + ky) * 3 + kx][ch]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int ch = 0; ch < CPL; ++ch)
+#pragma unroll
+            for (int m = CL; m < 64; m <<= 1) acc[t][ch] += __shfl_xor(acc[t][ch], m);
+    if (lane < CL) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int ch = 0; ch < CPL; ++ch) red[(wave * NA + CPL * t + ch) * CL + l] = acc[t][ch];
+    }
+    __syncthreads();
+    float *o = wpart + ((long)n * gridDim.x + blockIdx.x) * (C * 27);
+    for (int i = threadIdx.x; i < NA * CL; i += 256) {
+        const int q = i / CL, ll = i % CL, t = q / CPL, ch = q % CPL;         // q = CPL t + ch
+        o[(CPL * ll + ch) * 27 + t] = (red[(0 * NA + q) * CL + ll] + red[(1 * NA + q) * CL + ll]) + (red[(2 * NA + q) * CL + ll] + red[(3 * NA + q) * CL + ll]);
+    }
+}

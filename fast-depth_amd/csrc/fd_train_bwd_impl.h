@@ -572,6 +572,21 @@ int train_backward_t(fd_train_plan *plan, const fd_layer_params *params, const f
             const int nb_w = std::min(nblocks_w, 512);       // workgroups walk them grid-stride
             if (d.cout > 64) return fail(FD_ERR_INVALID, "stem weight gradient supports at most 64 output channels");
             float *wpart = tws(plan, L.wp_off);
+            if constexpr (!F32) {
+                // 16-bit plans, the 32-channel stem: row-walking fp32 kernel (fd_kernels_dw5p_bwd.h: fd_stem_wgrad_rows), one partial row per workgroup
+                if (L.dw3_groups) {
+                    const int wgs = ceil_div((long)L.dw3_groups * ceil_div(L.out_h, L.dw3_bh), 4), rows_w = wgs * plan->B;
+                    if ((size_t)rows_w * 27 * d.cout > L.wp_elems) return fail(FD_ERR_STATE, "stem weight-gradient partial region too small");
+#define FD_STEMW(CL_)                                                                                                                                     \
+    FD_LAUNCH((fd_stem_wgrad_rows<T, CL_, FD_STEMW_CPL>), dim3((unsigned)wgs, (unsigned)plan->B), dim3(256), 0, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), \
+              twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, L.in_h, L.in_w, L.dw3_groups, L.dw3_bh)
+                    if (d.cout == 32) FD_STEMW(32 / FD_STEMW_CPL); else if (d.cout == 16) FD_STEMW(16 / FD_STEMW_CPL); else FD_STEMW(8 / FD_STEMW_CPL);
+#undef FD_STEMW
+                    if ((rc = check_launch("fd_stem_wgrad_rows"))) return rc;
+                    if ((rc = defer_weights(c, wpart, rows_w, 27 * d.cout, 0, 0, grads[i].conv_weight))) return rc;
+                    break;
+                }
+            }
             FD_LAUNCH((fd_stem_wgrad<T>), dim3(nb_w), dim3(256), (size_t)(256 * 33 + 256 * (d.cout + 1)) * 4, s, static_cast<const float *>(plan->x_saved), twt<T>(plan, L.g_off), twt<T>(plan, L.z_off), tws(plan, L.coef_off), wpart, plan->B, L.in_h, L.in_w, d.cout, nblocks_w);
             if ((rc = check_launch("fd_stem_wgrad"))) return rc;
             if ((rc = defer_weights(c, wpart, nb_w, 27 * d.cout, 0, 0, grads[i].conv_weight))) return rc;

@@ -261,6 +261,14 @@ int fd_train_plan_create(const fd_layer_desc *layers, int32_t n_layers, int32_t 
                 L.nblk = bpi * batch;
             }
             L.wp_elems = (size_t)std::min(L.nblk, 512) * 27 * d.cout;
+            // 16-bit plans, 32 / 16 / 8 output channels: the backward-weights pass runs on the row-walking kernel fd_stem_wgrad_rows (bands of ~7 output rows, 16 output
+            // columns per wave); dw3_groups / dw3_bh carry its column groups per row and rows per band
+            if (h16 && (d.cout == 32 || d.cout == 16 || d.cout == 8) && L.out_w % 4 == 0 && L.in_h == 2 * L.out_h && L.in_w == 2 * L.out_w && !(tune & FD_TUNE_NO_DW5_ROWS)) {
+                L.dw3_groups = ceil_div(L.out_w, 4 * (64 / (d.cout / FD_STEMW_CPL)));     // a wave: cout / FD_STEMW_CPL channel lanes, the rest of its 64 lanes column groups of 4 output columns
+                L.dw3_bh = ceil_div(L.out_h, std::max(1, (L.out_h + FD_STEMW_BAND / 2) / FD_STEMW_BAND));
+                const long rows_w = (long)ceil_div((long)L.dw3_groups * ceil_div(L.out_h, L.dw3_bh), 4) * batch;
+                L.wp_elems = std::max(L.wp_elems, (size_t)rows_w * 27 * d.cout);
+            }
             break;
         case FD_OP_DW: {
             if (d.src < 0 || d.cin != d.cout || (d.ksize != 3 && d.ksize != 5) || (d.stride != 1 && d.stride != 2) || d.cin % 4) FD_BAD("layer %d: bad depthwise", i);

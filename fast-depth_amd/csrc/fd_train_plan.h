@@ -124,6 +124,12 @@ template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reint
 #define FD_STAT_FIN_MAX_ROWS_ALL 2
 #define FD_STAT_FIN_MAX_ROWS_BLOCK 8
 #endif
+#ifndef FD_STEMW_BAND
+#define FD_STEMW_BAND 14                // output rows per band of fd_stem_wgrad_rows
+#endif
+#ifndef FD_STEMW_CPL
+#define FD_STEMW_CPL 2                  // output channels per lane of fd_stem_wgrad_rows (2 or 4)
+#endif
 #ifndef FD_STAT_FIN_MAX_ROWS_ROWK
 #define FD_STAT_FIN_MAX_ROWS_ROWK 8       // ... the row-walking depthwise kernels (a few hundred fat workgroups per launch; 16 measured slower: DESIGN Appendix A)
 #endif
