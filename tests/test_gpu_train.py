@@ -258,7 +258,7 @@ def test_in_kernel_batchnorm_finalisations_batch32(dtype):
     """Round 5: every unit's kernels ADD their BatchNorm partial sums into the unit's statistics rows (64-bit integer atomics, fd_stat_add); where those rows are
     few (the maps up to 28 x 28 at batch 32: <= 2 rows for a pointwise / register-window / head consumer, <= 8 for an LDS-tiled depthwise consumer or the
     16-bit apply pass) the CONSUMER's workgroups derive their coefficients from them in their prologue and no finalisation launch exists: 25 of the 38 forward
-    finalisations and, in the bf16 plan, the backward finalisations of the pointwise units on those maps.  Asserted: the launch census of both plans, and that
+    finalisations and, in the bf16 plan, the backward finalisations of the pointwise units on those maps (round 6: and of the depthwise units on row-walking kernels).  Asserted: the launch census of both plans, and that
     the step computes what the plan with every finalisation as its own launch (FD_TUNE_NO_CONSUMER_FINALIZE) computes: both read the same integers; a consumer
     that deals a channel's rows to several work-items adds their doubles in a different order, so the tables agree to the last float bit or the one next to
     it -- prediction to 1e-4 (fp32) / 2e-2 (bf16: re-rounding noise) of its scale, the 114 gradient tensors to 1e-2 / 1e-1 in norm."""
@@ -275,8 +275,11 @@ def test_in_kernel_batchnorm_finalisations_batch32(dtype):
     assert 10 <= count(names, "fd_bn_finalize_rows_f32") <= 13
     if dtype == torch.bfloat16:
         fin = count(names, "fd_bn_bwd_apply_fin_h16")
-        assert fin >= 12 and fin + count(names, "fd_bn_bwd_apply_h16") == 18 and count(names, "fd_bn_bwd_finalize_rows_f32") == 38 - fin
-        assert len(names) == len(names_sep) - (38 - count(names, "fd_bn_finalize_rows_f32")) - fin
+        # backward: every pointwise unit in its apply pass; round 6: the depthwise units whose backward is a row-walking kernel and whose rows are <= 8 (conv4.0 ...
+        # conv13.0, decode_conv3.0: 11 units) in that kernel's prologue; the stem, conv1.0 - conv3.0, decode_conv1.0 / 2.0 / 4.0 / 5.0 and the head keep a launch
+        bwd_launches = count(names, "fd_bn_bwd_finalize_rows_f32")
+        assert fin >= 12 and fin + count(names, "fd_bn_bwd_apply_h16") == 18 and 38 - fin - 13 <= bwd_launches <= 38 - fin - 9
+        assert len(names) == len(names_sep) - (38 - count(names, "fd_bn_finalize_rows_f32")) - (38 - bwd_launches)
     else:
         assert count(names, "fd_bn_bwd_finalize_rows_f32") == 38 and len(names) == len(names_sep) - (38 - count(names, "fd_bn_finalize_rows_f32"))
         assert count(names, "fd_pw_gemm16_f32") == 9 and count(names_sep, "fd_pw_gemm16_f32") == 9      # conv6.3 ... conv13.3, decode_conv1.1: the fp32 forward GEMMs in train mode
