@@ -530,8 +530,8 @@ __device__ __forceinline__ unsigned fd_pair_sum(fd_bf16, unsigned a, unsigned b)
 // (forward) / 2^16 (backward) per PARTIAL the value saturates -- a diverged network).  The total of a column is then the EXACT sum of the fp32 partials,
 // reconstructed in double from the three bins (fd_stat_total).
 // One address takes an atomic every ~22 ns whatever the scope (tools/microbench/stat_atomics.hip, MI355X: 6272 workgroups x 128 columns into ONE row
-// 135 us, into 8 rows 18 us), so a unit's partials are dealt to nr rows (a power of two <= 16, chosen by the plan so that an address sees <= ~256
-// adds: row = workgroup number & (nr - 1)) and the consumer adds the nr x 3 integers of a column.
+// 135 us, into 8 rows 18 us), so a unit's partials are dealt to nr rows (a power of two <= 16, chosen by the plan so that an address sees <= ~128
+// adds (FD_STAT_ADDS_PER_ROW, fd_train_plan.h): row = workgroup number & (nr - 1)) and the consumer adds the nr x 3 integers of a column.
 // Layout of a unit's rows: int64 [nr][FD_STAT_BINS][2][cs]  (2 = first / second sum; cs = channel pitch >= C, a multiple of 16: the memory side
 // serialises atomics per 128-byte LINE and instruction, so no two (row, bin, sum) slots share a line).  The plan zeroes all rows of a step with one memset.
 #define FD_STAT_BINS 3

@@ -252,6 +252,24 @@ fd_bn_bwd_apply_fin_h16(const T *G, T *DZ, const T *__restrict__ Z, int M, int N
 // Backward-data:  G_in[M][K] = mask_in(y_in) * (dz[M][N] x W[N][K] (+ skipgrad)),  + the producer's BN partials.
 // Main loop = fd_pw_gemm_h16 with A = dz (row pitch N), B = wtt[K][N64].  Epilogue: the fp32 accumulators are transposed
 // through LDS so that z_in / skipgrad are read and G_in is written 8 channels (16 bytes) per lane.
+// measurement aid (tools/pw_bwd_phases.py, built with -DFD_PW_PROBE; nothing in product builds): 100 MHz real-time stamps of a workgroup's phases in the
+// paired 16-bit pointwise backward launch, for the unit whose (M, N, K) was selected.  Slot b = blockIdx.x: [0] role (1 backward-data, 2 weight-gradient),
+// [1..5] stamps, [6] / [7] ticks accumulated in the weight-gradient loop before / after its second barrier (staging incl. the wait for the loads / MFMAs)
+#ifdef FD_PW_PROBE
+#define FD_PW_PROBE_SLOTS 16384
+__device__ long long fd_pw_probe[8 * FD_PW_PROBE_SLOTS];
+__device__ int fd_pw_probe_sel[3];
+#define FD_PW_PROBE_ON(M_, N_, K_) (threadIdx.x == 0 && blockIdx.x < FD_PW_PROBE_SLOTS && (M_) == fd_pw_probe_sel[0] && (N_) == fd_pw_probe_sel[1] && (K_) == fd_pw_probe_sel[2])
+#define FD_PW_PROBE_AT(on, k) do { if (on) fd_pw_probe[8 * blockIdx.x + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define FD_PW_PROBE_SET(on, k, v) do { if (on) fd_pw_probe[8 * blockIdx.x + (k)] = (long long)(v); } while (0)
+#define FD_PW_PROBE_NOW() ((long long)__builtin_amdgcn_s_memrealtime())
+#else
+#define FD_PW_PROBE_ON(M_, N_, K_) false
+#define FD_PW_PROBE_AT(on, k) ((void)0)
+#define FD_PW_PROBE_SET(on, k, v) ((void)0)
+#define FD_PW_PROBE_NOW() 0LL
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // bytes of the LDS-DMA ring: min(FD_H16_STAGES, N tiles) stages of (64 + 64*TN) 128-byte rows, at least the epilogue's four fp32 [32][36] tiles
 #define FD_PW_DGRAD_H16_RING(N64_, TN_) ((size_t)(((N64_) < 64 * FD_H16_STAGES ? (N64_) / 64 : FD_H16_STAGES) * (64 + 64 * (TN_)) * 128 > 4 * 32 * 36 * 4 ? ((N64_) < 64 * FD_H16_STAGES ? (N64_) / 64 : FD_H16_STAGES) * (64 + 64 * (TN_)) * 128 : 4 * 32 * 36 * 4))
@@ -272,6 +290,8 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
     if (mt >= m_tiles) return;
     const long m0 = (long)mt * BM;
     const int k0 = kt * BKO;
+    const bool probe = FD_PW_PROBE_ON(M, N, K);
+    FD_PW_PROBE_SET(probe, 0, 1); FD_PW_PROBE_AT(probe, 1);
     const T *src[RG];
     int src_n[RG];
     bool src_is_a[RG];
@@ -334,6 +354,7 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
     }
     issue(0);
     if (FD_H16_STAGES > 2 && Tn > 1) issue(1);
+    FD_PW_PROBE_AT(probe, 2);
     for (int t = 0; t < Tn; ++t) {
         if (FD_H16_STAGES > 2 && t + 1 < Tn) fd_wait_vmcnt<RG>(); else fd_wait_vmcnt<0>();
         fd_block_barrier();
@@ -347,6 +368,7 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
         }
     }
     // epilogue, one 32-column tile of the wave at a time: fp32 tile [32][36] per wave
+    FD_PW_PROBE_AT(probe, 3);
     __syncthreads();
     float *tile = reinterpret_cast<float *>(smem) + wave * 32 * 36;
 #pragma unroll
@@ -407,11 +429,13 @@ fd_pw_dgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Wtt, const 
         }
         fd_wave_lds_fence();                                      // the next tile overwrites the wave's LDS tile
     }
+    FD_PW_PROBE_AT(probe, 4);
     __syncthreads();
     if (tid < BKO && k0 + tid < K) {
         fd_stat_add<FD_STAT_BWD>(sr, mt, K, 0, k0 + tid, red[0 * BKO + tid] + red[2 * BKO + tid]);
         fd_stat_add<FD_STAT_BWD>(sr, mt, K, 1, k0 + tid, red[1 * BKO + tid] + red[3 * BKO + tid]);
     }
+    FD_PW_PROBE_AT(probe, 5);
 }
 
 template <typename T, int ACT_IN, int ADD_SG, int TN = 1>
@@ -449,6 +473,9 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
     const long mbeg = (long)by * rows_per_split;
     long mend = mbeg + rows_per_split; if (mend > M) mend = M;
     const int Tn = (int)((mend - mbeg + BR - 1) / BR);
+    const bool probe = FD_PW_PROBE_ON(M, N, K);
+    long long pr_stage = 0, pr_mfma = 0;
+    FD_PW_PROBE_SET(probe, 0, 2); FD_PW_PROBE_AT(probe, 1);
     // loader mapping: chunk cc = tid & 7 (8 columns), rows lr and lr + 32 of the 64-pixel step
     const int cc = tid & 7, lr = tid >> 3;
     const int ncol = n0 + cc * 8;
@@ -512,12 +539,15 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
     // 500 us for the paired family: the step is bound by the transposing staging writes and the two barriers, not by the loads)
     if (Tn > 0) load(0);
     if (FD_PW_WGRAD_H16_BUFS > 1 && Tn > 0) { stage(0); __syncthreads(); }
+    FD_PW_PROBE_AT(probe, 2);
     for (int t = 0; t < Tn; ++t) {
+        const long long pr_t0 = probe ? FD_PW_PROBE_NOW() : 0;
         if (FD_PW_WGRAD_H16_BUFS == 1) {
             __syncthreads();                                      // the previous step's fragment reads are done
             stage(t);
             __syncthreads();
         }
+        const long long pr_t1 = probe ? FD_PW_PROBE_NOW() : 0;
         if (t + 1 < Tn) load(t + 1);                              // in flight during the MFMAs
         const unsigned char *s_dz = smem_w + (FD_PW_WGRAD_H16_BUFS > 1 ? (t & 1) * SET : 0), *s_a = s_dz + BR * PITCH;
 #pragma unroll
@@ -536,7 +566,10 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
             if (t + 1 < Tn) stage(t + 1);
             __syncthreads();
         }
+        if (probe) { const long long pr_t2 = FD_PW_PROBE_NOW(); pr_stage += pr_t1 - pr_t0; pr_mfma += pr_t2 - pr_t1; }
     }
+    FD_PW_PROBE_AT(probe, 3);
+    FD_PW_PROBE_SET(probe, 6, pr_stage); FD_PW_PROBE_SET(probe, 7, pr_mfma);
     float *o = wpart + (long)by * N * K;
     const int rbn = n0 + wn * 32 + 4 * (lane >> 5);
 #pragma unroll
@@ -550,6 +583,7 @@ fd_pw_wgrad_h16_body(const T *__restrict__ DZ, const T *__restrict__ Zin, const 
             }
         }
     }
+    FD_PW_PROBE_AT(probe, 4);
 }
 template <typename T, int ACT_IN, int TN = 1>
 __global__ void __launch_bounds__(256)
@@ -563,18 +597,22 @@ fd_pw_wgrad_h16(const T *__restrict__ DZ, const T *__restrict__ Zin, const float
 // One launch for BOTH backward GEMMs of a pointwise unit (they share the operand dz and are independent of each other; as two launches on one
 // stream they serialise, and on the 14x14 / 7x7 maps each is a single round of workgroups bound by its own latency chain).  1-D grid: the
 // backward-data workgroups first (their partial rows feed the BatchNorm finalisation that follows on the critical path), then the
-// n_w = tiles x splits weight-gradient workgroups.  LDS (dynamic) and registers are those of the larger role.
+// n_w = tiles x splits weight-gradient workgroups -- or, round 6, the weight-gradient workgroups first where they are the fewer (n_w > 0): they live 9-15 us against
+// the tiles' 3.5-9, and dispatched last they leave every slot one long workgroup to finish (family 484 -> 462 us).  LDS (dynamic) and registers are those of the larger role.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int ACT_IN, int ADD_SG, int TN>
 __global__ void __launch_bounds__(256)
 fd_pw_bwd_h16(const T *__restrict__ DZ, const T *__restrict__ Wtt, const T *__restrict__ Zin, const float *__restrict__ st_in,
               const T *__restrict__ SG, T *__restrict__ Gin, fd_stat_rows sr, float *__restrict__ wpart,
-              int M, int N, int K, int N64, int m_tiles, int k_tiles_d, int n_dgrad, int k_tiles_w, int tiles_w, int rows_per_split)
+              int M, int N, int K, int N64, int m_tiles, int k_tiles_d, int n_dgrad, int k_tiles_w, int tiles_w, int rows_per_split, int n_w)
 {
-    if ((int)blockIdx.x < n_dgrad) {
-        fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, sr, M, N, K, N64, m_tiles, k_tiles_d, blockIdx.x);
+    // (n_w > 0: the weight-gradient workgroups take the FIRST n_w numbers -- they live 9-15 us against the backward-data tiles' 4-10 (profiles/r06/
+    // pw_bwd_h16_phase_table.txt): dispatched last they leave a tail of one long workgroup per slot at the end of the launch)
+    const int first_d = n_w > 0 ? n_w : 0;
+    if ((int)blockIdx.x >= first_d && (int)blockIdx.x < first_d + n_dgrad) {
+        fd_pw_dgrad_h16_body<T, ACT_IN, ADD_SG, TN>(DZ, Wtt, Zin, st_in, SG, Gin, sr, M, N, K, N64, m_tiles, k_tiles_d, blockIdx.x - first_d);
     } else {
-        const int b = (int)blockIdx.x - n_dgrad;
+        const int b = n_w > 0 ? (int)blockIdx.x : (int)blockIdx.x - n_dgrad;
         const int by = b / tiles_w;
         fd_pw_wgrad_h16_body<T, ACT_IN, 1>(DZ, Zin, st_in, wpart, M, N, K, k_tiles_w, rows_per_split, b - by * tiles_w, by);
     }

@@ -22,3 +22,19 @@
 
 #include "fd_host_common.h"
 #include "fd_train_bwd_impl.h"
+
+#ifdef FD_PW_PROBE
+// measurement aid (tools/pw_bwd_phases.py): select the unit whose paired pointwise backward launch is stamped, read the stamps back
+extern "C" int fd_pw_probe_select(int M, int N, int K)
+{
+    const int sel[3] = {M, N, K};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fd_pw_probe_sel), sel, sizeof sel) != hipSuccess) return -1;
+    static long long zero[8 * FD_PW_PROBE_SLOTS];
+    return hipMemcpyToSymbol(HIP_SYMBOL(fd_pw_probe), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+extern "C" int fd_pw_probe_read(long long *host, int slots)
+{
+    if (slots > FD_PW_PROBE_SLOTS) slots = FD_PW_PROBE_SLOTS;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(fd_pw_probe), (size_t)slots * 8 * sizeof(long long)) == hipSuccess ? slots : -1;
+}
+#endif

@@ -435,7 +435,7 @@ int launch_pw_bwd_h16(BwdCtx &c, int i, int *nblk)
         (void)hipFuncSetAttribute((const void *)fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
         FD_LAUNCH((fd_pw_bwd_h16<T, ACT_IN, ADDV, TNV>), dim3(n_dgrad + (unsigned)(tiles_w * splits)), dim3(256), lds, c.s, G, twt<T>(c.p, L.wtt_off), twt<T>(c.p, P.z_off), \
                   tws(c.p, P.st_off), ADDV ? twt<T>(c.p, P.sg_off) : (const T *)nullptr, twt<T>(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, L.n64, \
-                  m_tiles, k_tiles, (int)n_dgrad, k_tiles_w, tiles_w, rows);                                                                       \
+                  m_tiles, k_tiles, (int)n_dgrad, k_tiles_w, tiles_w, rows, (FD_PW_BWD_W_FIRST && (unsigned)(tiles_w * splits) < n_dgrad) ? tiles_w * splits : 0); \
     } while (0)
         if (add) { if (tn == 2) FD_PWBWD_H16(1, 2); else FD_PWBWD_H16(1, 1); }
         else { if (tn == 2) FD_PWBWD_H16(0, 2); else FD_PWBWD_H16(0, 1); }

@@ -124,6 +124,9 @@ template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reint
 #define FD_STAT_FIN_MAX_ROWS_ALL 2
 #define FD_STAT_FIN_MAX_ROWS_BLOCK 8
 #endif
+#ifndef FD_PW_BWD_W_FIRST
+#define FD_PW_BWD_W_FIRST 1             // paired 16-bit pointwise backward: the (long-lived) weight-gradient workgroups are numbered before the backward-data tiles where they are the fewer
+#endif
 #ifndef FD_STEMW_BAND
 #define FD_STEMW_BAND 14                // output rows per band of fd_stem_wgrad_rows
 #endif
