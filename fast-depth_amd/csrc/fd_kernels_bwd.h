@@ -684,12 +684,14 @@ __global__ void __launch_bounds__(256)
 fd_pw_bwd_f32(const float *__restrict__ G, const float *__restrict__ Z, const float *__restrict__ coef,
               const float *__restrict__ Wt, const float *__restrict__ Zin, const float *__restrict__ st_in,
               const float *__restrict__ SG, float *__restrict__ Gin, fd_stat_rows sr, float *__restrict__ wpart,
-              int M, int N, int K, int m_tiles, int k_tiles, int n_dgrad, int tiles_w, int rows_per_split)
+              int M, int N, int K, int m_tiles, int k_tiles, int n_dgrad, int tiles_w, int rows_per_split, int n_w)
 {
-    if ((int)blockIdx.x < n_dgrad) {
-        fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, sr, M, N, K, m_tiles, k_tiles, blockIdx.x);
+    // (n_w > 0: the longer-lived weight-gradient workgroups take the first n_w numbers -- see fd_pw_bwd_h16, fd_kernels_train_h16.h)
+    const int first_d = n_w > 0 ? n_w : 0;
+    if ((int)blockIdx.x >= first_d && (int)blockIdx.x < first_d + n_dgrad) {
+        fd_pw_dgrad_f32_body<ACT_IN, ADD_SG>(G, Z, coef, Wt, Zin, st_in, SG, Gin, sr, M, N, K, m_tiles, k_tiles, blockIdx.x - first_d);
     } else {
-        const int b = (int)blockIdx.x - n_dgrad;
+        const int b = n_w > 0 ? (int)blockIdx.x : (int)blockIdx.x - n_dgrad;
         const int by = b / tiles_w;
         fd_pw_wgrad_f32_body<ACT_IN>(G, Z, coef, Zin, st_in, wpart, M, N, K, k_tiles, rows_per_split, b - by * tiles_w, by);
     }

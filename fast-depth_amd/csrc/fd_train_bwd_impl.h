@@ -490,14 +490,15 @@ int launch_pw_bwd(BwdCtx &c, int i, int *nblk)
         const size_t lds = std::max(lds_w, lds_d);
         const int tiles_w = n_tiles * k_tiles;
         const dim3 grid(n_dgrad + (unsigned)(tiles_w * splits));
+        const int n_w = (FD_PW_BWD_W_FIRST_F32 && (unsigned)(tiles_w * splits) < n_dgrad) ? tiles_w * splits : 0;
         if (add) {
             (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 1>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+                      tws(c.p, P.sg_off), tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows, n_w);
         } else {
             (void)hipFuncSetAttribute((const void *)fd_pw_bwd_f32<ACT_IN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FD_LAUNCH((fd_pw_bwd_f32<ACT_IN, 0>), grid, dim3(256), lds, c.s, G, Z, coef, c.params[i].conv_weight, tws(c.p, P.z_off), tws(c.p, P.st_off),
-                      (const float *)nullptr, tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows);
+                      (const float *)nullptr, tws(c.p, P.g_off), bwd_rows(c.p, L.d.src, m_tiles), tws(c.p, L.wp_off), M, N, K, m_tiles, k_tiles, (int)n_dgrad, tiles_w, rows, n_w);
         }
         if ((rc = check_launch("fd_pw_bwd_f32"))) return rc;
         return defer_weights(c, tws(c.p, L.wp_off), splits, N * K, 0, 0, c.grads[i].conv_weight);

@@ -127,6 +127,9 @@ template <typename T> inline T *twt(fd_train_plan *p, size_t off) { return reint
 #ifndef FD_PW_BWD_W_FIRST
 #define FD_PW_BWD_W_FIRST 1             // paired 16-bit pointwise backward: the (long-lived) weight-gradient workgroups are numbered before the backward-data tiles where they are the fewer
 #endif
+#ifndef FD_PW_BWD_W_FIRST_F32
+#define FD_PW_BWD_W_FIRST_F32 1         // the same numbering in the fp32 paired launch (fd_pw_bwd_f32)
+#endif
 #ifndef FD_STEMW_BAND
 #define FD_STEMW_BAND 14                // output rows per band of fd_stem_wgrad_rows
 #endif
